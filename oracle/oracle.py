@@ -1,0 +1,204 @@
+"""ctypes front-end of oracle/icon_oracle.c - TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module;
+nothing under icon_amd/ does (tests/test_no_oracle_in_product.py enforces it).
+
+Each function takes/returns numpy arrays with the reference's tensor shapes minus the batch
+dimension (batch size is 1 on this path, lib/common/seg3d_lossless.py:73).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "icon_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        try:
+            _lib = C.CDLL(_SO)
+        except OSError:
+            build(force=True)
+            _lib = C.CDLL(_SO)
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_point_tri_dist2.restype = C.c_float
+        _lib.orc_ray_hit.restype = C.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def num_threads() -> int:
+    return int(lib().orc_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    lib().orc_set_num_threads(C.c_int(n))
+
+
+def vertex_normals(verts, faces):
+    verts, faces = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3)
+    out = np.empty_like(verts)
+    lib().orc_vertex_normals(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(out))
+    return out
+
+
+def point_tri_dist2(p, a, b, c) -> float:
+    p, a, b, c = (_f32(t).reshape(3) for t in (p, a, b, c))
+    return float(lib().orc_point_tri_dist2(_p(p), _p(a), _p(b), _p(c)))
+
+
+def nearest_brute(verts, faces, pts):
+    verts, faces, pts = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3), _f32(pts).reshape(-1, 3)
+    d2 = np.empty(len(pts), np.float32)
+    idx = np.empty(len(pts), np.int64)
+    lib().orc_nearest_brute(_p(verts), _p(faces), C.c_int64(len(faces)), _p(pts), C.c_int64(len(pts)),
+                            _p(d2), _p(idx))
+    return d2, idx
+
+
+def check_sign(verts, faces, pts):
+    verts, faces, pts = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3), _f32(pts).reshape(-1, 3)
+    out = np.empty(len(pts), np.uint8)
+    lib().orc_check_sign(_p(verts), _p(faces), C.c_int64(len(faces)), _p(pts), C.c_int64(len(pts)), _p(out))
+    return out.astype(bool)
+
+
+def cal_sdf(verts, faces, cmap, vis, pts):
+    """-> dict(sdf [N], norm [N,3], cmap [N,3], vis [N], idx [N] int64, inside [N] bool)"""
+    verts, faces = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3)
+    cmap, vis, pts = _f32(cmap).reshape(-1, 3), _f32(vis).reshape(-1), _f32(pts).reshape(-1, 3)
+    n = len(pts)
+    sdf, nrm, cm, vs = (np.empty(n, np.float32), np.empty((n, 3), np.float32),
+                        np.empty((n, 3), np.float32), np.empty(n, np.float32))
+    idx, ins = np.empty(n, np.int64), np.empty(n, np.uint8)
+    lib().orc_cal_sdf(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(cmap), _p(vis),
+                      _p(pts), C.c_int64(n), _p(sdf), _p(nrm), _p(cm), _p(vs), _p(idx), _p(ins))
+    return dict(sdf=sdf, norm=nrm, cmap=cm, vis=vs, idx=idx, inside=ins.astype(bool))
+
+
+class _OrcMlp(C.Structure):
+    _fields_ = [("n_layers", C.c_int), ("cin", C.c_void_p), ("cout", C.c_void_p), ("is_res", C.c_void_p),
+                ("W", C.c_void_p), ("b", C.c_void_p), ("bn_g", C.c_void_p), ("bn_b", C.c_void_p),
+                ("bn_m", C.c_void_p), ("bn_v", C.c_void_p)]
+
+
+class Mlp:
+    """Holds a reference-layout state_dict (numpy) as the orc_mlp struct."""
+
+    def __init__(self, state_dict: dict, res_layers=(2, 3, 4)):
+        n = 0
+        while f"filters.{n}.weight" in state_dict:
+            n += 1
+        self.n = n
+        self._keep = []
+        W = [_f32(np.asarray(state_dict[f"filters.{l}.weight"]).reshape(
+            np.asarray(state_dict[f"filters.{l}.weight"]).shape[0], -1)) for l in range(n)]
+        b = [_f32(state_dict[f"filters.{l}.bias"]) for l in range(n)]
+        self.c0 = W[0].shape[1]
+        self.c_last = W[-1].shape[0]
+        cin = np.array([w.shape[1] for w in W], np.int32)
+        cout = np.array([w.shape[0] for w in W], np.int32)
+        is_res = np.array([1 if l in res_layers else 0 for l in range(n)], np.int32)
+        for l in range(n):
+            expect = (cout[l - 1] if l else self.c0) + (self.c0 if is_res[l] else 0)
+            assert cin[l] == expect, f"layer {l}: Cin {cin[l]} != {expect}"
+
+        def ptr_array(arrs):
+            arr = (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+            self._keep.append((arrs, arr))
+            return C.cast(arr, C.c_void_p)
+
+        bn = {k: [_f32(state_dict[f"norms.{l}.{k}"]) for l in range(n - 1)]
+              for k in ("weight", "bias", "running_mean", "running_var")}
+        self._keep += [cin, cout, is_res, W, b, bn]
+        self.struct = _OrcMlp(n, cin.ctypes.data, cout.ctypes.data, is_res.ctypes.data,
+                              ptr_array(W), ptr_array(b), ptr_array(bn["weight"]), ptr_array(bn["bias"]),
+                              ptr_array(bn["running_mean"]), ptr_array(bn["running_var"]))
+
+    def forward(self, x, f64: bool = False):
+        """x [N, c0] point-major -> [N, c_last]"""
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[1] == self.c0
+        out = np.empty((len(x), self.c_last), np.float32)
+        lib().orc_mlp_forward(C.byref(self.struct), _p(x), C.c_int64(len(x)), C.c_int(self.c0), _p(out),
+                              C.c_int(int(f64)))
+        return out
+
+
+_IDENT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)
+
+
+def _calib12(calib):
+    if calib is None:
+        return _IDENT.copy()
+    c = _f32(calib).reshape(-1, 4)[:3]
+    return np.ascontiguousarray(c)
+
+
+def query_icon(verts, faces, cmap, vis, feat, mlp: Mlp, pts, sdf_clip=0.05, calib=None, f64=False,
+               cmap_local=False):
+    """HGPIFuNet.query, icon branch -> (occ [N], X [N, C/2+7]).  cmap_local=False reproduces the
+    reference's tiled outlier-cmap assignment (HGPIFuNet.py:303-305), True the per-point rule."""
+    verts, faces = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3)
+    cmap, vis, pts = _f32(cmap).reshape(-1, 3), _f32(vis).reshape(-1), _f32(pts).reshape(-1, 3)
+    feat = _f32(feat)
+    feat = feat.reshape(feat.shape[-3:])
+    Cc, H, W = feat.shape
+    n = len(pts)
+    occ = np.empty(n, np.float32)
+    X = np.empty((n, Cc // 2 + 7), np.float32)
+    cal = _calib12(calib)
+    lib().orc_query_icon(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(cmap), _p(vis),
+                         _p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), C.byref(mlp.struct),
+                         C.c_float(np.float32(sdf_clip)), _p(cal), _p(pts), C.c_int64(n), _p(occ), _p(X),
+                         C.c_int(int(f64)), C.c_int(int(cmap_local)))
+    return occ, X
+
+
+def query_vol(feat, vol, mlp: Mlp, pts, calib=None, f64=False):
+    """PaMIR (vol [Cv,D,H,W]) or PIFu (vol None) branch -> (occ [N], X [N, c0])"""
+    feat = _f32(feat)
+    feat = feat.reshape(feat.shape[-3:])
+    Cc, H, W = feat.shape
+    pts = _f32(pts).reshape(-1, 3)
+    n = len(pts)
+    if vol is not None:
+        vol = _f32(vol)
+        vol = vol.reshape(vol.shape[-4:])
+        Cv, Dv, Hv, Wv = vol.shape
+        vp = _p(vol)
+    else:
+        Cv, Dv, Hv, Wv, vp = 1, 0, 0, 0, None
+    occ = np.empty(n, np.float32)
+    X = np.empty((n, Cc + Cv), np.float32)
+    cal = _calib12(calib)
+    lib().orc_query_vol(_p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), vp, C.c_int(Cv), C.c_int(Dv),
+                        C.c_int(Hv), C.c_int(Wv), C.byref(mlp.struct), _p(cal), _p(pts), C.c_int64(n),
+                        _p(occ), _p(X), C.c_int(int(f64)))
+    return occ, X
