@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py - BASELINE.json's headline metric on MI355X: query-points/sec of one dense 257^3
+("256^3") occupancy-lattice evaluation for the icon-filter configuration.
+
+A "step" is one full reconEngine forward for one image: lattice generation, nearest-triangle /
+inside queries against the SMPL-size body (V=6,890 / F=13,776), barycentric attributes, outlier
+clipping (reference cmap semantics), bilinear feature gather + front/back select, the fused
+13->512->256->128->1 MLP, the in_cube mask and the [D,H,W] volume write - plus, for N > 1, the
+RCCL exchange of the outlier sign lists and the all_gather of the Z-slabs.  Per-image constants
+(feature planes, packed mesh + BVH, folded weights) are resident in HBM before the timed region;
+their one-off preparation time is reported separately in config.prep_ms.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--res 257] [--no-cpu-baseline]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0 (contract in the task statement; roofline + cpu_baseline objects
+described in DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MLP_FLOP_PER_POINT = 344_602          # 2 * (13*512 + 512*256 + 269*128 + 141), SURVEY.md §8(d)
+PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+
+
+def cpu_baseline(assets, res, budget_s=14.0):
+    """Reference query path on the host cores: oracle/query_torch.py (the reference's torch
+    operators, leaves from oracle/icon_oracle.c with OpenMP), timed on whole z-planes of the same
+    lattice.  Sample size is calibrated to ~budget_s seconds of CPU work."""
+    import numpy as np
+    import torch
+    from icon_amd import synth
+    from oracle import oracle as orc, query_torch as qt
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    orc.set_num_threads(cores)
+    mlp = qt.build_mlp(assets.state_dict)
+    mid = res // 2
+    probe = synth.lattice_points(res, mid, mid + 1)[: 16384]
+    t0 = time.perf_counter()
+    qt.query(assets, mlp, probe, assets.sdf_clip)
+    dt = time.perf_counter() - t0
+    rate = len(probe) / dt
+    planes = int(max(1, min(res, (rate * budget_s) // (res * res))))
+    zs = np.unique(np.linspace(res // 8, res - 1 - res // 8, planes).round().astype(int))
+    pts = np.concatenate([synth.lattice_points(res, int(z), int(z) + 1) for z in zs])
+    t0 = time.perf_counter()
+    qt.query(assets, mlp, pts, assets.sdf_clip)
+    dt = time.perf_counter() - t0
+    return {"value": len(pts) / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": f"{len(zs)} whole z-planes of the {res}^3 lattice ({len(pts)} points, {dt:.1f} s), "
+                      f"oracle/query_torch.py: torch-CPU operators of the reference ({torch.get_num_threads()} threads) + "
+                      f"brute-force C leaves (OpenMP, {orc.num_threads()} threads)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--res", type=int, default=257)
+    ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
+    ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from icon_amd import synth, _lib
+    from icon_amd.engine import IconQueryEngine, query_func
+    from icon_amd.recon import DenseReconEngine
+    from types import SimpleNamespace
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    _lib.require_device()
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    res = args.res
+    a = synth.make_assets("body")
+    T = lambda x: torch.from_numpy(x).to(dev)
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, cmap_mode=args.cmap_mode, search=args.search)
+    eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
+    feats = [T(a.features)]
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                             resolutions=[33, 65, 129, res] if res == 257 else [res], align_corners=True,
+                             balance_value=0.5, faster=True, engine=eng).to(dev)
+    opt = SimpleNamespace(num_views=1)
+
+    def step():
+        return recon(opt=opt, netG=eng, features=feats, proj_matrix=None)
+
+    # one-off per-image preparation (BVH build, plane repack, BatchNorm fold + operand packing)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng._mesh_handle(); eng._feat_handle(feats[0]); eng._mlp_handle()
+    torch.cuda.synchronize()
+    prep_ms = (time.perf_counter() - t0) * 1e3
+
+    for _ in range(args.warmup):
+        step()
+    eng._work().profile(True)
+    stage = np.zeros(3)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        occ = step()
+        # stage_ms waits on this step's last event (the MLP) - the same point the reference's
+        # `(occupancys > 0.5).sum() == 0` check already synchronises on
+        stage += np.array(eng._work().stage_ms())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stage /= max(args.steps, 1)
+    assert occ is not None and occ.shape == (res, res, res)
+
+    n_points = res ** 3
+    my_points = n_points if world == 1 else (lambda z: (z[1] - z[0]) * res * res)(
+        __import__("icon_amd.recon", fromlist=["slab_bounds"]).slab_bounds(res, world, rank))
+    value = n_points * args.steps / elapsed
+    mlp_s = stage[2] * 1e-3
+    achieved = (MLP_FLOP_PER_POINT * my_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("k_mlp_f32_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        out = {
+            "metric": "query-points/sec at 256^3 grid", "value": value, "unit": "points/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"icon-filter.yaml, {res}^3 lattice (mcube_res={res - 1}), 1 image: SMPL-size body "
+                            f"V=6890/F=13776, planes [1,12,128,128], MLP 13-512-256-128-1, cmap_mode={args.cmap_mode}",
+                "parallelism": f"zslab{world}", "points_per_step": n_points, "prep_ms": prep_ms,
+                "stage_ms": {"features": stage[0], "cmap_patch": stage[1], "mlp": stage[2]},
+            },
+            "roofline": {"bound": "mfma", "kernel": "k_mlp_f32", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+                         "flop_per_launch": MLP_FLOP_PER_POINT * my_points, "avg_launch_ms": stage[2]},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a, res)
+            out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,152 @@
+// common.h - shared declarations of the icon_amd native library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/icon_amd.h"
+
+namespace icon {
+
+// ---- error handling -------------------------------------------------------------------------
+void set_error(const std::string &msg);
+int fail(int code, const std::string &msg);
+
+#define ICON_HIP(expr)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (expr);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            return ::icon::fail(ICON_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+#define ICON_ARG(cond, msg)                                                  \
+    do {                                                                     \
+        if (!(cond)) return ::icon::fail(ICON_ERR_ARG, std::string(msg));    \
+    } while (0)
+
+// ---- device data layouts (HBM) --------------------------------------------------------------
+// BVH2 node, 64 B (one cache line): both children's boxes live in the parent so one load
+// decides both.  child >= 0: internal node index; child < 0: leaf, ~child = (first_slot << 3) |
+// (count - 1), count in 1..8; an empty child has lo = +inf, hi = -inf (distance = +inf).
+struct alignas(64) BvhNode {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t child0, child1;
+    int32_t pad[2];
+};
+static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
+
+// Triangle record in BVH leaf ("slot") order, 48 B = three 16-byte loads:
+// positions of the three corners followed by their vertex ids (needed by the canonical
+// edge rule of the ray-parity test).
+struct alignas(16) TriRec {
+    float a[3], b[3], c[3];
+    int32_t ia, ib, ic;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// Per-triangle attributes in slot order, 96 B = six 16-byte loads: what face_vertices()
+// gathers for normals / cmaps / vis (lib/dataset/mesh_util.py:369-372).
+struct alignas(16) TriAttr {
+    float n[3][3];     // vertex normals of the three corners
+    float cm[3][3];    // cmap
+    float vis[3];      // visibility
+    int32_t face;      // original face index
+    int32_t pad[2];
+};
+static_assert(sizeof(TriAttr) == 96, "TriAttr must be 96 bytes");
+
+constexpr int kLeafMax = 4;        // triangles per BVH leaf
+constexpr int kStackDepth = 28;    // per-lane traversal stack entries (LDS)
+constexpr int kXRow = 16;          // floats per point row of the MLP input buffer
+constexpr int kCodeSlot = 15;      // row slot holding the per-point code word
+
+// code word bits (row slot 15)
+constexpr uint32_t kCodeOutlier = 1u;          // |sdf| >= sdf_clip
+constexpr uint32_t kCodeSignShift = 1;         // 2 bits: sign(sdf) + 1  (0,1,2)
+constexpr uint32_t kCodeInCube = 8u;           // all(-1 < xyz < 1)
+
+struct MeshDev {
+    const BvhNode *nodes;
+    const TriRec *tris;
+    const TriAttr *attr;
+    const int32_t *slot2face;
+    int32_t n_tris;
+    int32_t root_is_leaf;
+    // ray bins over (y, z)
+    const int32_t *bin_start;   // [gy*gz + 1]
+    const int32_t *bin_slots;   // triangle slots
+    float bin_y0, bin_z0, bin_y1, bin_z1, bin_inv_y, bin_inv_z;
+    int32_t gy, gz;
+};
+
+struct FeatDev {
+    const float *planes;   // [n_select][H][W][cpad]
+    const float *vol;      // [D][H][W][vpad] or null
+    int32_t C, H, W, n_select, csel, cpad;
+    int32_t Cv, Dv, Hv, Wv, vpad;
+};
+
+// affine calibration (rot | trans), row-major [3][4]
+struct Calib { float m[12]; };
+
+// lattice descriptor: point i -> (x, y, z) index; world = idx/(R-1) * (bmax-bmin) + bmin
+struct Lattice {
+    int32_t res, z0, z1;
+};
+
+}  // namespace icon
+
+// ---- opaque handle bodies -------------------------------------------------------------------
+struct icon_mesh {
+    int64_t V = 0, F = 0;
+    float *d_vnormals = nullptr;
+    icon::BvhNode *d_nodes = nullptr;
+    icon::TriRec *d_tris = nullptr;
+    icon::TriAttr *d_attr = nullptr;
+    int32_t *d_slot2face = nullptr;
+    int32_t *d_bin_start = nullptr;
+    int32_t *d_bin_slots = nullptr;
+    icon::MeshDev dev{};
+    int64_t stats[4] = {0, 0, 0, 0};
+};
+
+struct icon_feat {
+    float *d_planes = nullptr;
+    float *d_vol = nullptr;
+    icon::FeatDev dev{};
+};
+
+struct icon_mlp {
+    int c0 = 0;               // input channels (<= 15)
+    float *d_blob = nullptr;  // all packed operands, one allocation
+    size_t blob_bytes = 0;
+    // offsets (in floats) into the blob
+    size_t off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0, off_w2 = 0, off_w2x = 0, off_b2 = 0, off_w3 = 0;
+    float b3 = 0.f;
+};
+
+namespace icon {
+// mlp_kernels.hip
+int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
+int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
+}  // namespace icon
+
+struct icon_work {
+    float *d_x = nullptr;                 // [cap_points][16] MLP input rows
+    int64_t cap_points = 0;
+    int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
+    int64_t *d_block_offsets = nullptr;   // exclusive prefix of the above
+    int64_t cap_blocks = 0;
+    int8_t *d_signs = nullptr;            // compacted outlier signs of the call
+    int64_t cap_signs = 0;
+    int64_t *d_total = nullptr;           // device scalar: number of outliers
+    // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
+    int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
+    bool slab_ready = false, slab_needs_patch = false;
+    // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
+    bool prof = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+};

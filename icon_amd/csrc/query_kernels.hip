@@ -1,0 +1,974 @@
+// query_kernels.hip - gfx950 kernels for the per-point geometry/feature half of HGPIFuNet.query:
+//   nearest triangle (BVH2, per-lane LDS stack, or LDS-tiled brute force), +x ray parity over
+//   (y,z) bins, Heidrich barycentric interpolation, outlier clipping, bilinear / trilinear
+//   feature gather + front/back select, and assembly of the 16-float MLP input rows.
+//
+// Reference being replaced (paths relative to the reference root):
+//   lib/dataset/mesh_util.py:357-396 (cal_sdf_batch), :319-354 (barycentrics), :266-277 (feat_select)
+//   lib/net/HGPIFuNet.py:268-365 (query), lib/net/geometry.py:21-61 (index, orthogonal)
+//
+// Arithmetic spec: float32, the only fused operations are the explicit fmaf() calls,
+// IEEE division / sqrt (hipcc default: correctly rounded).  This file is compiled with
+// -ffp-contract=off; the pragma below is a second line of defence.
+#pragma clang fp contract(off)
+
+#include "common.h"
+
+#include <cstring>
+
+namespace icon {
+
+// ---------------------------------------------------------------------------------------------
+// small vector helpers
+// ---------------------------------------------------------------------------------------------
+struct f3 { float x, y, z; };
+__device__ __forceinline__ f3 mk3(float x, float y, float z) { f3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ f3 sub3(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float dot3(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 cross3(f3 a, f3 b)
+{
+    return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+
+// S2: exact point-triangle squared distance, Voronoi-region form (same operation sequence as
+// the checker's orc_point_tri_dist2).
+__device__ __forceinline__ float pt_tri_dist2(f3 p, f3 a, f3 b, f3 c)
+{
+    const f3 ab = sub3(b, a), ac = sub3(c, a);
+    const f3 ap = sub3(p, a), bp = sub3(p, b), cp = sub3(p, c);
+    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
+    const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
+    const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
+    const float va = fmaf(d3, d6, -(d5 * d4));
+    const float vb = fmaf(d5, d2, -(d1 * d6));
+    const float vc = fmaf(d1, d4, -(d3 * d2));
+    float v, w;
+    if (d1 <= 0.0f && d2 <= 0.0f) { v = 0.0f; w = 0.0f; }
+    else if (d3 >= 0.0f && d4 <= d3) { v = 1.0f; w = 0.0f; }
+    else if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
+        const float inv = 1.0f / (d1 - d3);
+        v = d1 * inv; w = 0.0f;
+    }
+    else if (d6 >= 0.0f && d5 <= d6) { v = 0.0f; w = 1.0f; }
+    else if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
+        const float inv = 1.0f / (d2 - d6);
+        v = 0.0f; w = d2 * inv;
+    }
+    else if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
+        const float n = d4 - d3;
+        const float inv = 1.0f / (n + (d5 - d6));
+        w = n * inv; v = 1.0f - w;
+    }
+    else {
+        const float inv = 1.0f / ((va + vb) + vc);
+        v = vb * inv; w = vc * inv;
+    }
+    f3 q;
+    q.x = fmaf(ac.x, w, fmaf(ab.x, v, a.x));
+    q.y = fmaf(ac.y, w, fmaf(ab.y, v, a.y));
+    q.z = fmaf(ac.z, w, fmaf(ab.z, v, a.z));
+    const f3 d = sub3(p, q);
+    return dot3(d, d);
+}
+
+// S4: +x ray / triangle crossing with the canonical (lower vertex id first) edge rule.
+__device__ __forceinline__ float edge_fn(float yi, float zi, float yj, float zj, float qy, float qz)
+{
+    const float t1 = (yj - yi) * (qz - zi);
+    return fmaf(-(zj - zi), (qy - yi), t1);
+}
+__device__ __forceinline__ void oriented_edge(int ia, f3 a, int ib, f3 b, float qy, float qz, float &val, bool &pos)
+{
+    if (ia < ib) { const float e = edge_fn(a.y, a.z, b.y, b.z, qy, qz); val = e; pos = (e >= 0.0f); }
+    else         { const float e = edge_fn(b.y, b.z, a.y, a.z, qy, qz); val = -e; pos = (e < 0.0f); }
+}
+__device__ __forceinline__ int ray_hit(f3 p, f3 a, f3 b, f3 c, int ia, int ib, int ic)
+{
+    float e_ab, e_bc, e_ca; bool s_ab, s_bc, s_ca;
+    oriented_edge(ia, a, ib, b, p.y, p.z, e_ab, s_ab);
+    oriented_edge(ib, b, ic, c, p.y, p.z, e_bc, s_bc);
+    oriented_edge(ic, c, ia, a, p.y, p.z, e_ca, s_ca);
+    if (!(s_ab == s_bc && s_bc == s_ca)) return 0;
+    const float num = fmaf(e_ab, c.x - p.x, fmaf(e_ca, b.x - p.x, e_bc * (a.x - p.x)));
+    return s_ab ? (num > 0.0f) : (num < 0.0f);
+}
+
+__device__ __forceinline__ void load_tri_pos(const TriRec *t, f3 &a, f3 &b, f3 &c)
+{
+    const float4 *q = reinterpret_cast<const float4 *>(t);
+    const float4 q0 = q[0], q1 = q[1];
+    const float q2 = reinterpret_cast<const float *>(t)[8];
+    a = mk3(q0.x, q0.y, q0.z); b = mk3(q0.w, q1.x, q1.y); c = mk3(q1.z, q1.w, q2);
+}
+__device__ __forceinline__ void load_tri_full(const TriRec *t, f3 &a, f3 &b, f3 &c, int &ia, int &ib, int &ic)
+{
+    const float4 *q = reinterpret_cast<const float4 *>(t);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+    a = mk3(q0.x, q0.y, q0.z); b = mk3(q0.w, q1.x, q1.y); c = mk3(q1.z, q1.w, q2.x);
+    ia = __float_as_int(q2.y); ib = __float_as_int(q2.z); ic = __float_as_int(q2.w);
+}
+
+__device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float hx, float hy, float hz, f3 p)
+{
+    const float dx = fmaxf(fmaxf(lx - p.x, p.x - hx), 0.0f);
+    const float dy = fmaxf(fmaxf(ly - p.y, p.y - hy), 0.0f);
+    const float dz = fmaxf(fmaxf(lz - p.z, p.z - hz), 0.0f);
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+struct Nearest { float d2; int slot; int face; };
+
+// Pruning bound: a subtree may be skipped only if no triangle in it can tie or beat `best`.
+// Computed distances carry < 1e-6 absolute error (coordinates are O(1)), so the bound is
+// (sqrt(best) + 4e-6)^2 with a relative cushion; see DESIGN.md "BVH conservativeness".
+__device__ __forceinline__ float prune_threshold(float best)
+{
+    const float s = sqrtf(best) + 4e-6f;
+    return s * s * 1.000001f;
+}
+
+__device__ __forceinline__ void consider(const MeshDev &m, f3 p, int slot, Nearest &nr, float &thr)
+{
+    f3 a, b, c;
+    load_tri_pos(m.tris + slot, a, b, c);
+    const float d2 = pt_tri_dist2(p, a, b, c);
+    if (d2 <= nr.d2) {                       // NaN never passes
+        const int face = m.slot2face[slot];
+        if (d2 < nr.d2 || face < nr.face) {  // S3: exact ties go to the lowest face index
+            nr.d2 = d2; nr.slot = slot; nr.face = face;
+            thr = prune_threshold(d2);
+        }
+    }
+}
+
+// BVH2 traversal, one query per lane, near child first, stack in LDS ([depth][thread]).
+template <int BLOCK>
+__device__ __forceinline__ Nearest nearest_bvh(const MeshDev &m, f3 p, int *stack /* LDS, kStackDepth*BLOCK */)
+{
+    Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
+    float thr = INFINITY;
+    int sp = 0;
+    int cur = 0;
+    const int tid = threadIdx.x;
+    while (true) {
+        if (cur < 0) {
+            const int code = ~cur;
+            const int first = code >> 3, cnt = (code & 7) + 1;
+            for (int t = 0; t < cnt; ++t) consider(m, p, first + t, nr, thr);
+            if (sp == 0) break;
+            cur = stack[(--sp) * BLOCK + tid];
+        } else {
+            const float4 *q = reinterpret_cast<const float4 *>(m.nodes + cur);
+            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+            const float d0 = box_dist2(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, p);
+            const float d1 = box_dist2(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, p);
+            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
+            const bool v0 = d0 <= thr, v1 = d1 <= thr;
+            if (v0 && v1) {
+                const bool first0 = d0 <= d1;
+                stack[(sp++) * BLOCK + tid] = first0 ? c1 : c0;
+                cur = first0 ? c0 : c1;
+            } else if (v0) cur = c0;
+            else if (v1) cur = c1;
+            else {
+                if (sp == 0) break;
+                cur = stack[(--sp) * BLOCK + tid];
+            }
+        }
+    }
+    return nr;
+}
+
+// Brute force over all triangle slots, staged through LDS in tiles (validation path).
+template <int BLOCK>
+__device__ __forceinline__ Nearest nearest_brute(const MeshDev &m, f3 p, float *tile /* LDS, BLOCK*12 floats */)
+{
+    Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
+    for (int base = 0; base < m.n_tris; base += BLOCK) {
+        __syncthreads();
+        const int s = base + threadIdx.x;
+        if (s < m.n_tris) {
+            const float4 *q = reinterpret_cast<const float4 *>(m.tris + s);
+            float4 *dst = reinterpret_cast<float4 *>(tile + threadIdx.x * 12);
+            dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
+            dst[2].w = __int_as_float(m.slot2face[s]);   // vertex id ic not needed here
+        }
+        __syncthreads();
+        const int n = min(BLOCK, m.n_tris - base);
+        for (int t = 0; t < n; ++t) {
+            const float *r = tile + t * 12;
+            const float d2 = pt_tri_dist2(p, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), mk3(r[6], r[7], r[8]));
+            const int face = __float_as_int(r[11]);
+            if (d2 < nr.d2 || (d2 == nr.d2 && face < nr.face)) { nr.d2 = d2; nr.slot = base + t; nr.face = face; }
+        }
+    }
+    return nr;
+}
+
+__device__ __forceinline__ int bin_cell(float v, float v0, float inv, int g)
+{
+    const int c = (int)floorf((v - v0) * inv);
+    return min(max(c, 0), g - 1);
+}
+
+__device__ __forceinline__ bool inside_bins(const MeshDev &m, f3 p)
+{
+    if (!(p.y >= m.bin_y0 && p.y <= m.bin_y1 && p.z >= m.bin_z0 && p.z <= m.bin_z1)) return false;
+    const int cy = bin_cell(p.y, m.bin_y0, m.bin_inv_y, m.gy);
+    const int cz = bin_cell(p.z, m.bin_z0, m.bin_inv_z, m.gz);
+    const int cell = cz * m.gy + cy;
+    const int beg = m.bin_start[cell], end = m.bin_start[cell + 1];
+    int cnt = 0;
+    for (int k = beg; k < end; ++k) {
+        f3 a, b, c; int ia, ib, ic;
+        load_tri_full(m.tris + m.bin_slots[k], a, b, c, ia, ib, ic);
+        cnt += ray_hit(p, a, b, c, ia, ib, ic);
+    }
+    return (cnt & 1) != 0;
+}
+
+__device__ __forceinline__ bool inside_brute(const MeshDev &m, f3 p)
+{
+    int cnt = 0;
+    for (int s = 0; s < m.n_tris; ++s) {
+        f3 a, b, c; int ia, ib, ic;
+        load_tri_full(m.tris + s, a, b, c, ia, ib, ic);
+        cnt += ray_hit(p, a, b, c, ia, ib, ic);
+    }
+    return (cnt & 1) != 0;
+}
+
+// S5: per-point tail of cal_sdf_batch (mesh_util.py:375-394)
+struct SdfOut { float sdf; f3 nrm; f3 cm; float vis; };
+
+__device__ __forceinline__ SdfOut sdf_attrs(const MeshDev &m, f3 p, const Nearest &nr, bool inside)
+{
+    f3 v0, v1, v2;
+    load_tri_pos(m.tris + nr.slot, v0, v1, v2);
+    const float4 *q = reinterpret_cast<const float4 *>(m.attr + nr.slot);
+    const float4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3], a4 = q[4], a5 = q[5];
+    // n[3][3] = a0.xyzw a1.xyzw a2.x ; cm[3][3] = a2.yzw a3.xyzw a4.xy ; vis[3] = a4.zw a5.x
+    const float n0[3] = {a0.x, a0.y, a0.z}, n1[3] = {a0.w, a1.x, a1.y}, n2[3] = {a1.z, a1.w, a2.x};
+    const float c0[3] = {a2.y, a2.z, a2.w}, c1[3] = {a3.x, a3.y, a3.z}, c2[3] = {a3.w, a4.x, a4.y};
+    const float s0 = a4.z, s1 = a4.w, s2 = a5.x;
+    // barycentric_coordinates_of_projection (unclamped)
+    const f3 u = sub3(v1, v0), v = sub3(v2, v0);
+    const f3 n = cross3(u, v);
+    float s = dot3(n, n);
+    if (s == 0.0f) s = 1e-6f;
+    const float inv = 1.0f / s;
+    const f3 ww = sub3(p, v0);
+    const float b2 = dot3(cross3(u, ww), n) * inv;
+    const float b1 = dot3(cross3(ww, v), n) * inv;
+    const float w0 = (1.0f - b1) - b2, w1 = b1, w2 = b2;
+    SdfOut o;
+    o.cm = mk3(fmaf(c2[0], w2, fmaf(c1[0], w1, c0[0] * w0)), fmaf(c2[1], w2, fmaf(c1[1], w1, c0[1] * w0)),
+               fmaf(c2[2], w2, fmaf(c1[2], w1, c0[2] * w0)));
+    const float nx = fmaf(n2[0], w2, fmaf(n1[0], w1, n0[0] * w0));
+    const float ny = fmaf(n2[1], w2, fmaf(n1[1], w1, n0[1] * w0));
+    const float nz = fmaf(n2[2], w2, fmaf(n1[2], w1, n0[2] * w0));
+    o.nrm = mk3(-nx, ny, -nz);
+    const float vsum = fmaf(s2, w2, fmaf(s1, w1, s0 * w0));
+    o.vis = (vsum >= 0.1f) ? 1.0f : 0.0f;
+    const float dist = sqrtf(nr.d2) / sqrtf(3.0f);
+    o.sdf = inside ? dist : -dist;
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// feature gather (grid_sample, bilinear / trilinear, zeros padding, align_corners=True)
+// planes: [n_select][H][W][cpad] channel-last, one tap = cpad/4 float4 loads
+// ---------------------------------------------------------------------------------------------
+template <int C4>
+__device__ __forceinline__ void gather_planes(const FeatDev &f, int sel, float x, float y, float *out /* C4*4 */)
+{
+    const int H = f.H, W = f.W;
+    const float ix = ((x + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((y + 1.0f) / 2.0f) * (float)(H - 1);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = ((float)x1 - ix) * ((float)y1 - iy);
+    const float ne = (ix - (float)x0) * ((float)y1 - iy);
+    const float sw = ((float)x1 - ix) * (iy - (float)y0);
+    const float se = (ix - (float)x0) * (iy - (float)y0);
+    const float4 *base = reinterpret_cast<const float4 *>(f.planes) + (size_t)sel * H * W * C4;
+    const bool bx0 = x0 >= 0 && x0 < W, bx1 = x1 >= 0 && x1 < W, by0 = y0 >= 0 && y0 < H, by1 = y1 >= 0 && y1 < H;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int c = 0; c < C4; ++c) {
+        const float4 t00 = (bx0 && by0) ? base[((size_t)y0 * W + x0) * C4 + c] : zero;
+        const float4 t01 = (bx1 && by0) ? base[((size_t)y0 * W + x1) * C4 + c] : zero;
+        const float4 t10 = (bx0 && by1) ? base[((size_t)y1 * W + x0) * C4 + c] : zero;
+        const float4 t11 = (bx1 && by1) ? base[((size_t)y1 * W + x1) * C4 + c] : zero;
+        float acc;
+        acc = t00.x * nw; acc += t01.x * ne; acc += t10.x * sw; acc += t11.x * se; out[4 * c + 0] = acc;
+        acc = t00.y * nw; acc += t01.y * ne; acc += t10.y * sw; acc += t11.y * se; out[4 * c + 1] = acc;
+        acc = t00.z * nw; acc += t01.z * ne; acc += t10.z * sw; acc += t11.z * se; out[4 * c + 2] = acc;
+        acc = t00.w * nw; acc += t01.w * ne; acc += t10.w * sw; acc += t11.w * se; out[4 * c + 3] = acc;
+    }
+}
+
+template <int C4>
+__device__ __forceinline__ void gather_volume(const FeatDev &f, float x, float y, float z, float *out /* C4*4 */)
+{
+    const int D = f.Dv, H = f.Hv, W = f.Wv;
+    const float ix = ((x + 1.0f) / 2.0f) * (float)(W - 1);
+    const float iy = ((y + 1.0f) / 2.0f) * (float)(H - 1);
+    const float iz = ((z + 1.0f) / 2.0f) * (float)(D - 1);
+    const int x0 = (int)floorf(ix), y0 = (int)floorf(iy), z0 = (int)floorf(iz);
+    const float tx = ix - (float)x0, ty = iy - (float)y0, tz = iz - (float)z0;
+    const float4 *base = reinterpret_cast<const float4 *>(f.vol);
+#pragma unroll
+    for (int c = 0; c < C4 * 4; ++c) out[c] = 0.0f;
+#pragma unroll
+    for (int dz = 0; dz < 2; ++dz)
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const int xi = x0 + dx, yi = y0 + dy, zi = z0 + dz;
+                const float wgt = (dx ? tx : 1.0f - tx) * (dy ? ty : 1.0f - ty) * (dz ? tz : 1.0f - tz);
+                if (xi >= 0 && xi < W && yi >= 0 && yi < H && zi >= 0 && zi < D) {
+#pragma unroll
+                    for (int c = 0; c < C4; ++c) {
+                        const float4 t = base[(((size_t)zi * H + yi) * W + xi) * C4 + c];
+                        out[4 * c + 0] += t.x * wgt; out[4 * c + 1] += t.y * wgt;
+                        out[4 * c + 2] += t.z * wgt; out[4 * c + 3] += t.w * wgt;
+                    }
+                }
+            }
+}
+
+// dispatch on the padded channel count (cpad in {4,8,12,16})
+__device__ __forceinline__ void gather_planes_dyn(const FeatDev &f, int sel, float x, float y, float *out)
+{
+    switch (f.cpad >> 2) {
+        case 1: gather_planes<1>(f, sel, x, y, out); break;
+        case 2: gather_planes<2>(f, sel, x, y, out); break;
+        case 3: gather_planes<3>(f, sel, x, y, out); break;
+        default: gather_planes<4>(f, sel, x, y, out); break;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// point sources
+// ---------------------------------------------------------------------------------------------
+// Lattice tiling: a wavefront owns a 4x4x4 block of lattice points (spatially compact, so its
+// 64 BVH traversals follow nearly the same path); a 256-thread workgroup owns 16x4x4.
+// Workgroups are numbered y-slowest and dealt to the 8 XCDs in contiguous runs, so each XCD's
+// private L2 keeps one horizontal band of the body mesh hot.
+struct LatticeMap {
+    int res, z0, nz;           // evaluated planes [z0, z0+nz)
+    int tx, ty, tz;            // tile counts
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int nb)
+{
+    // bijective "contiguous chunk per XCD" remap (blocks are dispatched round-robin to 8 XCDs)
+    const int q = nb >> 3, r = nb & 7;
+    const int xcd = b & 7, k = b >> 3;
+    const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + k;
+}
+
+__device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
+{
+    const int nb = L.tx * L.ty * L.tz;
+    const int t = xcd_remap(blockIdx.x, nb);
+    const int bty = t / (L.tz * L.tx);
+    const int rem = t - bty * (L.tz * L.tx);
+    const int btz = rem / L.tx, btx = rem - btz * L.tx;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    ix = btx * 16 + wave * 4 + (lane & 3);
+    iy = bty * 4 + ((lane >> 2) & 3);
+    iz = btz * 4 + (lane >> 4);
+    return ix < L.res && iy < L.res && iz < L.nz;
+}
+
+__device__ __forceinline__ f3 lattice_world(int res, int ix, int iy, int iz)
+{
+    // batch_eval, seg3d_lossless.py:132-137 with align_corners=True:
+    //   coords.float() / (R-1) * (b_max - b_min) + b_min, b_min=[-1,1,-1], b_max=[1,-1,1]
+    const float rm1 = (float)(res - 1);
+    const float fx = (float)ix / rm1, fy = (float)iy / rm1, fz = (float)iz / rm1;
+    return mk3(fx * 2.0f + (-1.0f), fy * (-2.0f) + 1.0f, fz * 2.0f + (-1.0f));
+}
+
+__device__ __forceinline__ f3 project(const Calib &c, f3 p)
+{
+    // orthogonal(): baddbmm(trans, rot, points), geometry.py:54-56
+    // k-ordered fma chain, then + trans (what ATen's CPU baddbmm computes for K = 3); exact for identity
+    f3 r;
+    r.x = fmaf(c.m[2], p.z, fmaf(c.m[1], p.y, c.m[0] * p.x)) + c.m[3];
+    r.y = fmaf(c.m[6], p.z, fmaf(c.m[5], p.y, c.m[4] * p.x)) + c.m[7];
+    r.z = fmaf(c.m[10], p.z, fmaf(c.m[9], p.y, c.m[8] * p.x)) + c.m[11];
+    return r;
+}
+
+__device__ __forceinline__ uint32_t in_cube_bit(f3 p)
+{
+    const bool in = p.x > -1.0f && p.x < 1.0f && p.y > -1.0f && p.y < 1.0f && p.z > -1.0f && p.z < 1.0f;
+    return in ? kCodeInCube : 0u;
+}
+
+__device__ __forceinline__ void store_row(float *X, int64_t i, const float *row)
+{
+    float4 *dst = reinterpret_cast<float4 *>(X + i * kXRow);
+    dst[0] = make_float4(row[0], row[1], row[2], row[3]);
+    dst[1] = make_float4(row[4], row[5], row[6], row[7]);
+    dst[2] = make_float4(row[8], row[9], row[10], row[11]);
+    dst[3] = make_float4(row[12], row[13], row[14], row[15]);
+}
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------
+// cal_sdf_batch for explicit points (API parity with the reference function; also the unit-test
+// surface for the geometry kernels)
+template <bool BRUTE>
+__global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__restrict__ pts, int64_t N,
+                                                      float *sdf, float *nrm, float *cm, float *vis,
+                                                      int64_t *face, uint8_t *inside_out)
+{
+    __shared__ int lds[kStackDepth * kBlock];
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < N;
+    const int64_t ic = live ? i : (N - 1);
+    const f3 p = mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
+    Nearest nr;
+    bool ins;
+    if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
+    else       { nr = nearest_bvh<kBlock>(m, p, lds); ins = inside_bins(m, p); }
+    if (!live) return;
+    const SdfOut o = sdf_attrs(m, p, nr, ins);
+    sdf[i] = o.sdf;
+    nrm[3 * i] = o.nrm.x; nrm[3 * i + 1] = o.nrm.y; nrm[3 * i + 2] = o.nrm.z;
+    cm[3 * i] = o.cm.x; cm[3 * i + 1] = o.cm.y; cm[3 * i + 2] = o.cm.z;
+    vis[i] = o.vis;
+    if (face) face[i] = nr.face;
+    if (inside_out) inside_out[i] = ins ? 1 : 0;
+}
+
+// Feature assembly: one 16-float row per point,
+//   icon : [img(csel) | sdf | cmap r g b | norm x y z | 0.. | code]
+//   pamir: [img(C) | vol(Cv) | 0.. | code]      pifu: [img(C) | z | 0.. | code]
+// Rows are indexed by the point's linear index (lattice: (z*R + y)*R + x relative to plane z0).
+template <int PRIOR, bool LATTICE, bool BRUTE>
+__global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib cal, LatticeMap L,
+                                                     const float *__restrict__ pts, int64_t N,
+                                                     float sdf_clip, int cmap_local, float *__restrict__ X)
+{
+    __shared__ int lds[(PRIOR == ICON_PRIOR_ICON) ? kStackDepth * kBlock : 1];
+    int64_t i; bool live; f3 p;
+    if (LATTICE) {
+        int ix, iy, iz;
+        live = lattice_point(L, ix, iy, iz);
+        const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+        p = lattice_world(L.res, cx, cy, cz + L.z0);
+        i = ((int64_t)cz * L.res + cy) * L.res + cx;
+    } else {
+        i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        live = i < N;
+        if (!live) i = N - 1;
+        p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    }
+    float row[kXRow];
+#pragma unroll
+    for (int k = 0; k < kXRow; ++k) row[k] = 0.0f;
+    uint32_t code = in_cube_bit(p);
+    if (PRIOR == ICON_PRIOR_ICON) {
+        Nearest nr;
+        bool ins;
+        if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
+        else       { nr = nearest_bvh<kBlock>(m, p, lds); ins = inside_bins(m, p); }
+        const SdfOut o = sdf_attrs(m, p, nr, ins);
+        float s = o.sdf;
+        f3 cmv = o.cm;
+        if (fabsf(s) >= sdf_clip) {            // HGPIFuNet.py:298-305
+            const int sg = (s > 0.0f) ? 1 : ((s < 0.0f) ? -1 : 0);
+            s = (float)sg;
+            code |= kCodeOutlier | ((uint32_t)(sg + 1) << kCodeSignShift);
+            if (cmap_local) cmv = mk3(s, s, s);   // reference mode: patched later from the sign list
+        }
+        float g[16];
+        gather_planes_dyn(f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, g);   // feat_select: vis==1 -> front half
+        const int h = f.csel;
+        for (int k = 0; k < h; ++k) row[k] = g[k];
+        row[h] = s;
+        row[h + 1] = cmv.x; row[h + 2] = cmv.y; row[h + 3] = cmv.z;
+        row[h + 4] = o.nrm.x; row[h + 5] = o.nrm.y; row[h + 6] = o.nrm.z;
+    } else {
+        float g[16];
+        gather_planes_dyn(f, 0, p.x, p.y, g);
+        const int h = f.csel;
+        for (int k = 0; k < h; ++k) row[k] = g[k];
+        if (PRIOR == ICON_PRIOR_PAMIR) {
+            float v[8];
+            if (f.vpad == 8) gather_volume<2>(f, p.x, p.y, p.z, v); else gather_volume<1>(f, p.x, p.y, p.z, v);
+            for (int k = 0; k < f.Cv; ++k) row[h + k] = v[k];
+        } else {
+            row[h] = p.z;
+        }
+    }
+    row[kCodeSlot] = __int_as_float((int)code);
+    if (live) store_row(X, i, row);
+}
+
+// ---------------------------------------------------------------------------------------------
+// outlier sign list (reference cmap mode): count -> scan -> compact -> patch, all in the linear
+// point order of the call.
+// ---------------------------------------------------------------------------------------------
+constexpr int kScanBlock = 1024;
+
+__device__ __forceinline__ uint32_t row_code(const float *X, int64_t i)
+{
+    return (uint32_t)__float_as_int(X[i * kXRow + kCodeSlot]);
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_outlier_count(const float *__restrict__ X, int64_t N, int32_t *block_counts)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const bool o = (i < N) && (row_code(X, i) & kCodeOutlier);
+    const unsigned long long b = __ballot(o);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int w = 0; w < kScanBlock / 64; ++w) s += wsum[w];
+        block_counts[blockIdx.x] = s;
+    }
+}
+
+// single-workgroup exclusive scan of the per-block counts (<= a few 100k entries);
+// offsets are int64 (a 513^3 lattice has 1.35e8 points)
+__global__ __launch_bounds__(1024) void k_scan_blocks(const int32_t *counts, int64_t nblocks, int64_t *offsets, int64_t *total)
+{
+    __shared__ int64_t part[1024];
+    const int t = threadIdx.x;
+    const int64_t per = (nblocks + 1023) / 1024;
+    const int64_t beg = min((int64_t)t * per, nblocks), end = min(beg + per, nblocks);
+    int64_t s = 0;
+    for (int64_t k = beg; k < end; ++k) s += counts[k];
+    part[t] = s;
+    __syncthreads();
+    if (t == 0) {
+        int64_t run = 0;
+        for (int k = 0; k < 1024; ++k) { const int64_t v = part[k]; part[k] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    int64_t run = part[t];
+    for (int64_t k = beg; k < end; ++k) { offsets[k] = run; run += counts[k]; }
+}
+
+__device__ __forceinline__ int64_t outlier_rank(bool o, const int64_t *block_offsets, int *wsum)
+{
+    // exclusive rank of this thread's outlier among the outliers of the call (linear order)
+    const unsigned long long b = __ballot(o);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int before = 0;
+    for (int k = 0; k < w; ++k) before += wsum[k];
+    before += __popcll(b & ((1ull << lane) - 1ull));
+    return block_offsets[blockIdx.x] + before;
+}
+
+__global__ __launch_bounds__(kScanBlock) void k_outlier_compact(const float *__restrict__ X, int64_t N,
+                                                                const int64_t *block_offsets, int8_t *signs)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const bool o = code & kCodeOutlier;
+    const int64_t r = outlier_rank(o, block_offsets, wsum);
+    if (o) signs[r] = (int8_t)((int)((code >> kCodeSignShift) & 3u) - 1);
+}
+
+// cmap[j][k] = s[(3j + k) mod K]  with j = global outlier rank = rank_offset + local rank
+__global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict__ X, int64_t N, int cmap_slot,
+                                                              const int64_t *block_offsets, const int8_t *signs_global,
+                                                              int64_t k_total, int64_t rank_offset)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const bool o = code & kCodeOutlier;
+    const int64_t j = rank_offset + outlier_rank(o, block_offsets, wsum);
+    if (o) {
+        float *row = X + i * kXRow + cmap_slot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int64_t mm = 3 * j + k;                 // j < K  =>  mm < 3K
+            if (mm >= k_total) mm -= k_total;
+            if (mm >= k_total) mm -= k_total;
+            row[k] = (float)signs_global[mm];
+        }
+    }
+}
+
+// repack feature planes [C][H][W] -> [n_select][H][W][cpad] (channel-last, zero padded)
+__global__ void k_pack_planes(const float *__restrict__ src, int C, int H, int W, int n_select, int csel, int cpad, float *dst)
+{
+    const int64_t n = (int64_t)n_select * H * W * cpad;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cpad);
+        const int64_t pix = (i / cpad) % ((int64_t)H * W);
+        const int sel = (int)(i / ((int64_t)cpad * H * W));
+        dst[i] = (c < csel) ? src[((int64_t)(sel * csel + c)) * H * W + pix] : 0.0f;
+    }
+}
+
+}  // namespace icon
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+using namespace icon;
+
+
+extern "C" int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, int64_t N,
+                              float *d_sdf, float *d_norm, float *d_cmap, float *d_vis,
+                              int64_t *d_face, uint8_t *d_inside, int search, void *stream)
+{
+    ICON_ARG(mesh && d_points && d_sdf && d_norm && d_cmap && d_vis, "icon_sdf_query: null argument");
+    ICON_ARG(N >= 0, "icon_sdf_query: negative N");
+    if (N == 0) return ICON_OK;
+    const int64_t nb = (N + kBlock - 1) / kBlock;
+    ICON_ARG(nb < (1ll << 31), "icon_sdf_query: N too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    if (search == ICON_SEARCH_BRUTE)
+        hipLaunchKernelGGL(k_sdf_query<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
+                           d_cmap, d_vis, d_face, d_inside);
+    else
+        hipLaunchKernelGGL(k_sdf_query<false>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
+                           d_cmap, d_vis, d_face, d_inside);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+extern "C" int icon_feat_create(const float *d_planes, int C, int H, int W, int n_select,
+                                const float *d_vol, int Cv, int Dv, int Hv, int Wv,
+                                void *stream, icon_feat_t **out)
+{
+    ICON_ARG(out != nullptr, "icon_feat_create: out is null");
+    *out = nullptr;
+    ICON_ARG(d_planes && C > 0 && H > 1 && W > 1, "icon_feat_create: bad planes");
+    ICON_ARG(n_select == 1 || n_select == 2, "icon_feat_create: n_select must be 1 or 2");
+    ICON_ARG(C % n_select == 0, "icon_feat_create: C not divisible by n_select");
+    const int csel = C / n_select;
+    const int cpad = (csel + 3) & ~3;
+    if (cpad > 16) return fail(ICON_ERR_UNSUPPORTED, "icon_feat_create: more than 16 channels per tap");
+    if (d_vol) {
+        ICON_ARG(Cv > 0 && Dv > 1 && Hv > 1 && Wv > 1, "icon_feat_create: bad volume");
+        if (Cv > 8) return fail(ICON_ERR_UNSUPPORTED, "icon_feat_create: more than 8 volume channels");
+    }
+    hipStream_t st = (hipStream_t)stream;
+    icon_feat *f = new icon_feat();
+    const size_t n = (size_t)n_select * H * W * cpad;
+    hipError_t e = hipMalloc((void **)&f->d_planes, n * sizeof(float));
+    if (e != hipSuccess) { delete f; return fail(ICON_ERR_HIP, std::string("hipMalloc planes: ") + hipGetErrorString(e)); }
+    hipLaunchKernelGGL(k_pack_planes, dim3(1024), dim3(256), 0, st, d_planes, C, H, W, n_select, csel, cpad, f->d_planes);
+    FeatDev &d = f->dev;
+    d.planes = f->d_planes; d.C = C; d.H = H; d.W = W; d.n_select = n_select; d.csel = csel; d.cpad = cpad;
+    d.vol = nullptr; d.Cv = 0; d.Dv = d.Hv = d.Wv = 0; d.vpad = 0;
+    if (d_vol) {
+        const int vpad = (Cv + 3) & ~3;
+        const size_t nv = (size_t)Dv * Hv * Wv * vpad;
+        e = hipMalloc((void **)&f->d_vol, nv * sizeof(float));
+        if (e != hipSuccess) { icon_feat_destroy(f); return fail(ICON_ERR_HIP, std::string("hipMalloc vol: ") + hipGetErrorString(e)); }
+        // a volume is a "plane" of H' = D*H rows: same channel-last repack
+        hipLaunchKernelGGL(k_pack_planes, dim3(1024), dim3(256), 0, st, d_vol, Cv, Dv * Hv, Wv, 1, Cv, vpad, f->d_vol);
+        d.vol = f->d_vol; d.Cv = Cv; d.Dv = Dv; d.Hv = Hv; d.Wv = Wv; d.vpad = vpad;
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) { icon_feat_destroy(f); return fail(ICON_ERR_HIP, std::string("pack planes: ") + hipGetErrorString(e)); }
+    *out = f;
+    return ICON_OK;
+}
+
+extern "C" int icon_feat_destroy(icon_feat_t *f)
+{
+    if (!f) return ICON_OK;
+    (void)hipFree(f->d_planes); (void)hipFree(f->d_vol);
+    delete f;
+    return ICON_OK;
+}
+
+extern "C" int icon_work_create(icon_work_t **out)
+{
+    ICON_ARG(out != nullptr, "icon_work_create: out is null");
+    *out = new icon_work();
+    return ICON_OK;
+}
+
+extern "C" int icon_work_destroy(icon_work_t *w)
+{
+    if (!w) return ICON_OK;
+    (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total);
+    for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+    delete w;
+    return ICON_OK;
+}
+
+extern "C" int icon_work_profile(icon_work_t *w, int enable)
+{
+    ICON_ARG(w != nullptr, "icon_work_profile: work is null");
+    if (enable && !w->ev[0])
+        for (int k = 0; k < 4; ++k) ICON_HIP(hipEventCreate(&w->ev[k]));
+    w->prof = enable != 0;
+    w->ev_valid = false;
+    return ICON_OK;
+}
+
+extern "C" int icon_work_stage_ms(icon_work_t *w, float out_ms[3])
+{
+    ICON_ARG(w && out_ms, "icon_work_stage_ms: null argument");
+    if (!w->prof || !w->ev_valid) return fail(ICON_ERR_STATE, "icon_work_stage_ms: no profiled call on this workspace");
+    ICON_HIP(hipEventSynchronize(w->ev[3]));
+    for (int k = 0; k < 3; ++k) ICON_HIP(hipEventElapsedTime(&out_ms[k], w->ev[k], w->ev[k + 1]));
+    return ICON_OK;
+}
+
+namespace {
+
+inline void mark(icon_work *w, int k, hipStream_t st)
+{
+    if (w->prof) { (void)hipEventRecord(w->ev[k], st); if (k == 3) w->ev_valid = true; }
+}
+
+int ensure_work(icon_work *w, int64_t n_points)
+{
+    if (n_points > w->cap_points) {
+        (void)hipFree(w->d_x); w->d_x = nullptr; w->cap_points = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_x, (size_t)n_points * kXRow * sizeof(float)));
+        w->cap_points = n_points;
+    }
+    const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
+    if (nblk > w->cap_blocks) {
+        (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
+        w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->cap_blocks = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_block_counts, (size_t)nblk * sizeof(int32_t)));
+        ICON_HIP(hipMalloc((void **)&w->d_block_offsets, (size_t)nblk * sizeof(int64_t)));
+        w->cap_blocks = nblk;
+    }
+    if (n_points > w->cap_signs) {
+        (void)hipFree(w->d_signs); w->d_signs = nullptr; w->cap_signs = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_signs, (size_t)n_points));
+        w->cap_signs = n_points;
+    }
+    if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
+    return ICON_OK;
+}
+
+int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int *c0)
+{
+    ICON_ARG(feat != nullptr, "feature handle is null");
+    const FeatDev &f = feat->dev;
+    if (prior == ICON_PRIOR_ICON) {
+        ICON_ARG(mesh != nullptr, "icon prior needs a mesh handle");
+        ICON_ARG(f.n_select == 2, "icon prior needs feature planes created with n_select = 2");
+        *c0 = f.csel + 7;
+    } else if (prior == ICON_PRIOR_PAMIR) {
+        ICON_ARG(f.n_select == 1 && f.vol != nullptr, "pamir prior needs n_select = 1 and a volume");
+        *c0 = f.csel + f.Cv;
+    } else if (prior == ICON_PRIOR_PIFU) {
+        ICON_ARG(f.n_select == 1, "pifu prior needs n_select = 1");
+        *c0 = f.csel + 1;
+    } else {
+        return fail(ICON_ERR_ARG, "unknown prior_type");
+    }
+    if (*c0 > kCodeSlot) return fail(ICON_ERR_UNSUPPORTED, "more than 15 MLP input channels");
+    return ICON_OK;
+}
+
+template <bool LATTICE>
+int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sdf_clip, int cmap_mode,
+                    const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, int search,
+                    float *d_x, hipStream_t st)
+{
+    int64_t nb;
+    if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
+    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    const dim3 grid((unsigned)nb), block(kBlock);
+    const MeshDev md = mesh ? mesh->dev : MeshDev{};
+    const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
+    const bool brute = (search == ICON_SEARCH_BRUTE);
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, d_x)
+    if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
+    else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
+    else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
+#undef ICON_LAUNCH
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+// count + scan + compact over rows [0, N): fills w->d_block_offsets, w->d_total, and `signs`
+int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
+{
+    const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, w->d_block_counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_block_offsets, w->d_total);
+    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, w->d_block_offsets, signs);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+}  // namespace
+
+namespace icon {
+// device-side K: same as k_outlier_patch but K and the list come from this call's own scan
+__global__ __launch_bounds__(kScanBlock) void k_outlier_patch_self(float *__restrict__ X, int64_t N, int cmap_slot,
+                                                                   const int64_t *block_offsets, const int8_t *signs,
+                                                                   const int64_t *k_total_dev)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    const int64_t K = *k_total_dev;
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const bool o = code & kCodeOutlier;
+    const int64_t j = outlier_rank(o, block_offsets, wsum);
+    if (o) {
+        float *row = X + i * kXRow + cmap_slot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int64_t mm = 3 * j + k;
+            if (mm >= K) mm -= K;
+            if (mm >= K) mm -= K;
+            row[k] = (float)signs[mm];
+        }
+    }
+}
+}  // namespace icon
+
+namespace {
+int patch_only(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
+{
+    const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(icon::k_outlier_patch_self, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, cmap_slot,
+                       w->d_block_offsets, w->d_signs, w->d_total);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+}  // namespace
+
+extern "C" int icon_query_points(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
+                                 int prior_type, float sdf_clip, int cmap_mode, const float *h_calib,
+                                 const float *d_points, int64_t N, float *d_occ,
+                                 int search, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(mlp && work && d_points && d_occ, "icon_query_points: null argument");
+    ICON_ARG(N >= 0, "icon_query_points: negative N");
+    int c0 = 0;
+    int rc = check_prior(mesh, feat, prior_type, &c0);
+    if (rc) return rc;
+    ICON_ARG(c0 == mlp->c0, "icon_query_points: MLP input width does not match the feature layout");
+    if (N == 0) return ICON_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_work(work, N))) return rc;
+    Calib cal;
+    static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    memcpy(cal.m, h_calib ? h_calib : ident, sizeof(cal.m));
+    LatticeMap L{};
+    mark(work, 0, st);
+    if ((rc = launch_features<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, work->d_x, st))) return rc;
+    const bool patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
+    if (patch && (rc = outlier_list(work, N, work->d_signs, st))) return rc;
+    mark(work, 1, st);
+    if (patch && (rc = patch_only(work, N, feat->dev.csel + 1, st))) return rc;
+    mark(work, 2, st);
+    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    mark(work, 3, st);
+    return rc;
+}
+
+static int lattice_map(int res, int z0, int z1, LatticeMap *L)
+{
+    ICON_ARG(res >= 3 && (res & 1) == 1, "lattice resolution must be odd and >= 3 (seg3d_lossless.py:84-86)");
+    ICON_ARG(z0 >= 0 && z1 > z0 && z1 <= res, "bad z range");
+    L->res = res; L->z0 = z0; L->nz = z1 - z0;
+    L->tx = (res + 15) / 16; L->ty = (res + 3) / 4; L->tz = (L->nz + 3) / 4;
+    return ICON_OK;
+}
+
+extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
+                                       int prior_type, float sdf_clip, int cmap_mode,
+                                       int res, int z0, int z1, int8_t *d_signs_local, int64_t *d_count_local,
+                                       int search, icon_work_t *work, void *stream)
+{
+    ICON_ARG(work != nullptr, "icon_grid_slab_features: work is null");
+    int c0 = 0;
+    int rc = check_prior(mesh, feat, prior_type, &c0);
+    if (rc) return rc;
+    LatticeMap L;
+    if ((rc = lattice_map(res, z0, z1, &L))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)L.nz * res * res;
+    if ((rc = ensure_work(work, N))) return rc;
+    Calib cal{};
+    work->slab_ready = false;
+    mark(work, 0, st);
+    if ((rc = launch_features<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, work->d_x, st))) return rc;
+    work->slab_needs_patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
+    work->slab_cmap_slot = feat->dev.csel + 1;
+    work->slab_c0 = c0;
+    if (work->slab_needs_patch) {
+        int8_t *signs = d_signs_local ? d_signs_local : work->d_signs;
+        if ((rc = outlier_list(work, N, signs, st))) return rc;
+        if (d_count_local)
+            ICON_HIP(hipMemcpyAsync(d_count_local, work->d_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    } else if (d_count_local) {
+        ICON_HIP(hipMemsetAsync(d_count_local, 0, sizeof(int64_t), st));
+    }
+    mark(work, 1, st);
+    work->slab_res = res; work->slab_z0 = z0; work->slab_z1 = z1; work->slab_ready = true;
+    return ICON_OK;
+}
+
+extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
+                                     const int8_t *d_signs_global, int64_t k_total, int64_t rank_offset,
+                                     float *d_occ, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(mlp && work && d_occ, "icon_grid_slab_finish: null argument");
+    if (!work->slab_ready || work->slab_res != res || work->slab_z0 != z0 || work->slab_z1 != z1)
+        return fail(ICON_ERR_STATE, "icon_grid_slab_finish: no matching icon_grid_slab_features call on this workspace");
+    ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_slab_finish: MLP input width does not match the feature layout");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)(z1 - z0) * res * res;
+    if (work->slab_needs_patch && k_total > 0) {
+        ICON_ARG(d_signs_global != nullptr, "icon_grid_slab_finish: sign list is null");
+        const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+        hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, N, work->slab_cmap_slot,
+                           work->d_block_offsets, d_signs_global, k_total, rank_offset);
+        ICON_HIP(hipGetLastError());
+    }
+    mark(work, 2, st);
+    work->slab_ready = false;
+    const int rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    mark(work, 3, st);
+    return rc;
+}
+
+extern "C" int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
+                                   int prior_type, float sdf_clip, int cmap_mode,
+                                   int res, int z0, int z1, float *d_occ,
+                                   int search, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(mlp && work && d_occ, "icon_grid_eval_slab: null argument");
+    int rc = icon_grid_slab_features(mesh, feat, prior_type, sdf_clip, cmap_mode, res, z0, z1, nullptr, nullptr, search, work, stream);
+    if (rc) return rc;
+    ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_eval_slab: MLP input width does not match the feature layout");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)(z1 - z0) * res * res;
+    // the slab's own sign list is the whole list (single call == whole lattice or caller's choice)
+    if (work->slab_needs_patch && (rc = patch_only(work, N, work->slab_cmap_slot, st))) return rc;
+    mark(work, 2, st);
+    work->slab_ready = false;
+    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    mark(work, 3, st);
+    return rc;
+}

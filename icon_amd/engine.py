@@ -1,0 +1,416 @@
+"""Host-side mirror of the reference's query interface, on top of the C ABI (include/icon_amd.h).
+
+What a user of the reference sees (paths relative to the reference root):
+
+* ``IconQueryEngine.query(features, points, calibs, transforms=None, regressor=None)``
+  == ``HGPIFuNet.query`` (lib/net/HGPIFuNet.py:268-367): same arguments, same ``[ [1,1,N] ]`` return.
+* ``query_func(opt, netG, features, points, proj_matrix=None)``
+  == lib/common/train_util.py:324-348.
+* ``DenseReconEngine`` == the ``reconEngine`` object (``Seg3dLossless``, lib/common/seg3d_lossless.py:36,
+  constructed at apps/ICON.py:78-90): ``forward(**kwargs) -> Tensor[D,H,W] | None``, ``export_mesh``,
+  ``resolutions`` / ``b_min`` / ``b_max`` buffers; it is an ``nn.Module`` so the checkpoint filters
+  that look for the substring ``reconEngine`` keep working (lib/dataset/mesh_util.py:203).
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); all per-point arithmetic is
+in the HIP kernels.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import IconAmdError, check, ptr
+
+
+def _stream() -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _key(*tensors) -> tuple:
+    return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors)
+
+
+def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise IconAmdError(f"{what} is on {t.device}; icon_amd has no CPU path - move it to the HIP device")
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _Handle:
+    _destroy = None
+
+    def __init__(self):
+        self.h = C.c_void_p(0)
+
+    def close(self):
+        if self.h and self.h.value:
+            getattr(_lib.lib(), self._destroy)(self.h)
+            self.h = C.c_void_p(0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class MeshHandle(_Handle):
+    """Per-image SMPL body (icon_mesh_create): the tensors of ``smpl_feat_dict``
+    (lib/net/HGPIFuNet.py:236-240), batch size 1."""
+    _destroy = "icon_mesh_destroy"
+
+    def __init__(self, smpl_verts, smpl_faces, smpl_cmap, smpl_vis):
+        super().__init__()
+        _lib.require_device()
+        v = _dev_f32(smpl_verts, "smpl_verts").reshape(-1, 3)
+        f = smpl_faces.detach()
+        if not f.is_cuda:
+            raise IconAmdError("smpl_faces must be on the HIP device")
+        f = f.to(torch.int64).reshape(-1, 3).contiguous()
+        cm = _dev_f32(smpl_cmap, "smpl_cmap").reshape(-1, 3)
+        vs = _dev_f32(smpl_vis, "smpl_vis").reshape(-1)
+        if cm.shape[0] != v.shape[0] or vs.shape[0] != v.shape[0]:
+            raise IconAmdError("smpl_cmap / smpl_vis do not match smpl_verts")
+        self.V, self.F = int(v.shape[0]), int(f.shape[0])
+        self.device = v.device
+        check(_lib.lib().icon_mesh_create(ptr(v), C.c_int64(self.V), ptr(f), C.c_int64(self.F), ptr(cm), ptr(vs),
+                                          _stream(), C.byref(self.h)), "icon_mesh_create")
+
+    def vertex_normals(self) -> torch.Tensor:
+        out = torch.empty((self.V, 3), dtype=torch.float32, device=self.device)
+        check(_lib.lib().icon_mesh_vertex_normals(self.h, ptr(out), _stream()), "icon_mesh_vertex_normals")
+        return out
+
+    def stats(self) -> dict:
+        arr = (C.c_int64 * 4)()
+        check(_lib.lib().icon_mesh_stats(self.h, arr), "icon_mesh_stats")
+        return dict(nodes=arr[0], depth=arr[1], bin_entries=arr[2], max_bin=arr[3])
+
+    def sdf_query(self, points: torch.Tensor, search: str = "bvh"):
+        """cal_sdf_batch (lib/dataset/mesh_util.py:357-396) for points [N,3] ->
+        dict(sdf [N], norm [N,3], cmap [N,3], vis [N], face [N] i64, inside [N] bool)"""
+        p = _dev_f32(points, "points").reshape(-1, 3)
+        n = p.shape[0]
+        dev = p.device
+        out = dict(sdf=torch.empty(n, device=dev), norm=torch.empty((n, 3), device=dev),
+                   cmap=torch.empty((n, 3), device=dev), vis=torch.empty(n, device=dev),
+                   face=torch.empty(n, dtype=torch.int64, device=dev),
+                   inside=torch.empty(n, dtype=torch.uint8, device=dev))
+        check(_lib.lib().icon_sdf_query(self.h, ptr(p), C.c_int64(n), ptr(out["sdf"]), ptr(out["norm"]),
+                                        ptr(out["cmap"]), ptr(out["vis"]), ptr(out["face"]), ptr(out["inside"]),
+                                        C.c_int(_lib.SEARCH[search]), _stream()), "icon_sdf_query")
+        out["inside"] = out["inside"].bool()
+        return out
+
+
+class FeatHandle(_Handle):
+    """Feature planes ``features[-1]`` of HGPIFuNet.filter ([1,C,H,W]) and, for PaMIR, the volume
+    encoder output ([1,Cv,D,H,W]); icon_feat_create."""
+    _destroy = "icon_feat_destroy"
+
+    def __init__(self, planes: torch.Tensor, n_select: int, vol: Optional[torch.Tensor] = None):
+        super().__init__()
+        _lib.require_device()
+        p = _dev_f32(planes, "features")
+        if p.dim() == 4:
+            if p.shape[0] != 1:
+                raise IconAmdError("batch size must be 1 (lib/common/seg3d_lossless.py:73)")
+            p = p[0]
+        p = p.contiguous()
+        Cc, H, W = (int(s) for s in p.shape)
+        vp, Cv, Dv, Hv, Wv = C.c_void_p(0), 0, 0, 0, 0
+        if vol is not None:
+            v = _dev_f32(vol, "vol_feat")
+            if v.dim() == 5:
+                v = v[0]
+            v = v.contiguous()
+            Cv, Dv, Hv, Wv = (int(s) for s in v.shape)
+            vp = ptr(v)
+        self.C, self.H, self.W, self.n_select, self.Cv = Cc, H, W, n_select, Cv
+        check(_lib.lib().icon_feat_create(ptr(p), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_int(n_select), vp,
+                                          C.c_int(Cv), C.c_int(Dv), C.c_int(Hv), C.c_int(Wv), _stream(),
+                                          C.byref(self.h)), "icon_feat_create")
+        torch.cuda.current_stream().synchronize()   # source tensors may be temporaries
+
+
+def _np32(t) -> np.ndarray:
+    if isinstance(t, torch.Tensor):
+        t = t.detach().to("cpu", torch.float32).numpy()
+    return np.ascontiguousarray(t, dtype=np.float32)
+
+
+class MlpHandle(_Handle):
+    """``if_regressor`` weights in reference state_dict layout (``filters.{l}.weight [Cout,Cin,1]``,
+    ``filters.{l}.bias``, ``norms.{l}.{weight,bias,running_mean,running_var}``; lib/net/MLP.py:26-45);
+    icon_mlp_create folds BatchNorm and packs the MFMA operands."""
+    _destroy = "icon_mlp_destroy"
+
+    def __init__(self, state_dict, res_layers: Sequence[int] = (2, 3, 4), bn_eps: float = 1e-5):
+        super().__init__()
+        _lib.require_device()
+        n = 0
+        while f"filters.{n}.weight" in state_dict:
+            n += 1
+        if n == 0:
+            raise IconAmdError("state_dict has no filters.0.weight")
+        W = [_np32(state_dict[f"filters.{l}.weight"]) for l in range(n)]
+        W = [w.reshape(w.shape[0], -1) for w in W]
+        b = [_np32(state_dict[f"filters.{l}.bias"]) for l in range(n)]
+        has_bn = f"norms.0.running_mean" in state_dict
+        cin = (C.c_int * n)(*[w.shape[1] for w in W])
+        cout = (C.c_int * n)(*[w.shape[0] for w in W])
+        is_res = (C.c_int * n)(*[1 if l in tuple(res_layers) else 0 for l in range(n)])
+        self.c0 = int(W[0].shape[1])
+
+        def parr(arrs):
+            return (C.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+
+        keep = [W, b]
+        if has_bn:
+            bn = [[_np32(state_dict[f"norms.{l}.{k}"]) for l in range(n - 1)]
+                  for k in ("weight", "bias", "running_mean", "running_var")]
+            keep.append(bn)
+            bn_ptrs = [parr(x) for x in bn]
+        else:
+            bn_ptrs = [None] * 4
+        check(_lib.lib().icon_mlp_create(C.c_int(n), cin, cout, is_res, parr(W), parr(b), bn_ptrs[0], bn_ptrs[1],
+                                         bn_ptrs[2], bn_ptrs[3], C.c_float(bn_eps), _stream(), C.byref(self.h)),
+              "icon_mlp_create")
+
+    def forward(self, x: torch.Tensor, precision: str = "f32") -> torch.Tensor:
+        """MLP.forward on point-major rows x [N,16] (slots >= c0 ignored) -> [N]"""
+        x = _dev_f32(x, "x")
+        if x.dim() != 2 or x.shape[1] != 16:
+            raise IconAmdError("x must be [N,16]")
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+        check(_lib.lib().icon_mlp_forward(self.h, ptr(x), C.c_int64(x.shape[0]), ptr(out),
+                                          C.c_int(_lib.PRECISION[precision]), _stream()), "icon_mlp_forward")
+        return out
+
+
+class Workspace(_Handle):
+    _destroy = "icon_work_destroy"
+
+    def __init__(self):
+        super().__init__()
+        check(_lib.lib().icon_work_create(C.byref(self.h)), "icon_work_create")
+
+    def profile(self, enable: bool = True) -> None:
+        check(_lib.lib().icon_work_profile(self.h, C.c_int(int(enable))), "icon_work_profile")
+
+    def stage_ms(self):
+        """(features_ms, patch_ms, mlp_ms) of the most recent call, from HIP events on its stream"""
+        out = (C.c_float * 3)()
+        check(_lib.lib().icon_work_stage_ms(self.h, out), "icon_work_stage_ms")
+        return float(out[0]), float(out[1]), float(out[2])
+
+
+def regressor_state_dict(regressor) -> dict:
+    """state_dict of an ``MLP`` module (lib/net/MLP.py) or a dict already in that layout."""
+    if isinstance(regressor, dict):
+        return regressor
+    return {k: v for k, v in regressor.state_dict().items() if "num_batches_tracked" not in k}
+
+
+class IconQueryEngine:
+    """Drop-in for ``HGPIFuNet.query`` (lib/net/HGPIFuNet.py:268-367).
+
+    Either attach it to a constructed reference network (``IconQueryEngine.attach(netG)`` replaces
+    ``netG.query`` and reads ``netG.smpl_feat_dict / sdf_clip / prior_type / smpl_feats`` exactly
+    as the method does), or use it standalone via ``set_mesh`` / ``set_regressor``.
+    """
+
+    def __init__(self, prior_type: str = "icon", sdf_clip: float = 0.05,
+                 smpl_feats: Sequence[str] = ("sdf", "norm", "vis", "cmap"),
+                 cmap_mode: str = "reference", search: str = "bvh", precision: str = "f32",
+                 res_layers: Sequence[int] = (2, 3, 4)):
+        if prior_type not in _lib.PRIOR:
+            raise IconAmdError(f"unknown prior_type {prior_type!r}")
+        if prior_type == "icon" and set(smpl_feats) != {"sdf", "norm", "vis", "cmap"}:
+            raise IconAmdError("the icon kernels are built for smpl_feats = [sdf, norm, vis, cmap] "
+                               "(configs/icon-filter.yaml:16); other subsets are not supported")
+        self.prior_type, self.sdf_clip = prior_type, float(sdf_clip)
+        self.cmap_mode, self.search, self.precision = cmap_mode, search, precision
+        self.res_layers = tuple(res_layers)
+        self.netG = None
+        self.work = None
+        self._mesh = self._mesh_key = None
+        self._feat = self._feat_key = None
+        self._mlp = self._mlp_key = None
+        self._vol = self._vol_key = None
+        self._smpl_feat_dict = None
+        self._regressor = None
+
+    # ---- binding -----------------------------------------------------------------------------
+    @classmethod
+    def attach(cls, netG, **kw) -> "IconQueryEngine":
+        """Replace ``netG.query`` by the HIP path; everything else on netG is untouched."""
+        eng = cls(prior_type=netG.prior_type, sdf_clip=netG.sdf_clip,
+                  smpl_feats=getattr(netG, "smpl_feats", ("sdf", "norm", "vis", "cmap")),
+                  res_layers=getattr(netG.if_regressor, "res_layers", (2, 3, 4)), **kw)
+        eng.netG = netG
+        netG.query = eng.query
+        netG.icon_amd_engine = eng
+        return eng
+
+    def set_mesh(self, smpl_verts, smpl_faces, smpl_cmap, smpl_vis) -> None:
+        self._smpl_feat_dict = dict(smpl_verts=smpl_verts, smpl_faces=smpl_faces, smpl_cmap=smpl_cmap,
+                                    smpl_vis=smpl_vis)
+
+    def set_regressor(self, regressor) -> None:
+        self._regressor = regressor
+
+    def set_volume_features(self, vol_feat: torch.Tensor) -> None:
+        """PaMIR: the VolumeEncoder output [1,Cv,D,H,W] (lib/net/HGPIFuNet.py:321-325), computed once
+        per image on PyTorch-ROCm by the caller (hoisted out of query())."""
+        self._vol = vol_feat
+
+    # ---- handle caches ---------------------------------------------------------------------------
+    def _work(self) -> Workspace:
+        if self.work is None:
+            self.work = Workspace()
+        return self.work
+
+    def _mesh_handle(self) -> Optional[MeshHandle]:
+        if self.prior_type != "icon":
+            return None
+        d = self.netG.smpl_feat_dict if self.netG is not None else self._smpl_feat_dict
+        if d is None:
+            raise IconAmdError("no SMPL tensors bound: call filter() on the network or set_mesh() first")
+        ts = (d["smpl_verts"], d["smpl_faces"], d["smpl_cmap"], d["smpl_vis"])
+        k = _key(*ts)
+        if k != self._mesh_key:
+            self._mesh = MeshHandle(*ts)
+            self._mesh_key = k
+        return self._mesh
+
+    def _feat_handle(self, im_feat: torch.Tensor) -> FeatHandle:
+        vol = self._pamir_volume() if self.prior_type == "pamir" else None
+        k = _key(im_feat) + (_key(vol) if vol is not None else ())
+        if k != self._feat_key:
+            self._feat = FeatHandle(im_feat, 2 if self.prior_type == "icon" else 1, vol)
+            self._feat_key = k
+        return self._feat
+
+    def _pamir_volume(self) -> torch.Tensor:
+        if self._vol is not None:
+            return self._vol
+        netG = self.netG
+        if netG is None or not hasattr(netG, "voxelization"):
+            raise IconAmdError("pamir prior: call set_volume_features(vol_feat) (VolumeEncoder output)")
+        d = netG.smpl_feat_dict
+        k = _key(d["voxel_verts"], d["voxel_faces"])
+        if k != self._vol_key:   # reference recomputes this on every query(); it only depends on the image
+            vv = d["voxel_verts"][:, :-d["pad_v_num"][0], :]
+            vf = d["voxel_faces"][:, :-d["pad_f_num"][0], :]
+            netG.voxelization.update_param(batch_size=vf.shape[0], smpl_tetra=vf[0].detach().cpu().numpy())
+            self._vol_cached = netG.ve(netG.voxelization(vv), intermediate_output=False)[-1]
+            self._vol_key = k
+        return self._vol_cached
+
+    def _mlp_handle(self, regressor=None) -> MlpHandle:
+        reg = regressor if regressor is not None else self._regressor
+        if reg is None and self.netG is not None:
+            reg = self.netG.if_regressor
+        if reg is None:
+            raise IconAmdError("no regressor bound: pass regressor= or call set_regressor()")
+        sd = regressor_state_dict(reg)
+        k = tuple((n, ) + (_key(t)[0] if isinstance(t, torch.Tensor) else (id(t),)) for n, t in sd.items())
+        if k != self._mlp_key:
+            self._mlp = MlpHandle(sd, self.res_layers)
+            self._mlp_key = k
+        return self._mlp
+
+    # ---- HGPIFuNet.query ---------------------------------------------------------------------------
+    def query(self, features, points, calibs, transforms=None, regressor=None):
+        """features: list of [1,C,H,W]; points [1,3,N]; calibs [1,4,4] (or [1,3,4]) -> list of [1,1,N]"""
+        if points.dim() != 3 or points.shape[0] != 1 or points.shape[1] != 3:
+            raise IconAmdError("points must be [1,3,N] (batch size 1)")
+        if not points.is_cuda:
+            raise IconAmdError("points are on the CPU; icon_amd has no CPU path")
+        n = int(points.shape[2])
+        if transforms is not None:
+            # orthogonal() with an image transform (lib/net/geometry.py:57-60): do it in torch, then
+            # hand already-projected points to the kernel with an identity calibration
+            rot, trans = calibs[:, :3, :3], calibs[:, :3, 3:4]
+            pts = torch.baddbmm(trans, rot, points)
+            pts[:, :2, :] = torch.baddbmm(transforms[:2, 2:3], transforms[:2, :2], pts[:, :2, :])
+            calib12 = None
+            pts = pts[0].t().contiguous()
+        else:
+            calib12 = np.ascontiguousarray(calibs[0, :3, :4].detach().to("cpu", torch.float32).numpy())
+            pts = points[0].t().to(torch.float32).contiguous()
+        mesh = self._mesh_handle()
+        mlp = self._mlp_handle(regressor)
+        preds = []
+        for im_feat in features:
+            feat = self._feat_handle(im_feat)
+            occ = torch.empty(n, dtype=torch.float32, device=points.device)
+            check(_lib.lib().icon_query_points(
+                mesh.h if mesh is not None else C.c_void_p(0), feat.h, mlp.h, C.c_int(_lib.PRIOR[self.prior_type]),
+                C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]),
+                ptr(calib12) if calib12 is not None else C.c_void_p(0), ptr(pts), C.c_int64(n), ptr(occ),
+                C.c_int(_lib.SEARCH[self.search]), C.c_int(_lib.PRECISION[self.precision]), self._work().h, _stream()),
+                "icon_query_points")
+            preds.append(occ.view(1, 1, n))
+        return preds
+
+    # ---- dense lattice (one rank's share of reconEngine) ------------------------------------------------
+    def eval_slab(self, im_feat, res: int, z0: int, z1: int, regressor=None, out=None) -> torch.Tensor:
+        mesh, mlp, feat = self._mesh_handle(), self._mlp_handle(regressor), self._feat_handle(im_feat)
+        if out is None:
+            out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=im_feat.device)
+        check(_lib.lib().icon_grid_eval_slab(
+            mesh.h if mesh is not None else C.c_void_p(0), feat.h, mlp.h, C.c_int(_lib.PRIOR[self.prior_type]),
+            C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
+            C.c_int(z1), ptr(out), C.c_int(_lib.SEARCH[self.search]), C.c_int(_lib.PRECISION[self.precision]),
+            self._work().h, _stream()), "icon_grid_eval_slab")
+        return out
+
+    def slab_features(self, im_feat, res: int, z0: int, z1: int):
+        """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device)"""
+        mesh, feat = self._mesh_handle(), self._feat_handle(im_feat)
+        n = (z1 - z0) * res * res
+        signs = torch.empty(n, dtype=torch.int8, device=im_feat.device)
+        count = torch.zeros(1, dtype=torch.int64, device=im_feat.device)
+        check(_lib.lib().icon_grid_slab_features(
+            mesh.h if mesh is not None else C.c_void_p(0), feat.h, C.c_int(_lib.PRIOR[self.prior_type]),
+            C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
+            C.c_int(z1), ptr(signs), ptr(count), C.c_int(_lib.SEARCH[self.search]), self._work().h, _stream()),
+            "icon_grid_slab_features")
+        return signs, count
+
+    def slab_finish(self, res: int, z0: int, z1: int, signs_global, k_total: int, rank_offset: int,
+                    regressor=None, out=None, device=None) -> torch.Tensor:
+        mlp = self._mlp_handle(regressor)
+        if out is None:
+            out = torch.empty((z1 - z0, res, res), dtype=torch.float32,
+                              device=device if device is not None else signs_global.device)
+        check(_lib.lib().icon_grid_slab_finish(
+            mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), ptr(signs_global) if signs_global is not None else C.c_void_p(0),
+            C.c_int64(k_total), C.c_int64(rank_offset), ptr(out), C.c_int(_lib.PRECISION[self.precision]),
+            self._work().h, _stream()), "icon_grid_slab_finish")
+        return out
+
+
+def query_func(opt, netG, features, points, proj_matrix=None):
+    """lib/common/train_util.py:324-348, verbatim contract: points [1,N,3] -> [1,1,N].
+    ``netG`` is either a reference HGPIFuNet with an attached engine or an IconQueryEngine."""
+    assert len(points) == 1
+    if getattr(opt, "num_views", 1) != 1:
+        raise IconAmdError("num_views must be 1 (lib/common/config.py:34)")
+    samples = points.permute(0, 2, 1)  # [1,3,N]
+    if proj_matrix is not None:
+        rot, trans = proj_matrix[:, :3, :3], proj_matrix[:, :3, 3:4]
+        samples = torch.baddbmm(trans, rot, samples)
+    calib = torch.eye(4, dtype=torch.float32, device=samples.device)[None]
+    regressor = getattr(netG, "if_regressor", None)
+    preds = netG.query(features=features, points=samples, calibs=calib, regressor=regressor)
+    if type(preds) is list:
+        preds = preds[0]
+    return preds

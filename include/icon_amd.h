@@ -1,0 +1,198 @@
+/*
+ * icon_amd.h - C ABI of the MI355X-native implicit-surface query engine for ICON.
+ *
+ * The reference (YuliangXiu/ICON) has no FFI / plugin registry on this path: the seam is two
+ * Python call signatures plus module state.  This header is the boundary a
+ * maintainer binds with ctypes; every entry point cites the reference
+ * code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - all `d_*` pointers are DEVICE pointers (HIP), all `h_*` pointers are HOST pointers;
+ *   - float data is float32, indices int64 (as in the reference) unless stated;
+ *   - every call that launches work enqueues it on `stream` (a hipStream_t passed as void*) and
+ *     returns without synchronising, except where the comment says "synchronises";
+ *   - return value: 0 on success, non-zero error code otherwise; icon_last_error() returns a
+ *     thread-local human-readable message.  No CPU fallback exists: without a GPU every compute
+ *     entry point fails with ICON_ERR_HIP.
+ */
+#ifndef ICON_AMD_H
+#define ICON_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ICON_AMD_VERSION 100          /* 0.1.0 */
+
+enum {
+    ICON_OK = 0,
+    ICON_ERR_ARG = 1,                 /* bad argument (null, shape, range)         */
+    ICON_ERR_HIP = 2,                 /* HIP runtime error (message has details)   */
+    ICON_ERR_UNSUPPORTED = 3,         /* shape outside what the kernels are built for */
+    ICON_ERR_STATE = 4                /* call order violated (e.g. finish before features) */
+};
+
+/* prior_type of lib/net/HGPIFuNet.py:63 */
+enum { ICON_PRIOR_ICON = 0, ICON_PRIOR_PAMIR = 1, ICON_PRIOR_PIFU = 2 };
+
+/* How clipped ("outlier") points get their cmap channels, lib/net/HGPIFuNet.py:298-305.
+ * REFERENCE reproduces the reference bit for bit: smpl_sdf[outlier].repeat(1,1,3) tiles the
+ * list of outlier signs of the whole call, so the j-th outlier's channel k receives the sign of
+ * outlier (3j+k) mod K.  LOCAL is the per-point rule (cmap := own sign). */
+enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
+
+/* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
+enum { ICON_SEARCH_BVH = 0, ICON_SEARCH_BRUTE = 1 };
+
+typedef struct icon_mesh icon_mesh_t;   /* per-image SMPL body: triangles, normals, BVH, ray bins   */
+typedef struct icon_feat icon_feat_t;   /* per-image feature planes (and PaMIR volume), repacked    */
+typedef struct icon_mlp  icon_mlp_t;    /* if_regressor weights, BatchNorm folded, MFMA operand order */
+typedef struct icon_work icon_work_t;   /* reusable device workspace                                  */
+
+const char *icon_last_error(void);
+int icon_version(void);
+/* number of HIP devices visible; 0 (not an error) when there is none */
+int icon_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Mesh: the per-image half of cal_sdf_batch (lib/dataset/mesh_util.py:357-372):
+ *   Meshes(verts, faces).verts_normals_padded()            :367  (pytorch3d leaf)
+ *   face_vertices(verts|normals|cmaps|vis, faces)          :369-372, lib/common/render_utils.py:149-163
+ * plus the acceleration structures our kernels need (BVH over triangles, (y,z) ray bins).
+ * The reference redoes this work on every query() call; here it is once per image.
+ * d_verts [V,3] f32, d_faces [F,3] i64, d_cmap [V,3] f32, d_vis [V] f32 (the [1,V,1] tensor).
+ * Synchronises (copies the mesh to the host to build the BVH).
+ * ------------------------------------------------------------------------------------------- */
+int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *d_faces, int64_t F,
+                     const float *d_cmap, const float *d_vis, void *stream, icon_mesh_t **out);
+int icon_mesh_destroy(icon_mesh_t *mesh);
+/* copy the area-weighted unit vertex normals [V,3] to a device buffer (for tests) */
+int icon_mesh_vertex_normals(const icon_mesh_t *mesh, float *d_out, void *stream);
+/* BVH statistics: out[0]=nodes, out[1]=max depth, out[2]=ray-bin entries, out[3]=max bin length */
+int icon_mesh_stats(const icon_mesh_t *mesh, int64_t out[4]);
+
+/* ---------------------------------------------------------------------------------------------
+ * cal_sdf_batch, per-point half (lib/dataset/mesh_util.py:374-396):
+ *   point_to_mesh_distance (kaolin leaf) :374, gathers :375-382,
+ *   barycentric_coordinates_of_projection :319-354,383, weighted sums :385-391,
+ *   check_sign (kaolin leaf) :393.
+ * d_points [N,3]; outputs d_sdf [N], d_norm [N,3], d_cmap [N,3], d_vis [N] (0/1 as float),
+ * optional d_face [N] int64 (nearest face index) and d_inside [N] uint8.  Unclipped, as
+ * cal_sdf_batch returns them.
+ * ------------------------------------------------------------------------------------------- */
+int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, int64_t N,
+                   float *d_sdf, float *d_norm, float *d_cmap, float *d_vis,
+                   int64_t *d_face, uint8_t *d_inside, int search, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Feature planes: what index() samples (lib/net/geometry.py:21-43):
+ *   d_planes [C,H,W] f32 - features[-1][0] from HGPIFuNet.filter (lib/net/HGPIFuNet.py:204-266);
+ *   d_vol [Cv,D,H,W] f32 or NULL - VolumeEncoder output (PaMIR, lib/net/HGPIFuNet.py:321-325).
+ * n_select = 2 for the icon prior (front/back halves chosen by feat_select,
+ * lib/dataset/mesh_util.py:266-277), 1 otherwise.  Repacks to channel-last so one bilinear tap
+ * is one or two 16-byte loads.
+ * ------------------------------------------------------------------------------------------- */
+int icon_feat_create(const float *d_planes, int C, int H, int W, int n_select,
+                     const float *d_vol, int Cv, int Dv, int Hv, int Wv,
+                     void *stream, icon_feat_t **out);
+int icon_feat_destroy(icon_feat_t *feat);
+
+/* ---------------------------------------------------------------------------------------------
+ * MLP (lib/net/MLP.py:8-72 as built by lib/net/HGPIFuNet.py:128-133): Conv1d(k=1) stack with
+ * BatchNorm1d (eval) + LeakyReLU(0.01) after all but the last layer, raw input re-concatenated
+ * (after the activations, MLP.py:62) before the layers flagged in is_res, no last_op (test mode).
+ * HOST pointers, reference state_dict layout:
+ *   h_W[l] [cout[l], cin[l]], h_b[l] [cout[l]],
+ *   h_bn_gamma/beta/mean/var[l] [cout[l]] for l < n_layers-1 (NULL arrays => no norm).
+ * Supported: n_layers == 4, cin[0] <= 15, cout = {512,256,128,1}, is_res = {0,0,1,1}
+ * (every config in configs/ *.yaml).  BatchNorm is folded in float64 on the host.
+ * ------------------------------------------------------------------------------------------- */
+int icon_mlp_create(int n_layers, const int *cin, const int *cout, const int *is_res,
+                    const float *const *h_W, const float *const *h_b,
+                    const float *const *h_bn_gamma, const float *const *h_bn_beta,
+                    const float *const *h_bn_mean, const float *const *h_bn_var,
+                    float bn_eps, void *stream, icon_mlp_t **out);
+int icon_mlp_destroy(icon_mlp_t *mlp);
+/* MLP.forward on point-major input rows: d_x [N,16] f32 (channels cin[0]..15 ignored),
+ * d_out [N].  precision: 0 = exact-f32 MFMA path. */
+int icon_mlp_forward(const icon_mlp_t *mlp, const float *d_x, int64_t N, float *d_out,
+                     int precision, void *stream);
+
+/* workspace: grows on demand, reusable across calls on one stream */
+int icon_work_create(icon_work_t **out);
+int icon_work_destroy(icon_work_t *work);
+/* Stage timing with HIP events recorded on the caller's stream (bench.py's live roofline leg).
+ * After enabling, every icon_query_points / icon_grid_* call brackets its stages with events;
+ * icon_work_stage_ms synchronises on the last one and returns milliseconds of the most recent
+ * call: out_ms[0] = features (SDF + gather + outlier count/scan/compact),
+ *       out_ms[1] = outlier cmap patch, out_ms[2] = MLP kernel alone. */
+int icon_work_profile(icon_work_t *work, int enable);
+int icon_work_stage_ms(icon_work_t *work, float out_ms[3]);
+
+/* ---------------------------------------------------------------------------------------------
+ * HGPIFuNet.query (lib/net/HGPIFuNet.py:268-367) for explicit points:
+ *   xyz = orthogonal(points, calib)                lib/net/geometry.py:46-61  (h_calib: 12 floats,
+ *         row-major [3,4] = calibs[0,:3,:4]; NULL = identity as query_func passes,
+ *         lib/common/train_util.py:340)
+ *   icon : cal_sdf_batch + clipping (:285-305), index + feat_select (:335-336), cat (:343,359)
+ *   pamir: index(im_feat, xy) ++ index(vol_feat, xyz)   (:348-354)
+ *   pifu : index(im_feat, xy) ++ z                       (:356-357)
+ *   preds = in_cube * regressor(point_feat)              (:274-275,361-363)
+ * d_points [N,3] (the [1,3,N] tensor transposed), d_occ [N].
+ * mesh may be NULL for the pamir / pifu priors.
+ * ------------------------------------------------------------------------------------------- */
+int icon_query_points(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
+                      int prior_type, float sdf_clip, int cmap_mode, const float *h_calib,
+                      const float *d_points, int64_t N, float *d_occ,
+                      int search, int precision, icon_work_t *work, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dense lattice evaluation: one rank's Z-slab of reconEngine (lib/common/seg3d_lossless.py).
+ * Lattice of `res`^3 points (res odd, :84-86), world mapping of batch_eval (:125-137) with
+ * align_corners=True, b_min=[-1,1,-1], b_max=[1,-1,1] (apps/ICON.py:78-90), identity calibration
+ * (lib/common/train_util.py:340); output layout [z, y, x] as `occupancys.view(..., D, H, W)`
+ * (seg3d_lossless.py:171).  Evaluates planes z0 <= z < z1 into d_occ [(z1-z0), res, res].
+ *
+ * The result equals ONE query() call over the whole lattice in z,y,x order, i.e. what
+ * Seg3dLossless computes with resolutions=[res].
+ *
+ * Single call (single GPU, or ICON_CMAP_LOCAL on any number of GPUs):
+ * ------------------------------------------------------------------------------------------- */
+int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
+                        int prior_type, float sdf_clip, int cmap_mode,
+                        int res, int z0, int z1, float *d_occ,
+                        int search, int precision, icon_work_t *work, void *stream);
+
+/* Split form for Z-slab sharding with ICON_CMAP_REFERENCE, where the outlier sign list of the
+ * WHOLE lattice is needed before any slab can finish:
+ *   1. icon_grid_slab_features: SDF + gather for the slab; writes the slab's outlier signs
+ *      (int8, +1/-1/0, lattice order) to d_signs_local (capacity (z1-z0)*res*res) and the
+ *      count to *d_count_local (device int64).
+ *   2. caller exchanges counts and sign lists between ranks (RCCL all_gather) and builds the
+ *      concatenated list d_signs_global [K_total] in rank order;
+ *   3. icon_grid_slab_finish: patches the slab's cmap channels from the global list
+ *      (rank_offset = number of outliers in lower slabs) and runs the MLP. */
+int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
+                            int prior_type, float sdf_clip, int cmap_mode,
+                            int res, int z0, int z1, int8_t *d_signs_local, int64_t *d_count_local,
+                            int search, icon_work_t *work, void *stream);
+int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
+                          const int8_t *d_signs_global, int64_t k_total, int64_t rank_offset,
+                          float *d_occ, int precision, icon_work_t *work, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Seg3dLossless.export_mesh (lib/common/seg3d_lossless.py:583-604): marching cubes at 0.5 on
+ * occ[1:,1:,1:]; vertices returned as (x,y,z) in voxel units of the cropped grid
+ * (verts[:, [2,1,0]]), faces with flipped winding (faces[:, [0,2,1]]).
+ * h_occ: HOST [res,res,res] f32.  Two-call protocol: call with h_verts == NULL to get the counts,
+ * then with buffers of that size.
+ * ------------------------------------------------------------------------------------------- */
+int icon_export_mesh(const float *h_occ, int res, float level,
+                     float *h_verts, int64_t *n_verts, int64_t *h_faces, int64_t *n_faces);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICON_AMD_H */

@@ -404,10 +404,12 @@ void orc_project(const float *calib, const float *pts, int64_t N, float *xyz)
 {
     for (int64_t i = 0; i < N; ++i)
         for (int r = 0; r < 3; ++r) {
+            /* (rot @ p) as a k-ordered fma chain, then + trans: bit-identical to ATen's CPU
+             * baddbmm for K = 3 (probe in tests/test_oracle_vs_reference.py); exact for identity */
             float acc = calib[4 * r + 0] * pts[3 * i];
-            acc += calib[4 * r + 1] * pts[3 * i + 1];
-            acc += calib[4 * r + 2] * pts[3 * i + 2];
-            xyz[3 * i + r] = calib[4 * r + 3] + acc;
+            acc = fmaf(calib[4 * r + 1], pts[3 * i + 1], acc);
+            acc = fmaf(calib[4 * r + 2], pts[3 * i + 2], acc);
+            xyz[3 * i + r] = acc + calib[4 * r + 3];
         }
 }
 

@@ -1,0 +1,344 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle and against the
+golden fixtures generated from the reference's own Python.
+
+Bars (DESIGN.md "Parity"):
+  * integer / boolean outputs - nearest face index, inside flag, visibility flag, the outlier
+    sign list - BIT-EXACT against the oracle (same float32 operation sequence on both sides);
+  * sdf / norm / cmap / image features: <= 1e-6 absolute (they are bit-exact in practice);
+  * occupancy: <= 1e-4 absolute (north-star tolerance), observed ~1e-6: the only difference is
+    the summation order of the MLP dot products and the float64 BatchNorm fold.
+"""
+import numpy as np
+import pytest
+import torch
+
+from common import assets, golden, oracle_query, orc, rows16, vol_assets
+from icon_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+OCC_TOL = 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x)).to(dev())
+
+
+def make_engine(a, **kw):
+    from icon_amd.engine import IconQueryEngine
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, **kw)
+    eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
+    return eng
+
+
+@pytest.fixture(scope="module")
+def body():
+    return assets("body")
+
+
+@pytest.fixture(scope="module")
+def eng_body(body):
+    return make_engine(body)
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry leaves
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("mesh", ["ico", "body"])
+def test_vertex_normals_bitexact(mesh):
+    from icon_amd.engine import MeshHandle
+    a = assets(mesh)
+    h = MeshHandle(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    vn = h.vertex_normals().cpu().numpy()
+    ref = orc.vertex_normals(a.smpl_verts[0], a.smpl_faces[0])
+    assert np.array_equal(vn.view(np.uint32), ref.view(np.uint32))
+    st = h.stats()
+    assert st["depth"] <= 26 and st["nodes"] >= 1
+
+
+@pytest.mark.parametrize("mesh,n", [("ico", 5000), ("body", 6000)])
+@pytest.mark.parametrize("search", ["bvh", "brute"])
+def test_sdf_query_vs_oracle(mesh, n, search):
+    from icon_amd.engine import MeshHandle
+    a = assets(mesh)
+    pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], n)
+    h = MeshHandle(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    g = {k: v.cpu().numpy() for k, v in h.sdf_query(T(pts), search=search).items()}
+    o = orc.cal_sdf(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], pts)
+    assert np.array_equal(g["face"], o["idx"]), f"{(g['face'] != o['idx']).sum()} nearest-face mismatches"
+    assert np.array_equal(g["inside"], o["inside"])
+    assert np.array_equal(g["vis"], o["vis"])
+    assert np.array_equal(g["sdf"].view(np.uint32), o["sdf"].view(np.uint32)), np.abs(g["sdf"] - o["sdf"]).max()
+    assert np.abs(g["norm"] - o["norm"]).max() <= 1e-6
+    assert np.abs(g["cmap"] - o["cmap"]).max() <= 1e-6
+
+
+def test_sdf_bvh_equals_brute_large(body):
+    """50k points incl. a dense far field: BVH pruning never changes the argmin / tie rule"""
+    from icon_amd.engine import MeshHandle
+    rng = np.random.RandomState(3)
+    pts = np.concatenate([synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 30000, seed=5),
+                          rng.uniform(-1.2, 1.2, (20000, 3)).astype(np.float32)])
+    h = MeshHandle(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    a = h.sdf_query(T(pts), search="bvh")
+    b = h.sdf_query(T(pts), search="brute")
+    for k in ("face", "inside", "vis", "sdf", "norm", "cmap"):
+        assert torch.equal(a[k], b[k]), k
+
+
+def test_sdf_golden_reference(body):
+    """against cal_sdf_batch run verbatim (reference python + oracle leaves)"""
+    from icon_amd.engine import MeshHandle
+    g = golden("query_body_4096.npz")
+    h = MeshHandle(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    o = {k: v.cpu().numpy() for k, v in h.sdf_query(T(g["points"])).items()}
+    assert np.abs(o["sdf"] - g["sdf"]).max() <= 1e-6
+    assert np.array_equal(o["vis"], g["vis"])
+    assert np.abs(o["norm"] - g["norm"]).max() <= 2e-5
+    assert np.abs(o["cmap"] - g["cmap"]).max() <= 2e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# MLP
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 128, 129, 777, 40000])
+def test_mlp_forward_vs_oracle(body, n):
+    from icon_amd.engine import MlpHandle
+    rng = np.random.RandomState(n)
+    x = rng.normal(0, 1, (n, 13)).astype(np.float32)
+    rows = rows16(x)
+    rows[:, 13:] = np.nan if n == 33 else 7.0      # pad slots and the code word must never reach the GEMM
+    mlp = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
+    y = mlp.forward(T(rows)).cpu().numpy()
+    ref = orc.Mlp(body.state_dict).forward(x, f64=True)[:, 0]
+    assert np.isfinite(y).all()
+    assert np.abs(y - ref).max() <= 1e-5, np.abs(y - ref).max()
+
+
+def test_mlp_golden_reference(body):
+    from icon_amd.engine import MlpHandle
+    g = golden("mlp_777.npz")
+    mlp = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
+    y = mlp.forward(T(rows16(g["x"].T.copy()))).cpu().numpy()
+    assert np.abs(y - g["y"]).max() <= 1e-5
+
+
+def test_mlp_transpose_detecting():
+    """asymmetric one-hot weights: any row/column or k-permutation slip in the packed operands
+    shows up as a wrong channel being routed to the output"""
+    from icon_amd.engine import MlpHandle
+    sd = synth.make_mlp_state_dict(seed=77)
+    rng = np.random.RandomState(1)
+    for l, (co, ci) in enumerate(synth.mlp_layer_shapes()):
+        w = np.zeros((co, ci, 1), np.float32)
+        for o in range(co):
+            w[o, (o * 7 + 3 * l + 1) % ci, 0] = 1.0 + 0.001 * o
+        sd[f"filters.{l}.weight"] = w
+        sd[f"filters.{l}.bias"] = (0.01 * rng.normal(size=co)).astype(np.float32)
+    x = rng.normal(0, 1, (4096, 13)).astype(np.float32)
+    y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x))).cpu().numpy()
+    ref = orc.Mlp(sd).forward(x, f64=True)[:, 0]
+    assert np.abs(y - ref).max() <= 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# HGPIFuNet.query
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+@pytest.mark.parametrize("n", [1, 3, 257, 5000])
+def test_query_points_vs_oracle(body, cmap_mode, n):
+    eng = make_engine(body, cmap_mode=cmap_mode)
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], n, seed=n)
+    out = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])
+    assert isinstance(out, list) and out[0].shape == (1, 1, n)
+    occ = out[0][0, 0].cpu().numpy()
+    ref, _ = oracle_query(body, pts, cmap_local=(cmap_mode == "local"))
+    assert np.abs(occ - ref).max() <= OCC_TOL, np.abs(occ - ref).max()
+
+
+def test_query_golden_reference(eng_body, body):
+    """the committed output of the reference's own query_func -> HGPIFuNet.query"""
+    g = golden("query_body_4096.npz")
+    from icon_amd.engine import query_func
+    from types import SimpleNamespace
+    occ = query_func(SimpleNamespace(num_views=1), eng_body, [T(body.features)], T(g["points"])[None])
+    assert occ.shape == (1, 1, 4096)
+    d = np.abs(occ[0, 0].cpu().numpy() - g["occ"])
+    assert d.max() <= OCC_TOL, d.max()
+
+
+def test_query_golden_projection(eng_body, body):
+    g = golden("query_body_proj_1024.npz")
+    from icon_amd.engine import query_func
+    from types import SimpleNamespace
+    # (a) proj_matrix applied by query_func with torch (rocBLAS baddbmm), as the reference does
+    occ = query_func(SimpleNamespace(num_views=1), eng_body, [T(body.features)], T(g["points"])[None],
+                     proj_matrix=T(g["proj"])[None])[0, 0].cpu().numpy()
+    # rocBLAS may round the projected coordinates differently from ATen-CPU; a 1-ulp change of a
+    # coordinate can flip one outlier flag and thereby shift the reference's tiled cmap
+    # assignment for the rest of the call, so compare in 'local' mode robustly and in
+    # 'reference' mode through the in-kernel calibration (b)
+    # (b) the calibration folded into the kernel: bit-identical projection arithmetic
+    out = eng_body.query([T(body.features)], T(g["points"].T.copy())[None], T(g["proj"])[None])[0][0, 0].cpu().numpy()
+    assert np.abs(out - g["occ"]).max() <= OCC_TOL
+    frac_bad = (np.abs(occ - g["occ"]) > OCC_TOL).mean()
+    assert frac_bad <= 0.05, frac_bad
+
+
+def test_query_ico_small_mesh():
+    a = assets("ico")
+    g = golden("query_ico_1500.npz")
+    eng = make_engine(a)
+    occ = eng.query([T(a.features)], T(g["points"].T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0]
+    assert np.abs(occ.cpu().numpy() - g["occ"]).max() <= OCC_TOL
+
+
+@pytest.mark.parametrize("prior", ["pamir", "pifu"])
+def test_query_vol_priors(prior):
+    from icon_amd.engine import IconQueryEngine
+    g = golden(f"query_{prior}_2000.npz")
+    feat, vol, sd = vol_assets(prior)
+    eng = IconQueryEngine(prior_type=prior)
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    if vol is not None:
+        eng.set_volume_features(T(vol))
+    occ = eng.query([T(feat)], T(g["points"].T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    assert np.abs(occ - g["occ"]).max() <= OCC_TOL
+    ref, _ = orc.query_vol(feat, vol, orc.Mlp(sd), g["points"])
+    assert np.abs(occ - ref).max() <= OCC_TOL
+
+
+def test_regressor_cache_invalidation(body):
+    """the engine must use the regressor's CURRENT weights"""
+    eng = make_engine(body)
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 512)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in body.state_dict.items()}
+    eng.set_regressor(sd)
+    args = ([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])
+    a = eng.query(*args)[0].clone()
+    sd["filters.3.bias"].add_(0.25)          # in-place update bumps the tensor version
+    b = eng.query(*args)[0]
+    inside = (T(pts).abs() < 1).all(1)
+    assert torch.allclose((b - a)[0, 0][inside], torch.full_like(a[0, 0][inside], 0.25), atol=1e-6)
+
+
+def test_errors(body):
+    from icon_amd.engine import IconQueryEngine, IconAmdError
+    eng = make_engine(body)
+    with pytest.raises(IconAmdError):
+        eng.query([T(body.features)], torch.zeros(1, 3, 5), torch.eye(4)[None])      # CPU tensors
+    with pytest.raises(IconAmdError):
+        eng.query([T(body.features)], torch.zeros(2, 3, 5, device=dev()), torch.eye(4, device=dev())[None])
+    with pytest.raises(IconAmdError):
+        IconQueryEngine(prior_type="icon", smpl_feats=("sdf", "cmap"))
+    e2 = IconQueryEngine()
+    with pytest.raises(IconAmdError):
+        e2.query([T(body.features)], torch.zeros(1, 3, 5, device=dev()), torch.eye(4, device=dev())[None])
+
+
+# ---------------------------------------------------------------------------------------------
+# dense lattice (reconEngine)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("res", [17, 33])
+def test_lattice_vs_golden_seg3d(eng_body, body, res):
+    """== the reference's Seg3dLossless with resolutions=[res], run verbatim"""
+    g = golden(f"seg3d_body_dense{res}.npz")
+    occ = eng_body.eval_slab(T(body.features), res, 0, res).cpu().numpy()
+    assert occ.shape == (res, res, res)
+    assert np.abs(occ - g["occ"]).max() <= OCC_TOL
+
+
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+def test_lattice_65_vs_oracle(body, cmap_mode):
+    res = 65
+    eng = make_engine(body, cmap_mode=cmap_mode)
+    occ = eng.eval_slab(T(body.features), res, 0, res).cpu().numpy().ravel()
+    ref, _ = oracle_query(body, synth.lattice_points(res), cmap_local=(cmap_mode == "local"))
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    # same thing through the explicit-point API: the lattice kernel generates identical coordinates
+    pts = synth.lattice_points(res)
+    q = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    assert np.array_equal(q, occ)
+
+
+def test_lattice_slab_split_equals_single_call(body):
+    """Z-slab sharding: 3 'ranks' on one GPU, sign lists exchanged by hand, == the single call"""
+    from icon_amd.recon import slab_bounds
+    res, world = 33, 3
+    feat = T(body.features)
+    full = make_engine(body).eval_slab(feat, res, 0, res)
+    engines = [make_engine(body) for _ in range(world)]
+    lists, counts = [], []
+    for r, e in enumerate(engines):
+        z0, z1, _ = slab_bounds(res, world, r)
+        s, c = e.slab_features(feat, res, z0, z1)
+        counts.append(int(c.item())); lists.append(s[: counts[-1]])
+    signs = torch.cat(lists).contiguous()
+    parts = []
+    for r, e in enumerate(engines):
+        z0, z1, _ = slab_bounds(res, world, r)
+        parts.append(e.slab_finish(res, z0, z1, signs, sum(counts), sum(counts[:r]), device=dev()))
+    assert torch.equal(torch.cat(parts), full)
+    # the exchanged list is the oracle's list of outlier signs in lattice order
+    o = orc.cal_sdf(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], synth.lattice_points(res))
+    exp = np.sign(o["sdf"][np.abs(o["sdf"]) >= np.float32(body.sdf_clip)]).astype(np.int8)
+    assert np.array_equal(signs.cpu().numpy(), exp)
+
+
+def test_lattice_257_properties(body):
+    """BASELINE.json's full size (257^3 = 16,974,593 points): size-independent properties"""
+    res = 257
+    feat = T(body.features)
+    e_ref, e_loc = make_engine(body, cmap_mode="reference"), make_engine(body, cmap_mode="local")
+    a = e_ref.eval_slab(feat, res, 0, res)
+    b = e_loc.eval_slab(feat, res, 0, res)
+    assert a.shape == (res, res, res) and torch.isfinite(a).all()
+    # in_cube: the outermost lattice shell is exactly +-1 and therefore exactly zero
+    for v in (a, b):
+        assert (v[0] == 0).all() and (v[-1] == 0).all() and (v[:, 0] == 0).all() and (v[:, -1] == 0).all()
+        assert (v[:, :, 0] == 0).all() and (v[:, :, -1] == 0).all()
+    # the two cmap modes differ only on clipped points; a stride-8 sub-lattice is the 33^3 lattice
+    sub = b[::8, ::8, ::8].contiguous()
+    pts = synth.lattice_points(33)
+    q = e_loc.query([feat], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].view(33, 33, 33)
+    assert torch.equal(sub, q)
+    sdf = e_ref._mesh_handle().sdf_query(T(synth.lattice_points(res, 120, 124)))["sdf"].view(4, res, res)
+    near = sdf.abs() < body.sdf_clip
+    assert near.any() and torch.equal(a[120:124][near], b[120:124][near])
+    # slabs are independent of how the z range is cut (local mode)
+    c = e_loc.eval_slab(feat, res, 100, 131)
+    assert torch.equal(c, b[100:131])
+    # a level set exists and hugs the body: inside fraction ~ body volume / 8
+    frac = (a > 0.5).float().mean().item()
+    assert 0.005 < frac < 0.02, frac
+
+
+def test_dense_recon_engine_api(body):
+    """reconEngine call contract: kwargs, [D,H,W] layout, None when empty, export_mesh"""
+    from icon_amd.recon import DenseReconEngine
+    from icon_amd.engine import query_func
+    from types import SimpleNamespace
+    eng = make_engine(body)
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                             resolutions=[33, 65], align_corners=True, balance_value=0.5, faster=True).to(dev())
+    sdf = recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert sdf.shape == (65, 65, 65) and sdf.is_cuda
+    assert any("resolutions" in k for k in recon.state_dict())
+    verts, faces = recon.export_mesh(sdf)
+    assert verts.shape[1] == 3 and faces.shape[1] == 3 and faces.dtype == torch.int64 and len(faces) > 100
+    # generic path (non-default box -> coordinates materialised, one query): same numbers here
+    recon2 = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                              resolutions=[65], align_corners=True).to(dev())
+    recon2._lattice_fast_path = lambda p: False
+    sdf2 = recon2(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert torch.equal(sdf, sdf2)
+    # nothing above 0.5 -> None (seg3d_lossless.py:173-177)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in body.state_dict.items()}
+    sd["filters.3.bias"] -= 10.0
+    eng.set_regressor(sd)
+    assert recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None) is None

@@ -1,0 +1,151 @@
+"""CPU: host logic and the C-ABI surface (no compute calls - there is no GPU here)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from common import ROOT, chamfer
+from icon_amd import _lib, synth
+from icon_amd.recon import DenseReconEngine, export_mesh_numpy, lattice_coords, slab_bounds
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "icon_amd.h")).read()
+    declared = set(re.findall(r"\b(icon_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    lib = _lib.lib()
+    for s in _lib.SYMBOLS:
+        assert hasattr(lib, s), s
+    assert lib.icon_version() == 100
+
+
+def test_header_is_plain_c():
+    """the boundary is a C ABI: the header must compile as C (no torch / C++ types)"""
+    src = '#include "icon_amd.h"\nint main(void){return ICON_OK;}\n'
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"),
+                        "-x", "c", "-"], input=src, text=True, capture_output=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")
+def test_fails_loudly_without_device():
+    from icon_amd.engine import IconAmdError, IconQueryEngine, MlpHandle
+    assert _lib.device_count() == 0
+    a = synth.make_assets("ico")
+    with pytest.raises(IconAmdError, match="no CPU fallback"):
+        MlpHandle({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
+    eng = IconQueryEngine()
+    eng.set_mesh(*(torch.from_numpy(x) for x in (a.smpl_verts, a.smpl_faces, a.smpl_cmap, a.smpl_vis)))
+    with pytest.raises(IconAmdError):
+        eng.query([torch.from_numpy(a.features)], torch.zeros(1, 3, 4), torch.eye(4)[None])
+
+
+def test_argument_errors_have_messages():
+    import ctypes as C
+    lib = _lib.lib()
+    h = C.c_void_p(0)
+    rc = lib.icon_mesh_create(None, C.c_int64(0), None, C.c_int64(0), None, None, None, C.byref(h))
+    assert rc == 1 and b"null" in lib.icon_last_error()
+    nv, nf = C.c_int64(0), C.c_int64(0)
+    assert lib.icon_export_mesh(None, C.c_int(5), C.c_float(0.5), None, C.byref(nv), None, C.byref(nf)) == 1
+
+
+def test_product_never_touches_the_oracle():
+    bad = []
+    for dp, _, fs in os.walk(os.path.join(ROOT, "icon_amd")):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".cpp", ".h", "Makefile")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"(from|import)\s+oracle|oracle/|liboracle", txt):
+                    bad.append(os.path.join(dp, f))
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("res,world", [(257, 8), (257, 2), (257, 3), (33, 8), (9, 8), (513, 8)])
+def test_slab_bounds(res, world):
+    cover = []
+    for r in range(world):
+        z0, z1, per = slab_bounds(res, world, r)
+        assert 0 <= z0 <= z1 <= res and z1 - z0 <= per
+        cover += list(range(z0, z1))
+    assert cover == list(range(res))
+    if (res, world) == (257, 8):
+        assert [slab_bounds(res, world, r)[1] - slab_bounds(res, world, r)[0] for r in range(8)] == [33] * 7 + [26]
+
+
+def test_lattice_mapping_matches_reference_formula():
+    """batch_eval / create_grid3D conventions: x fastest, y flipped"""
+    res = 9
+    p = lattice_coords(res, torch.tensor([[[-1.0, 1.0, -1.0]]]), torch.tensor([[[1.0, -1.0, 1.0]]]), True, "cpu")[0].numpy()
+    assert np.array_equal(p, synth.lattice_points(res))
+    assert np.allclose(p[0], [-1, 1, -1]) and np.allclose(p[1], [-0.75, 1, -1]) and np.allclose(p[res], [-1, 0.75, -1])
+    assert np.allclose(p[-1], [1, -1, 1])
+    for r in (33, 257, 129):
+        q = synth.lattice_points(r, 3, 5)
+        assert q.shape == (2 * r * r, 3) and np.isclose(q[0, 2], -1 + 2 * 3 / (r - 1))
+
+
+def test_dense_recon_engine_is_a_module_with_reference_buffers():
+    e = DenseReconEngine(query_func=None, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                         resolutions=[33, 65, 129, 257], align_corners=True, balance_value=0.5, faster=True,
+                         visualize=False, debug=False, use_cuda_impl=False, device="cpu")
+    assert isinstance(e, torch.nn.Module)
+    assert set(e.state_dict()) == {"b_min", "b_max", "resolutions"}
+    assert e.resolutions[-1].tolist() == [257, 257, 257] and e._lattice_fast_path(None)
+    assert not e._lattice_fast_path(torch.eye(4)[None])
+    with pytest.raises(AssertionError):
+        DenseReconEngine(resolutions=[32])
+
+
+def _closed_manifold(v, f):
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+    key, rkey = e[:, 0] * len(v) + e[:, 1], e[:, 1] * len(v) + e[:, 0]
+    return len(np.unique(key)) == len(key) and set(key) == set(rkey)
+
+
+def test_marching_cubes_sphere_and_noise():
+    R = 49
+    idx = np.arange(R, dtype=np.float32)
+    Z, Y, X = np.meshgrid(idx, idx, idx, indexing="ij")
+    c, r = np.array([24.3, 25.1, 23.7]), 15.2
+    occ = (0.5 + (r - np.sqrt((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2)) * 0.2).astype(np.float32)
+    v, f = export_mesh_numpy(occ, 0.5)
+    v, f = v.numpy().astype(np.float64), f.numpy()
+    assert _closed_manifold(v, f)
+    vol = (np.cross(v[f[:, 0]], v[f[:, 1]]) * v[f[:, 2]]).sum() / 6          # outward normals => positive
+    assert abs(vol / (4 / 3 * np.pi * r ** 3) - 1) < 0.01
+    # vertices are in the cropped grid's (x,y,z) index space (seg3d_lossless.py:585,594)
+    assert np.allclose(v.mean(0), c - 1.0, atol=0.05)
+    assert np.abs(np.linalg.norm(v - (c - 1.0), axis=1) - r).max() < 0.05
+    # heavy noise exercises every ambiguous configuration: still watertight
+    rng = np.random.RandomState(0)
+    noisy = occ + (rng.rand(*occ.shape).astype(np.float32) - 0.5) * 0.6
+    v2, f2 = export_mesh_numpy(noisy, 0.5)
+    assert _closed_manifold(v2.numpy(), f2.numpy())
+    # nothing above the level -> empty mesh, no error
+    v3, f3 = export_mesh_numpy(np.zeros((9, 9, 9), np.float32), 0.5)
+    assert len(v3) == 0 and len(f3) == 0
+
+
+def test_chamfer_definition():
+    v, f = synth.icosphere(3)
+    c0, p0 = chamfer(v, f, v, f, n=4000)
+    assert c0 < 0.1
+    c1, _ = chamfer(v, f, v + np.float32([0.01, 0, 0]), f, n=4000)
+    assert 0.3 < c1 < 1.2                         # ~0.01 * 100 * (mean |cos|) per direction
+
+
+def test_synthetic_assets_are_deterministic():
+    a, b = synth.make_assets("body"), synth.make_assets("body")
+    assert a.smpl_verts.shape == (1, 6890, 3) and a.smpl_faces.shape == (1, 13776, 3)
+    assert a.features.shape == (1, 12, 128, 128) and a.smpl_vis.shape == (1, 6890, 1)
+    for k in a.state_dict:
+        assert np.array_equal(a.state_dict[k], b.state_dict[k])
+    assert [a.state_dict[f"filters.{l}.weight"].shape for l in range(4)] == [(512, 13, 1), (256, 512, 1), (128, 269, 1), (1, 141, 1)]
+    import hashlib
+    h = hashlib.sha1(a.features.tobytes() + a.state_dict["filters.1.weight"].tobytes()).hexdigest()
+    assert h == open(os.path.join(ROOT, "tests", "golden", "synth.sha1")).read().strip()

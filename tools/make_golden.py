@@ -1,0 +1,116 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python (imported verbatim from
+/root/reference through oracle/ref_loader.py) on the seeded synthetic assets.
+
+Runs only in the build container (the reference tree does not travel to the GPU box); the
+fixtures are committed.  The three third-party leaves (kaolin point_to_mesh_distance /
+check_sign, pytorch3d vertex normals) are bound to the oracle's CPU restatements - everything
+above them is reference code: cal_sdf_batch, barycentrics, clipping incl. the tiled cmap
+assignment, index/grid_sample, feat_select, MLP, in_cube mask, query_func, Seg3dLossless.
+
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from icon_amd import synth  # noqa: E402
+from oracle import ref_loader  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def T(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_loader.load()
+    torch.set_num_threads(os.cpu_count())
+
+    # ---- (a) HGPIFuNet.query through query_func on the body mesh, 4096 stratified points ----
+    a = synth.make_assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 4096)
+    with torch.no_grad():
+        occ = ref.query_func(cfg, netG, [T(a.features)], T(pts)[None])[0, 0].numpy()
+        sdf, nrm, cm, vis = ref.cal_sdf_batch(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis),
+                                              T(pts)[None])
+        img = ref.index(T(a.features), T(pts[:, :2].T.copy())[None])[0].numpy()     # [12, N]
+    np.savez_compressed(os.path.join(OUT, "query_body_4096.npz"), points=pts, occ=occ,
+                        sdf=sdf[0, :, 0].numpy(), norm=nrm[0].numpy(), cmap=cm[0].numpy(),
+                        vis=vis[0, :, 0].numpy().astype(np.float32), img_feat=img)
+    print("query_body_4096: occ range", occ.min(), occ.max(), "outliers", int((np.abs(sdf[0, :, 0].numpy()) >= 0.05).sum()))
+
+    # affine calibration + non-identity proj_matrix through query_func
+    rng = np.random.RandomState(7)
+    A = np.eye(4, dtype=np.float32)
+    A[:3, :3] += rng.normal(0, 0.05, (3, 3)).astype(np.float32)
+    A[:3, 3] = rng.normal(0, 0.02, 3).astype(np.float32)
+    with torch.no_grad():
+        occ_p = ref.query_func(cfg, netG, [T(a.features)], T(pts[:1024])[None], proj_matrix=T(A)[None])[0, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "query_body_proj_1024.npz"), points=pts[:1024], proj=A, occ=occ_p)
+
+    # ---- (b) MLP.forward alone -------------------------------------------------------------
+    x = rng.normal(0, 1, (13, 777)).astype(np.float32)
+    with torch.no_grad():
+        y = netG.if_regressor(T(x)[None])[0, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "mlp_777.npz"), x=x, y=y)
+
+    # ---- (c) Seg3dLossless, single-level (dense) and the reference's adaptive schedule -------
+    with torch.no_grad():
+        for name, resolutions in (("dense17", [17]), ("dense33", [33]), ("adaptive_33_65", [33, 65])):
+            eng = ref.Seg3dLossless(query_func=ref.query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                    resolutions=resolutions, align_corners=True, balance_value=0.5, faster=True)
+            vol = eng(opt=cfg, netG=netG, features=[T(a.features)], proj_matrix=None)
+            vol = vol.numpy().astype(np.float32)
+            np.savez_compressed(os.path.join(OUT, f"seg3d_body_{name}.npz"), occ=vol,
+                                resolutions=np.array(resolutions))
+            print(name, vol.shape, "inside voxels", int((vol > 0.5).sum()))
+
+    # ---- (d) small mesh (fast CPU tests): icosphere, 1500 points ---------------------------------
+    b = synth.make_assets("ico")
+    netB, cfgB = ref_loader.build_netG(b)
+    ptsb = synth.stratified_points(b.smpl_verts[0], b.smpl_faces[0], 1500)
+    with torch.no_grad():
+        occb = ref.query_func(cfgB, netB, [T(b.features)], T(ptsb)[None])[0, 0].numpy()
+        sdfb, nrmb, cmb, visb = ref.cal_sdf_batch(T(b.smpl_verts), T(b.smpl_faces), T(b.smpl_cmap), T(b.smpl_vis),
+                                                  T(ptsb)[None])
+    np.savez_compressed(os.path.join(OUT, "query_ico_1500.npz"), points=ptsb, occ=occb,
+                        sdf=sdfb[0, :, 0].numpy(), norm=nrmb[0].numpy(), cmap=cmb[0].numpy(),
+                        vis=visb[0, :, 0].numpy().astype(np.float32))
+
+    # ---- (e) PaMIR / PIFu branches (HGPIFuNet.py:348-357): reference index() + reference MLP ------
+    # (HGPIFuNet cannot be constructed with prior_type='pamir' here: it needs voxelize_cuda and SMPL
+    #  data files, lib/net/HGPIFuNet.py:107-119; the two-line branch is composed from the
+    #  reference's own index / MLP / in_cube expressions.)
+    for prior in ("pamir", "pifu"):
+        c = synth.make_assets("ico", prior_type="pamir")
+        feat = synth.make_feature_planes(6 if prior == "pamir" else 12, 128, synth.SEED)
+        sd = synth.make_mlp_state_dict(synth.SEED + (1 if prior == "pamir" else 2), sdf_channel=None)
+        mlp = ref.MLP(filter_channels=[13, 512, 256, 128, 1], name="if", res_layers=[2, 3, 4], norm="batch", last_op=None)
+        mlp.load_state_dict({k: T(v) for k, v in sd.items()}, strict=False)
+        mlp.eval()
+        p = rng.uniform(-1.05, 1.05, (2000, 3)).astype(np.float32)
+        xyz = T(p.T.copy())[None]
+        with torch.no_grad():
+            in_cube = ((xyz > -1.0) & (xyz < 1.0)).all(dim=1, keepdim=True).float()
+            if prior == "pamir":
+                lst = [ref.index(T(feat), xyz[:, :2]), ref.index(T(c.vol_feat), xyz)]
+            else:
+                lst = [ref.index(T(feat), xyz[:, :2]), xyz[:, 2:3]]
+            pred = (in_cube * mlp(torch.cat(lst, 1)))[0, 0].numpy()
+        # inputs are re-created by the tests from the same synth seeds (tests/common.py: vol_assets)
+        np.savez_compressed(os.path.join(OUT, f"query_{prior}_2000.npz"), points=p, occ=pred)
+    print("golden fixtures written to", OUT)
+    os.system(f"ls -la {OUT}")
+
+
+if __name__ == "__main__":
+    main()
