@@ -23,6 +23,12 @@ import os
 import sys
 import time
 
+# two OpenMP runtimes live in this process during the cpu_baseline leg (torch's and the oracle's):
+# make idle workers sleep instead of spinning against each other
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+os.environ.setdefault("KMP_BLOCKTIME", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -40,6 +46,10 @@ def cpu_baseline(assets, res, budget_s=14.0):
     from oracle import oracle as orc, query_torch as qt
 
     cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
     torch.set_num_threads(cores)
     orc.set_num_threads(cores)
     mlp = qt.build_mlp(assets.state_dict)
@@ -52,10 +62,12 @@ def cpu_baseline(assets, res, budget_s=14.0):
     planes = int(max(1, min(res, (rate * budget_s) // (res * res))))
     zs = np.unique(np.linspace(res // 8, res - 1 - res // 8, planes).round().astype(int))
     pts = np.concatenate([synth.lattice_points(res, int(z), int(z) + 1) for z in zs])
+    qt.TIMES["leaves"] = 0.0
     t0 = time.perf_counter()
     qt.query(assets, mlp, pts, assets.sdf_clip)
     dt = time.perf_counter() - t0
     return {"value": len(pts) / dt, "unit": "points/s", "cores": cores, "kind": "port",
+            "seconds": {"total": dt, "leaves_c_openmp": qt.TIMES["leaves"], "torch_ops": dt - qt.TIMES["leaves"]},
             "sample": f"{len(zs)} whole z-planes of the {res}^3 lattice ({len(pts)} points, {dt:.1f} s), "
                       f"oracle/query_torch.py: torch-CPU operators of the reference ({torch.get_num_threads()} threads) + "
                       f"brute-force C leaves (OpenMP, {orc.num_threads()} threads)"}

@@ -58,7 +58,7 @@ struct alignas(16) TriAttr {
 static_assert(sizeof(TriAttr) == 96, "TriAttr must be 96 bytes");
 
 constexpr int kLeafMax = 4;        // triangles per BVH leaf
-constexpr int kStackDepth = 28;    // per-lane traversal stack entries (LDS)
+constexpr int kStackDepth = 48;    // per-wave traversal stack entries (LDS)
 constexpr int kXRow = 16;          // floats per point row of the MLP input buffer
 constexpr int kCodeSlot = 15;      // row slot holding the per-point code word
 
@@ -142,6 +142,9 @@ struct icon_work {
     int8_t *d_signs = nullptr;            // compacted outlier signs of the call
     int64_t cap_signs = 0;
     int64_t *d_total = nullptr;           // device scalar: number of outliers
+    int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
+    int32_t *d_row_slots = nullptr;       // [rows][kRowCap]
+    int64_t cap_rows = 0;
     // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
     int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
     bool slab_ready = false, slab_needs_patch = false;

@@ -237,21 +237,23 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     // eps, overlaps.  cell_of() is monotone, so a query point inside the grown box lands in one
     // of those cells; eps covers the rounding of the float32 edge functions.
     const float eps = 1e-5f;
-    int g = (int)std::lround(std::sqrt((double)F) * 1.1);
-    g = std::min(std::max(g, 8), 512);
     const float y0 = mesh_box.lo[1] - 4 * eps, y1 = mesh_box.hi[1] + 4 * eps;
     const float z0 = mesh_box.lo[2] - 4 * eps, z1 = mesh_box.hi[2] + 4 * eps;
-    const float inv_y = (float)g / (y1 - y0), inv_z = (float)g / (z1 - z0);
-    std::vector<int32_t> bin_start((size_t)g * g + 1, 0);
+    // square cells, about two per triangle
+    const double cell = std::sqrt(std::max((double)(y1 - y0) * (double)(z1 - z0), 1e-12) / (2.0 * (double)F));
+    const int gy = std::min(std::max((int)std::ceil((y1 - y0) / cell), 1), 2048);
+    const int gz = std::min(std::max((int)std::ceil((z1 - z0) / cell), 1), 2048);
+    const float inv_y = (float)gy / (y1 - y0), inv_z = (float)gz / (z1 - z0);
+    std::vector<int32_t> bin_start((size_t)gy * gz + 1, 0);
     auto range = [&](int64_t s, int &cy0, int &cy1, int &cz0, int &cz1) {
         const Box &b = bd.tbox[bd.order[s]];
-        cy0 = cell_of(b.lo[1] - eps, y0, inv_y, g); cy1 = cell_of(b.hi[1] + eps, y0, inv_y, g);
-        cz0 = cell_of(b.lo[2] - eps, z0, inv_z, g); cz1 = cell_of(b.hi[2] + eps, z0, inv_z, g);
+        cy0 = cell_of(b.lo[1] - eps, y0, inv_y, gy); cy1 = cell_of(b.hi[1] + eps, y0, inv_y, gy);
+        cz0 = cell_of(b.lo[2] - eps, z0, inv_z, gz); cz1 = cell_of(b.hi[2] + eps, z0, inv_z, gz);
     };
     for (int64_t s = 0; s < F; ++s) {
         int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
         for (int cz = cz0; cz <= cz1; ++cz)
-            for (int cy = cy0; cy <= cy1; ++cy) bin_start[(size_t)cz * g + cy + 1]++;
+            for (int cy = cy0; cy <= cy1; ++cy) bin_start[(size_t)cz * gy + cy + 1]++;
     }
     int64_t max_bin = 0;
     for (size_t i = 1; i < bin_start.size(); ++i) { max_bin = std::max<int64_t>(max_bin, bin_start[i]); bin_start[i] += bin_start[i - 1]; }
@@ -261,7 +263,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         for (int64_t s = 0; s < F; ++s) {   // ascending slot order inside every bin
             int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
             for (int cz = cz0; cz <= cz1; ++cz)
-                for (int cy = cy0; cy <= cy1; ++cy) bin_slots[fill[(size_t)cz * g + cy]++] = (int32_t)s;
+                for (int cy = cy0; cy <= cy1; ++cy) bin_slots[fill[(size_t)cz * gy + cy]++] = (int32_t)s;
         }
     }
 
@@ -281,7 +283,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     d.n_tris = (int32_t)F; d.root_is_leaf = root_is_leaf;
     d.bin_start = m->d_bin_start; d.bin_slots = m->d_bin_slots;
     d.bin_y0 = y0; d.bin_z0 = z0; d.bin_y1 = y1; d.bin_z1 = z1; d.bin_inv_y = inv_y; d.bin_inv_z = inv_z;
-    d.gy = g; d.gz = g;
+    d.gy = gy; d.gz = gz;
     m->stats[0] = (int64_t)bd.nodes.size(); m->stats[1] = bd.max_depth;
     m->stats[2] = (int64_t)bin_slots.size(); m->stats[3] = max_bin;
     *out = m;

@@ -93,6 +93,18 @@ __device__ __forceinline__ int ray_hit(f3 p, f3 a, f3 b, f3 c, int ia, int ib, i
     return s_ab ? (num > 0.0f) : (num < 0.0f);
 }
 
+// Wave-uniform reads of the (read-only) BVH and triangle arrays go through the CONSTANT address
+// space so the compiler emits scalar loads (s_load_dwordx8/x16 into SGPRs, served by the scalar
+// cache) instead of 64 identical vector loads.
+typedef __attribute__((address_space(4))) const float cfloat;
+__device__ __forceinline__ cfloat *as_const(const void *p) { return (cfloat *)(uintptr_t)p; }
+
+__device__ __forceinline__ void load_tri_pos_uniform(const TriRec *t, f3 &a, f3 &b, f3 &c)
+{
+    cfloat *q = as_const(t);
+    a = mk3(q[0], q[1], q[2]); b = mk3(q[3], q[4], q[5]); c = mk3(q[6], q[7], q[8]);
+}
+
 __device__ __forceinline__ void load_tri_pos(const TriRec *t, f3 &a, f3 &b, f3 &c)
 {
     const float4 *q = reinterpret_cast<const float4 *>(t);
@@ -141,38 +153,57 @@ __device__ __forceinline__ void consider(const MeshDev &m, f3 p, int slot, Neare
     }
 }
 
-// BVH2 traversal, one query per lane, near child first, stack in LDS ([depth][thread]).
-template <int BLOCK>
-__device__ __forceinline__ Nearest nearest_bvh(const MeshDev &m, f3 p, int *stack /* LDS, kStackDepth*BLOCK */)
+// BVH2 PACKET traversal: the 64 lanes of a wavefront descend the tree TOGETHER.  Control flow, the
+// node / triangle addresses and the stack are wave-uniform (scalar registers, scalar loads, one
+// LDS word per stack entry per wave); every lane tests its own point against the shared node
+// boxes and triangles, and a subtree is entered when ANY lane still needs it.  In lattice mode a
+// wavefront owns a 4x4x4 block of lattice points, so the lanes' candidate sets nearly coincide and
+// there is no divergence at all.  Near child first, ordered by the block's centre lane.
+// `live` = false parks a padding lane: it never votes and its result is discarded.
+__device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
-    float thr = INFINITY;
+    float thr = live ? INFINITY : -INFINITY;
     int sp = 0;
     int cur = 0;
-    const int tid = threadIdx.x;
     while (true) {
         if (cur < 0) {
             const int code = ~cur;
             const int first = code >> 3, cnt = (code & 7) + 1;
-            for (int t = 0; t < cnt; ++t) consider(m, p, first + t, nr, thr);
+            for (int t = 0; t < cnt; ++t) {
+                const int slot = first + t;
+                f3 a, b, c;
+                load_tri_pos_uniform(m.tris + slot, a, b, c);
+                const float d2 = pt_tri_dist2(p, a, b, c);
+                const bool cand = live && d2 <= nr.d2;            // NaN never passes
+                if (__any(cand)) {
+                    const int face = __float_as_int(as_const(m.slot2face)[slot]);
+                    if (cand && (d2 < nr.d2 || face < nr.face)) { // S3: exact ties -> lowest face index
+                        nr.d2 = d2; nr.slot = slot; nr.face = face;
+                        thr = prune_threshold(d2);
+                    }
+                }
+            }
             if (sp == 0) break;
-            cur = stack[(--sp) * BLOCK + tid];
+            cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
         } else {
-            const float4 *q = reinterpret_cast<const float4 *>(m.nodes + cur);
-            const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-            const float d0 = box_dist2(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, p);
-            const float d1 = box_dist2(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, p);
-            const int c0 = __float_as_int(q3.x), c1 = __float_as_int(q3.y);
-            const bool v0 = d0 <= thr, v1 = d1 <= thr;
+            cfloat *q = as_const(m.nodes + cur);
+            const float d0 = box_dist2(q[0], q[1], q[2], q[3], q[4], q[5], p);
+            const float d1 = box_dist2(q[6], q[7], q[8], q[9], q[10], q[11], p);
+            const int c0 = __float_as_int(q[12]), c1 = __float_as_int(q[13]);
+            const bool v0 = __any(d0 <= thr), v1 = __any(d1 <= thr);
             if (v0 && v1) {
-                const bool first0 = d0 <= d1;
-                stack[(sp++) * BLOCK + tid] = first0 ? c1 : c0;
+                // order by the block's centre lane; non-negative floats order like their bit patterns
+                const int e0 = __builtin_amdgcn_readlane(__float_as_int(d0), 21);
+                const int e1 = __builtin_amdgcn_readlane(__float_as_int(d1), 21);
+                const bool first0 = e0 <= e1;
+                wstack[sp++] = first0 ? c1 : c0;
                 cur = first0 ? c0 : c1;
             } else if (v0) cur = c0;
             else if (v1) cur = c1;
             else {
                 if (sp == 0) break;
-                cur = stack[(--sp) * BLOCK + tid];
+                cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
             }
         }
     }
@@ -233,6 +264,34 @@ __device__ __forceinline__ bool inside_brute(const MeshDev &m, f3 p)
     for (int s = 0; s < m.n_tris; ++s) {
         f3 a, b, c; int ia, ib, ic;
         load_tri_full(m.tris + s, a, b, c, ia, ib, ic);
+        cnt += ray_hit(p, a, b, c, ia, ib, ic);
+    }
+    return (cnt & 1) != 0;
+}
+
+// Lattice mode: every point of an x-row shares (y,z), hence the same set of triangles whose (y,z)
+// projection contains it - the 2-D half of the ray test does not depend on x.  k_row_crossings
+// finds that set once per row (<= kRowCap slots, ascending); the per-point test then only
+// re-evaluates ray_hit() on those few triangles instead of scanning the whole bin.
+constexpr int kRowCap = 16;
+
+__device__ __forceinline__ bool ray_covers(f3 p, f3 a, f3 b, f3 c, int ia, int ib, int ic)
+{
+    float e_ab, e_bc, e_ca; bool s_ab, s_bc, s_ca;
+    oriented_edge(ia, a, ib, b, p.y, p.z, e_ab, s_ab);
+    oriented_edge(ib, b, ic, c, p.y, p.z, e_bc, s_bc);
+    oriented_edge(ic, c, ia, a, p.y, p.z, e_ca, s_ca);
+    return s_ab == s_bc && s_bc == s_ca;
+}
+
+__device__ __forceinline__ bool inside_row(const MeshDev &m, f3 p, const int32_t *row_count, const int32_t *row_slots, int64_t row)
+{
+    const int n = row_count[row];
+    if (n < 0) return inside_bins(m, p);          // list overflowed: fall back to the bin scan
+    int cnt = 0;
+    for (int k = 0; k < n; ++k) {
+        f3 a, b, c; int ia, ib, ic;
+        load_tri_full(m.tris + row_slots[row * kRowCap + k], a, b, c, ia, ib, ic);
         cnt += ray_hit(p, a, b, c, ia, ib, ic);
     }
     return (cnt & 1) != 0;
@@ -432,7 +491,7 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
                                                       float *sdf, float *nrm, float *cm, float *vis,
                                                       int64_t *face, uint8_t *inside_out)
 {
-    __shared__ int lds[kStackDepth * kBlock];
+    __shared__ int lds[kBlock * 12];   // brute: triangle tile (12 floats x kBlock); packet: 4 wave stacks
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < N;
     const int64_t ic = live ? i : (N - 1);
@@ -440,7 +499,7 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     Nearest nr;
     bool ins;
     if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
-    else       { nr = nearest_bvh<kBlock>(m, p, lds); ins = inside_bins(m, p); }
+    else       { nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth); ins = inside_bins(m, p); }
     if (!live) return;
     const SdfOut o = sdf_attrs(m, p, nr, ins);
     sdf[i] = o.sdf;
@@ -458,16 +517,20 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
 template <int PRIOR, bool LATTICE, bool BRUTE>
 __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib cal, LatticeMap L,
                                                      const float *__restrict__ pts, int64_t N,
-                                                     float sdf_clip, int cmap_local, float *__restrict__ X)
+                                                     float sdf_clip, int cmap_local,
+                                                     const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
+                                                     float *__restrict__ X)
 {
-    __shared__ int lds[(PRIOR == ICON_PRIOR_ICON) ? kStackDepth * kBlock : 1];
+    __shared__ int lds[(PRIOR == ICON_PRIOR_ICON) ? kBlock * 12 : 1];
     int64_t i; bool live; f3 p;
+    int64_t yz_row = 0;
     if (LATTICE) {
         int ix, iy, iz;
         live = lattice_point(L, ix, iy, iz);
         const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
         p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
+        yz_row = (int64_t)cz * L.res + cy;
     } else {
         i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         live = i < N;
@@ -482,7 +545,10 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
         Nearest nr;
         bool ins;
         if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
-        else       { nr = nearest_bvh<kBlock>(m, p, lds); ins = inside_bins(m, p); }
+        else {
+            nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+            ins = LATTICE ? inside_row(m, p, row_count, row_slots, yz_row) : inside_bins(m, p);
+        }
         const SdfOut o = sdf_attrs(m, p, nr, ins);
         float s = o.sdf;
         f3 cmv = o.cm;
@@ -514,6 +580,32 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
     }
     row[kCodeSlot] = __int_as_float((int)code);
     if (live) store_row(X, i, row);
+}
+
+// one thread per (y, z) row of the slab: triangles whose (y,z) projection covers the row
+__global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots)
+{
+    const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (row >= (int64_t)L.nz * L.res) return;
+    const int iy = (int)(row % L.res), iz = (int)(row / L.res);
+    const f3 p = lattice_world(L.res, 0, iy, iz + L.z0);
+    int n = 0;
+    if (p.y >= m.bin_y0 && p.y <= m.bin_y1 && p.z >= m.bin_z0 && p.z <= m.bin_z1) {
+        const int cy = bin_cell(p.y, m.bin_y0, m.bin_inv_y, m.gy);
+        const int cz = bin_cell(p.z, m.bin_z0, m.bin_inv_z, m.gz);
+        const int cell = cz * m.gy + cy;
+        const int beg = m.bin_start[cell], end = m.bin_start[cell + 1];
+        for (int k = beg; k < end; ++k) {
+            const int slot = m.bin_slots[k];
+            f3 a, b, c; int ia, ib, ic;
+            load_tri_full(m.tris + slot, a, b, c, ia, ib, ic);
+            if (ray_covers(p, a, b, c, ia, ib, ic)) {
+                if (n < kRowCap) row_slots[row * kRowCap + n] = slot;
+                ++n;
+            }
+        }
+    }
+    row_count[row] = (n <= kRowCap) ? n : -1;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -709,7 +801,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     delete w;
     return ICON_OK;
@@ -789,8 +881,23 @@ int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int
 template <bool LATTICE>
 int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sdf_clip, int cmap_mode,
                     const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, int search,
-                    float *d_x, hipStream_t st)
+                    icon_work *work, hipStream_t st)
 {
+    float *d_x = work->d_x;
+    int32_t *row_count = nullptr, *row_slots = nullptr;
+    if (LATTICE && prior == ICON_PRIOR_ICON && search != ICON_SEARCH_BRUTE) {
+        const int64_t rows = (int64_t)L.nz * L.res;
+        if (rows > work->cap_rows) {
+            (void)hipFree(work->d_row_count); (void)hipFree(work->d_row_slots);
+            work->d_row_count = nullptr; work->d_row_slots = nullptr; work->cap_rows = 0;
+            ICON_HIP(hipMalloc((void **)&work->d_row_count, (size_t)rows * sizeof(int32_t)));
+            ICON_HIP(hipMalloc((void **)&work->d_row_slots, (size_t)rows * kRowCap * sizeof(int32_t)));
+            work->cap_rows = rows;
+        }
+        row_count = work->d_row_count; row_slots = work->d_row_slots;
+        hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
+                           row_count, row_slots);
+    }
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
@@ -798,7 +905,7 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     const MeshDev md = mesh ? mesh->dev : MeshDev{};
     const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
     const bool brute = (search == ICON_SEARCH_BRUTE);
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, d_x)
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, d_x)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
@@ -875,7 +982,7 @@ extern "C" int icon_query_points(const icon_mesh_t *mesh, const icon_feat_t *fea
     memcpy(cal.m, h_calib ? h_calib : ident, sizeof(cal.m));
     LatticeMap L{};
     mark(work, 0, st);
-    if ((rc = launch_features<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, work->d_x, st))) return rc;
+    if ((rc = launch_features<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, work, st))) return rc;
     const bool patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
     if (patch && (rc = outlier_list(work, N, work->d_signs, st))) return rc;
     mark(work, 1, st);
@@ -912,7 +1019,7 @@ extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_
     Calib cal{};
     work->slab_ready = false;
     mark(work, 0, st);
-    if ((rc = launch_features<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, work->d_x, st))) return rc;
+    if ((rc = launch_features<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, work, st))) return rc;
     work->slab_needs_patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
     work->slab_cmap_slot = feat->dev.csel + 1;
     work->slab_c0 = c0;

@@ -45,12 +45,19 @@ def build_mlp(state_dict) -> TorchMLP:
     return m.eval()
 
 
+TIMES = {"leaves": 0.0}
+
+
 def cal_sdf_batch(verts, faces, cmaps, vis, points):
     """mesh_util.py:357-396; tensors [1,V,3] [1,F,3] [1,V,3] [1,V,1] [1,N,3]"""
+    import time
+    t0 = time.perf_counter()
+    leaf_sign = orc.check_sign(verts[0].numpy(), faces[0].numpy(), points[0].numpy())
     vn = torch.from_numpy(orc.vertex_normals(verts[0].numpy(), faces[0].numpy()))[None]
     fl = faces[0].long()
     tri, nrm, cm, vs = verts[0][fl], vn[0][fl], cmaps[0][fl], vis[0][fl]          # face_vertices
     d2, idx = orc.nearest_brute(verts[0].numpy(), faces[0].numpy(), points[0].numpy())
+    TIMES["leaves"] += time.perf_counter() - t0
     idx = torch.from_numpy(idx)
     ct, cn, cc, cv = tri[idx], nrm[idx], cm[idx], vs[idx]                          # gathers
     p = points[0]
@@ -67,7 +74,7 @@ def cal_sdf_batch(verts, faces, cmaps, vis, points):
     pts_vis = (cv * bw[:, :, None]).sum(1)[None].ge(1e-1)
     pts_norm = (cn * bw[:, :, None]).sum(1)[None] * torch.tensor([-1.0, 1.0, -1.0])
     dist = torch.sqrt(torch.from_numpy(d2))[None] / torch.sqrt(torch.tensor(3.0))
-    sign = 2.0 * (torch.from_numpy(orc.check_sign(verts[0].numpy(), faces[0].numpy(), points[0].numpy()))[None].float() - 0.5)
+    sign = 2.0 * (torch.from_numpy(leaf_sign)[None].float() - 0.5)
     return (dist * sign).unsqueeze(-1), pts_norm, pts_cmap, pts_vis
 
 
