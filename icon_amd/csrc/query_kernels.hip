@@ -74,13 +74,23 @@ __device__ __forceinline__ float pt_tri_dist2(f3 p, f3 a, f3 b, f3 c)
 // S4: +x ray / triangle crossing with the canonical (lower vertex id first) edge rule.
 __device__ __forceinline__ float edge_fn(float yi, float zi, float yj, float zj, float qy, float qz)
 {
-    const float t1 = (yj - yi) * (qz - zi);
-    return fmaf(-(zj - zi), (qy - yi), t1);
+    // twice the signed area of (q, vi, vj), relative to q: exactly 0 when q projects onto an end point
+    const float t1 = (yi - qy) * (zj - qz);
+    return fmaf(-(zi - qz), (yj - qy), t1);
+}
+__device__ __forceinline__ bool edge_side(float yi, float zi, float yj, float zj, float e)
+{
+    // exact zeros: symbolic perturbation q -> q + (eps, eps^2), identical for every edge
+    if (e > 0.0f) return true;
+    if (e < 0.0f) return false;
+    const float dz = zj - zi, dy = yj - yi;
+    if (dz != 0.0f) return dz < 0.0f;
+    return dy > 0.0f;
 }
 __device__ __forceinline__ void oriented_edge(int ia, f3 a, int ib, f3 b, float qy, float qz, float &val, bool &pos)
 {
-    if (ia < ib) { const float e = edge_fn(a.y, a.z, b.y, b.z, qy, qz); val = e; pos = (e >= 0.0f); }
-    else         { const float e = edge_fn(b.y, b.z, a.y, a.z, qy, qz); val = -e; pos = (e < 0.0f); }
+    if (ia < ib) { const float e = edge_fn(a.y, a.z, b.y, b.z, qy, qz); val = e; pos = edge_side(a.y, a.z, b.y, b.z, e); }
+    else         { const float e = edge_fn(b.y, b.z, a.y, a.z, qy, qz); val = -e; pos = !edge_side(b.y, b.z, a.y, a.z, e); }
 }
 __device__ __forceinline__ int ray_hit(f3 p, f3 a, f3 b, f3 c, int ia, int ib, int ic)
 {

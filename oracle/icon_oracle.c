@@ -175,21 +175,37 @@ void orc_nearest_brute(const float *verts, const int64_t *faces, int64_t F,
  *     iff p's (y,z) projection lies in the projected triangle and the hit is in front of p.
  *     Every mesh edge is evaluated once in a canonical direction (lower vertex id first), so
  *     the two triangles sharing an edge take opposite sides of it for every query point and a
- *     ray through an edge is counted exactly once (watertight rule; ties go to the triangle
- *     that traverses the edge in canonical direction).
+ *     ray through an edge is counted exactly once; exact zeros (ray through a vertex) are
+ *     resolved by one global symbolic perturbation of the query point (edge_side).
  * ---------------------------------------------------------------------------------------- */
+/* twice the signed area of (q, vi, vj) in the (y,z) plane, vi -> vj in canonical (lower id first)
+ * direction, written relative to q so that it is EXACTLY zero when q coincides with the
+ * projection of either end point */
 static inline float edge_fn(float yi, float zi, float yj, float zj, float qy, float qz)
 {
-    const float t1 = (yj - yi) * (qz - zi);
-    return fmaf(-(zj - zi), (qy - yi), t1);
+    const float t1 = (yi - qy) * (zj - qz);
+    return fmaf(-(zi - qz), (yj - qy), t1);
+}
+
+/* side of q w.r.t. the canonical edge; an exact zero is resolved by the symbolic perturbation
+ * q -> q + (eps, eps^2): sign of dE/dqy = -(zj - zi), then of dE/dqz = (yj - yi).  The
+ * perturbation is the same for every edge, so a ray through a mesh vertex or edge is assigned to
+ * exactly the triangles a slightly shifted ray would cross (simulation of simplicity). */
+static inline int edge_side(float yi, float zi, float yj, float zj, float e)
+{
+    if (e > 0.0f) return 1;
+    if (e < 0.0f) return 0;
+    const float dz = zj - zi, dy = yj - yi;
+    if (dz != 0.0f) return dz < 0.0f;
+    return dy > 0.0f;
 }
 
 /* oriented edge value and side for the edge from vertex (id ia) to vertex (id ib) */
 static inline void oriented_edge(int64_t ia, v3 a, int64_t ib, v3 b, float qy, float qz,
                                  float *val, int *pos)
 {
-    if (ia < ib) { const float e = edge_fn(a.y, a.z, b.y, b.z, qy, qz); *val = e; *pos = (e >= 0.0f); }
-    else         { const float e = edge_fn(b.y, b.z, a.y, a.z, qy, qz); *val = -e; *pos = (e < 0.0f); }
+    if (ia < ib) { const float e = edge_fn(a.y, a.z, b.y, b.z, qy, qz); *val = e; *pos = edge_side(a.y, a.z, b.y, b.z, e); }
+    else         { const float e = edge_fn(b.y, b.z, a.y, a.z, qy, qz); *val = -e; *pos = !edge_side(b.y, b.z, a.y, a.z, e); }
 }
 
 int orc_ray_hit(const float *pp, int64_t ia, const float *pa, int64_t ib, const float *pb,
