@@ -33,7 +33,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 MLP_FLOP_PER_POINT = 344_602          # 2 * (13*512 + 512*256 + 269*128 + 141), SURVEY.md §8(d)
-PEAK_F32_MFMA_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, v_mfma_f32_32x32x2_f32
+# /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks for the instruction each path issues
+PEAK_TFLOPS = {"f32": 157.3,          # v_mfma_f32_32x32x2_f32
+               "f16x3": 2500.0}       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
+KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_mlp_f16x3"}
+DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (f32 accumulate)"}
 
 
 def cpu_baseline(assets, res, budget_s=14.0):
@@ -81,6 +85,7 @@ def main():
     ap.add_argument("--res", type=int, default=257)
     ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
+    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -108,7 +113,8 @@ def main():
     res = args.res
     a = synth.make_assets("body")
     T = lambda x: torch.from_numpy(x).to(dev)
-    eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, cmap_mode=args.cmap_mode, search=args.search)
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, cmap_mode=args.cmap_mode, search=args.search,
+                          precision=args.precision)
     eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
     eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
     feats = [T(a.features)]
@@ -163,7 +169,7 @@ def main():
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("k_mlp_f32_bytes_per_launch")
+            traffic = json.load(open(tpath)).get(KERNEL[args.precision] + "_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -172,15 +178,16 @@ def main():
             "metric": "query-points/sec at 256^3 grid", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {
                 "workload": f"icon-filter.yaml, {res}^3 lattice (mcube_res={res - 1}), 1 image: SMPL-size body "
-                            f"V=6890/F=13776, planes [1,12,128,128], MLP 13-512-256-128-1, cmap_mode={args.cmap_mode}",
+                            f"V=6890/F=13776, planes [1,12,128,128], MLP 13-512-256-128-1, cmap_mode={args.cmap_mode}, mlp={args.precision}",
                 "parallelism": f"zslab{world}", "points_per_step": n_points, "prep_ms": prep_ms,
                 "stage_ms": {"features": stage[0], "cmap_patch": stage[1], "mlp": stage[2]},
             },
-            "roofline": {"bound": "mfma", "kernel": "k_mlp_f32", "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+            "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved,
+                         "peak": PEAK_TFLOPS[args.precision],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
                          "flop_per_launch": MLP_FLOP_PER_POINT * my_points, "avg_launch_ms": stage[2]},
         }
         if not args.no_cpu_baseline and world == 1:

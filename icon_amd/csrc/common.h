@@ -125,12 +125,18 @@ struct icon_mlp {
     // offsets (in floats) into the blob
     size_t off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0, off_w2 = 0, off_w2x = 0, off_b2 = 0, off_w3 = 0;
     float b3 = 0.f;
+    // 3xf16 split-precision path (mlp_f16x3.hip): chunked hi/lo operand image + f32 side arrays
+    char *d_f16 = nullptr;
+    float f16_inv[3] = {1.f, 1.f, 1.f};
 };
 
 namespace icon {
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
+// mlp_f16x3.hip
+int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
+int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
 }  // namespace icon
 
 struct icon_work {

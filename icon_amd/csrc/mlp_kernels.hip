@@ -184,8 +184,9 @@ __global__ __launch_bounds__(kMlpBlock, 2) void k_mlp_f32(const float *__restric
 
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st)
 {
-    if (precision != 0) return fail(ICON_ERR_UNSUPPORTED, "mlp: only precision 0 (exact f32 MFMA) is built");
-    return mlp_launch_ex(mlp, d_x, N, d_out, true, st);
+    if (precision == ICON_PRECISION_F32) return mlp_launch_ex(mlp, d_x, N, d_out, true, st);
+    if (precision == ICON_PRECISION_F16X3) return mlp_launch_f16x3(mlp, d_x, N, d_out, true, st);
+    return fail(ICON_ERR_ARG, "mlp: unknown precision");
 }
 
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st)
@@ -311,6 +312,8 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
     e = hipMemcpyAsync(m->d_blob, blob.data(), m->blob_bytes, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { icon_mlp_destroy(m); return fail(ICON_ERR_HIP, std::string("upload mlp: ") + hipGetErrorString(e)); }
+    const int rc = mlp_pack_f16x3(m, W, B, st);
+    if (rc) { icon_mlp_destroy(m); return rc; }
     *out = m;
     return ICON_OK;
 }
@@ -318,7 +321,7 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
 extern "C" int icon_mlp_destroy(icon_mlp_t *m)
 {
     if (!m) return ICON_OK;
-    (void)hipFree(m->d_blob);
+    (void)hipFree(m->d_blob); (void)hipFree(m->d_f16);
     delete m;
     return ICON_OK;
 }
@@ -328,6 +331,7 @@ extern "C" int icon_mlp_forward(const icon_mlp_t *mlp, const float *d_x, int64_t
 {
     ICON_ARG(mlp && d_x && d_out, "icon_mlp_forward: null argument");
     ICON_ARG(N >= 0, "icon_mlp_forward: negative N");
-    if (precision != 0) return fail(ICON_ERR_UNSUPPORTED, "icon_mlp_forward: only precision 0 (exact f32 MFMA) is built");
-    return mlp_launch_ex(mlp, d_x, N, d_out, false, (hipStream_t)stream);
+    if (precision == ICON_PRECISION_F32) return mlp_launch_ex(mlp, d_x, N, d_out, false, (hipStream_t)stream);
+    if (precision == ICON_PRECISION_F16X3) return mlp_launch_f16x3(mlp, d_x, N, d_out, false, (hipStream_t)stream);
+    return fail(ICON_ERR_ARG, "icon_mlp_forward: unknown precision");
 }

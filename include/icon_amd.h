@@ -43,6 +43,11 @@ enum { ICON_PRIOR_ICON = 0, ICON_PRIOR_PAMIR = 1, ICON_PRIOR_PIFU = 2 };
  * outlier (3j+k) mod K.  LOCAL is the per-point rule (cmap := own sign). */
 enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
 
+/* MLP arithmetic.  F32: v_mfma_f32_32x32x2_f32, bit-for-bit an f32 fma chain.  F16X3: every
+ * product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with f32 accumulation
+ * (22-bit operands; ~1e-6 of the f32 result, 5x the rate). */
+enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1 };
+
 /* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
 enum { ICON_SEARCH_BVH = 0, ICON_SEARCH_BRUTE = 1 };
 
@@ -116,7 +121,7 @@ int icon_mlp_create(int n_layers, const int *cin, const int *cout, const int *is
                     float bn_eps, void *stream, icon_mlp_t **out);
 int icon_mlp_destroy(icon_mlp_t *mlp);
 /* MLP.forward on point-major input rows: d_x [N,16] f32 (channels cin[0]..15 ignored),
- * d_out [N].  precision: 0 = exact-f32 MFMA path. */
+ * d_out [N].  precision: ICON_PRECISION_*. */
 int icon_mlp_forward(const icon_mlp_t *mlp, const float *d_x, int64_t N, float *d_out,
                      int precision, void *stream);
 

@@ -106,29 +106,53 @@ def test_sdf_golden_reference(body):
 # ---------------------------------------------------------------------------------------------
 # MLP
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 128, 129, 777, 40000])
-def test_mlp_forward_vs_oracle(body, n):
+PRECISIONS = ["f32", "f16x3"]
+# f32: exact-f32 MFMA chain (differs from the float64 oracle by f32 round-off only);
+# f16x3: 22-bit split operands on the f16 matrix cores, f32 accumulate
+MLP_TOL = {"f32": 1e-5, "f16x3": 2e-5}
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+@pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 777, 40000])
+def test_mlp_forward_vs_oracle(body, n, precision):
     from icon_amd.engine import MlpHandle
     rng = np.random.RandomState(n)
     x = rng.normal(0, 1, (n, 13)).astype(np.float32)
     rows = rows16(x)
     rows[:, 13:] = np.nan if n == 33 else 7.0      # pad slots and the code word must never reach the GEMM
     mlp = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
-    y = mlp.forward(T(rows)).cpu().numpy()
+    y = mlp.forward(T(rows), precision=precision).cpu().numpy()
     ref = orc.Mlp(body.state_dict).forward(x, f64=True)[:, 0]
     assert np.isfinite(y).all()
-    assert np.abs(y - ref).max() <= 1e-5, np.abs(y - ref).max()
+    assert np.abs(y - ref).max() <= MLP_TOL[precision], np.abs(y - ref).max()
 
 
-def test_mlp_golden_reference(body):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_mlp_golden_reference(body, precision):
     from icon_amd.engine import MlpHandle
     g = golden("mlp_777.npz")
     mlp = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
-    y = mlp.forward(T(rows16(g["x"].T.copy()))).cpu().numpy()
-    assert np.abs(y - g["y"]).max() <= 1e-5
+    y = mlp.forward(T(rows16(g["x"].T.copy())), precision=precision).cpu().numpy()
+    assert np.abs(y - g["y"]).max() <= MLP_TOL[precision]
 
 
-def test_mlp_transpose_detecting():
+def test_mlp_f16x3_error_statistics(body):
+    """how far the split-precision path is from float64, on inputs with a wide dynamic range"""
+    from icon_amd.engine import MlpHandle
+    rng = np.random.RandomState(5)
+    x = (rng.normal(0, 1, (200000, 13)) * np.exp(rng.normal(0, 1.5, (200000, 1)))).astype(np.float32)
+    mlp = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
+    ref = orc.Mlp(body.state_dict).forward(x, f64=True)[:, 0]
+    e32 = np.abs(mlp.forward(T(rows16(x)), precision="f32").cpu().numpy() - ref)
+    e16 = np.abs(mlp.forward(T(rows16(x)), precision="f16x3").cpu().numpy() - ref)
+    scale = np.maximum(np.abs(ref), 1.0)
+    print(f"max/mean |err|/max(1,|ref|): f32 {np.max(e32 / scale):.2e}/{np.mean(e32 / scale):.2e}  "
+          f"f16x3 {np.max(e16 / scale):.2e}/{np.mean(e16 / scale):.2e}")
+    assert np.max(e16 / scale) <= 2e-5 and np.mean(e16 / scale) <= 2e-6
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_mlp_transpose_detecting(precision):
     """asymmetric one-hot weights: any row/column or k-permutation slip in the packed operands
     shows up as a wrong channel being routed to the output"""
     from icon_amd.engine import MlpHandle
@@ -141,18 +165,19 @@ def test_mlp_transpose_detecting():
         sd[f"filters.{l}.weight"] = w
         sd[f"filters.{l}.bias"] = (0.01 * rng.normal(size=co)).astype(np.float32)
     x = rng.normal(0, 1, (4096, 13)).astype(np.float32)
-    y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x))).cpu().numpy()
+    y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x)), precision=precision).cpu().numpy()
     ref = orc.Mlp(sd).forward(x, f64=True)[:, 0]
-    assert np.abs(y - ref).max() <= 1e-5
+    assert np.abs(y - ref).max() <= MLP_TOL[precision]
 
 
 # ---------------------------------------------------------------------------------------------
 # HGPIFuNet.query
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("cmap_mode", ["reference", "local"])
 @pytest.mark.parametrize("n", [1, 3, 257, 5000])
-def test_query_points_vs_oracle(body, cmap_mode, n):
-    eng = make_engine(body, cmap_mode=cmap_mode)
+def test_query_points_vs_oracle(body, cmap_mode, n, precision):
+    eng = make_engine(body, cmap_mode=cmap_mode, precision=precision)
     pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], n, seed=n)
     out = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])
     assert isinstance(out, list) and out[0].shape == (1, 1, n)
@@ -161,11 +186,13 @@ def test_query_points_vs_oracle(body, cmap_mode, n):
     assert np.abs(occ - ref).max() <= OCC_TOL, np.abs(occ - ref).max()
 
 
-def test_query_golden_reference(eng_body, body):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_query_golden_reference(body, precision):
     """the committed output of the reference's own query_func -> HGPIFuNet.query"""
     g = golden("query_body_4096.npz")
     from icon_amd.engine import query_func
     from types import SimpleNamespace
+    eng_body = make_engine(body, precision=precision)
     occ = query_func(SimpleNamespace(num_views=1), eng_body, [T(body.features)], T(g["points"])[None])
     assert occ.shape == (1, 1, 4096)
     d = np.abs(occ[0, 0].cpu().numpy() - g["occ"])
@@ -244,19 +271,21 @@ def test_errors(body):
 # ---------------------------------------------------------------------------------------------
 # dense lattice (reconEngine)
 # ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("res", [17, 33])
-def test_lattice_vs_golden_seg3d(eng_body, body, res):
+def test_lattice_vs_golden_seg3d(body, res, precision):
     """== the reference's Seg3dLossless with resolutions=[res], run verbatim"""
     g = golden(f"seg3d_body_dense{res}.npz")
-    occ = eng_body.eval_slab(T(body.features), res, 0, res).cpu().numpy()
+    occ = make_engine(body, precision=precision).eval_slab(T(body.features), res, 0, res).cpu().numpy()
     assert occ.shape == (res, res, res)
     assert np.abs(occ - g["occ"]).max() <= OCC_TOL
 
 
+@pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("cmap_mode", ["reference", "local"])
-def test_lattice_65_vs_oracle(body, cmap_mode):
+def test_lattice_65_vs_oracle(body, cmap_mode, precision):
     res = 65
-    eng = make_engine(body, cmap_mode=cmap_mode)
+    eng = make_engine(body, cmap_mode=cmap_mode, precision=precision)
     occ = eng.eval_slab(T(body.features), res, 0, res).cpu().numpy().ravel()
     ref, _ = oracle_query(body, synth.lattice_points(res), cmap_local=(cmap_mode == "local"))
     assert np.abs(occ - ref).max() <= OCC_TOL
@@ -290,11 +319,13 @@ def test_lattice_slab_split_equals_single_call(body):
     assert np.array_equal(signs.cpu().numpy(), exp)
 
 
-def test_lattice_257_properties(body):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_lattice_257_properties(body, precision):
     """BASELINE.json's full size (257^3 = 16,974,593 points): size-independent properties"""
     res = 257
     feat = T(body.features)
-    e_ref, e_loc = make_engine(body, cmap_mode="reference"), make_engine(body, cmap_mode="local")
+    e_ref = make_engine(body, cmap_mode="reference", precision=precision)
+    e_loc = make_engine(body, cmap_mode="local", precision=precision)
     a = e_ref.eval_slab(feat, res, 0, res)
     b = e_loc.eval_slab(feat, res, 0, res)
     assert a.shape == (res, res, res) and torch.isfinite(a).all()
