@@ -27,11 +27,11 @@ int fail(int code, const std::string &msg);
 
 // ---- device data layouts (HBM) --------------------------------------------------------------
 // BVH2 node, 64 B (one cache line): both children's boxes live in the parent so one load
-// decides both.  child >= 0: internal node index; child < 0: leaf, ~child = (first_slot << 3) |
-// (count - 1), count in 1..8; an empty child has lo = +inf, hi = -inf (distance = +inf).
+// decides both.  child >= 0: internal node index; child < 0: leaf, ~child = (leaf index << 2) |
+// (triangle count - 1); the leaf's triangles are slots 4*leaf .. 4*leaf+3; an empty child has
+// lo = +inf, hi = -inf (distance = +inf).
 struct alignas(64) BvhNode {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
+    float lo[3][2], hi[3][2];   // [axis][child]: the two children's bounds interleaved (packed-f32 operands)
     int32_t child0, child1;
     int32_t pad[2];
 };
@@ -57,7 +57,28 @@ struct alignas(16) TriAttr {
 };
 static_assert(sizeof(TriAttr) == 96, "TriAttr must be 96 bytes");
 
-constexpr int kLeafMax = 4;        // triangles per BVH leaf
+// Per-triangle constants of the distance test, 96 B, evaluated once on the host:
+// corners a, b; edges ab, ac, bc; reciprocal squared edge lengths; Gram matrix of (ab, ac) and
+// the reciprocal of its determinant (reciprocals are 0 for zero-length / zero-area cases).
+struct alignas(32) TriPre {
+    float a[3], b[3], ab[3], ac[3], bc[3];
+    float i00, i11, ibc, a00, a01, a11, inn;
+    int32_t face;       // original face index
+    int32_t pad;
+};
+static_assert(sizeof(TriPre) == 96, "TriPre must be 96 bytes");
+
+// BVH leaf as the packet traversal reads it: two PAIRS of triangles, each pair stored
+// field-interleaved ([field 0..23][triangle 0..1]) so that one 8-byte scalar load yields the same
+// constant of both triangles - the operand shape of the packed-f32 VALU (v_pk_fma_f32 & co), which
+// evaluates the distance test for two triangles per instruction.  Short leaves repeat their last
+// triangle.  Field order = TriPre's 24 dwords.
+struct alignas(32) LeafRec {
+    float pair[2][24][2];
+};
+static_assert(sizeof(LeafRec) == 384, "LeafRec must be 384 bytes");
+
+constexpr int kLeafMax = 4;        // triangle slots per BVH leaf (short leaves are padded)
 constexpr int kStackDepth = 48;    // per-wave traversal stack entries (LDS)
 constexpr int kXRow = 16;          // floats per point row of the MLP input buffer
 constexpr int kCodeSlot = 15;      // row slot holding the per-point code word
@@ -72,7 +93,8 @@ struct MeshDev {
     const TriRec *tris;
     const TriAttr *attr;
     const int32_t *slot2face;
-    int32_t n_tris;
+    const LeafRec *leaves;
+    int32_t n_tris;             // triangle slots = 4 * leaves (incl. padding copies)
     int32_t root_is_leaf;
     // ray bins over (y, z)
     const int32_t *bin_start;   // [gy*gz + 1]
@@ -106,10 +128,11 @@ struct icon_mesh {
     icon::TriRec *d_tris = nullptr;
     icon::TriAttr *d_attr = nullptr;
     int32_t *d_slot2face = nullptr;
+    icon::LeafRec *d_leaves = nullptr;
     int32_t *d_bin_start = nullptr;
     int32_t *d_bin_slots = nullptr;
     icon::MeshDev dev{};
-    int64_t stats[4] = {0, 0, 0, 0};
+    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
 };
 
 struct icon_feat {
@@ -141,6 +164,7 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
 
 struct icon_work {
     float *d_x = nullptr;                 // [cap_points][16] MLP input rows
+    void *d_near = nullptr;               // [cap_points] (slot, d^2 bits) from k_nearest
     int64_t cap_points = 0;
     int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
     int64_t *d_block_offsets = nullptr;   // exclusive prefix of the above

@@ -9,6 +9,7 @@
 // other contraction) so that the normals are bit-identical to the checker's.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -51,7 +52,9 @@ struct Builder {
     std::vector<float> cen;        // [F][3]
     std::vector<int32_t> order;    // permutation of faces; leaves index into it
     std::vector<BvhNode> nodes;
+    std::vector<std::pair<int, int>> leaves;   // (first index into `order`, count 1..kLeafMax)
     int max_depth = 0;
+    int leaf_cap = kLeafMax;                   // triangles per leaf (tuning knob ICON_AMD_LEAF, 1..kLeafMax)
 
     // returns child reference (>=0 node, <0 leaf code); fills `box`
     int32_t build(int begin, int end, int depth, Box &box)
@@ -61,7 +64,7 @@ struct Builder {
         Box cb;
         for (int i = begin; i < end; ++i) { box.grow(tbox[order[i]]); cb.grow(&cen[3 * order[i]]); }
         const int n = end - begin;
-        if (n <= kLeafMax) return ~((begin << 3) | (n - 1));
+        if (n <= leaf_cap) { leaves.emplace_back(begin, n); return ~(int32_t)(((leaves.size() - 1) << 2) | (size_t)(n - 1)); }
 
         int axis = 0, mid = -1;
         const bool force_median = depth >= kStackDepth - 6;
@@ -116,11 +119,26 @@ struct Builder {
         const int32_t c0 = build(begin, mid, depth + 1, b0);
         const int32_t c1 = build(mid, end, depth + 1, b1);
         BvhNode &nd = nodes[me];
-        for (int k = 0; k < 3; ++k) { nd.lo0[k] = b0.lo[k]; nd.hi0[k] = b0.hi[k]; nd.lo1[k] = b1.lo[k]; nd.hi1[k] = b1.hi[k]; }
+        for (int k = 0; k < 3; ++k) { nd.lo[k][0] = b0.lo[k]; nd.hi[k][0] = b0.hi[k]; nd.lo[k][1] = b1.lo[k]; nd.hi[k][1] = b1.hi[k]; }
         nd.child0 = c0; nd.child1 = c1; nd.pad[0] = nd.pad[1] = 0;
         return me;
     }
 };
+
+// S2 per-triangle constants (same float32 operation sequence as the checker's orc_tri_setup)
+inline float dot3(const float *a, const float *b) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+inline void tri_setup(const float *a, const float *b, const float *c, int32_t face, TriPre &t)
+{
+    for (int k = 0; k < 3; ++k) { t.a[k] = a[k]; t.b[k] = b[k]; t.ab[k] = b[k] - a[k]; t.ac[k] = c[k] - a[k]; t.bc[k] = c[k] - b[k]; }
+    t.a00 = dot3(t.ab, t.ab); t.a01 = dot3(t.ab, t.ac); t.a11 = dot3(t.ac, t.ac);
+    const float b11 = dot3(t.bc, t.bc);
+    t.i00 = (t.a00 > 0.0f) ? 1.0f / t.a00 : 0.0f;
+    t.i11 = (t.a11 > 0.0f) ? 1.0f / t.a11 : 0.0f;
+    t.ibc = (b11 > 0.0f) ? 1.0f / b11 : 0.0f;
+    const float nn = fmaf(t.a00, t.a11, -(t.a01 * t.a01));
+    t.inn = (nn > 0.0f) ? 1.0f / nn : 0.0f;
+    t.face = face; t.pad = 0;
+}
 
 inline int cell_of(float v, float v0, float inv, int g)
 {
@@ -201,13 +219,14 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         mesh_box.grow(bd.tbox[f]);
     }
     bd.nodes.reserve(F);
+    if (const char *e = getenv("ICON_AMD_LEAF")) bd.leaf_cap = std::min(std::max(atoi(e), 1), kLeafMax);
     Box root_box;
     int32_t root = bd.build(0, (int)F, 0, root_box);
     int32_t root_is_leaf = 0;
     if (root < 0) {   // tiny mesh: wrap the single leaf in a node with an empty second child
         BvhNode nd{};
-        for (int k = 0; k < 3; ++k) { nd.lo0[k] = root_box.lo[k]; nd.hi0[k] = root_box.hi[k]; nd.lo1[k] = INFINITY; nd.hi1[k] = -INFINITY; }
-        nd.child0 = root; nd.child1 = ~0;  // never visited: its box distance is +inf
+        for (int k = 0; k < 3; ++k) { nd.lo[k][0] = root_box.lo[k]; nd.hi[k][0] = root_box.hi[k]; nd.lo[k][1] = INFINITY; nd.hi[k][1] = -INFINITY; }
+        nd.child0 = root; nd.child1 = root;  // second child is never visited: its box distance is +inf
         bd.nodes.push_back(nd);
         root_is_leaf = 1;
     } else if (root != 0) {
@@ -215,22 +234,38 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     }
     if (bd.max_depth + 2 > kStackDepth) return fail(ICON_ERR_UNSUPPORTED, "icon_mesh_create: BVH too deep");
 
-    // slot-ordered triangle records / attributes
-    std::vector<TriRec> tris(F);
-    std::vector<TriAttr> attr(F);
-    std::vector<int32_t> slot2face(F);
-    for (int64_t s = 0; s < F; ++s) {
-        const int64_t f = bd.order[s];
-        const int64_t id[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
-        TriRec &t = tris[s];
-        for (int k = 0; k < 3; ++k) { t.a[k] = verts[3 * id[0] + k]; t.b[k] = verts[3 * id[1] + k]; t.c[k] = verts[3 * id[2] + k]; }
-        t.ia = (int32_t)id[0]; t.ib = (int32_t)id[1]; t.ic = (int32_t)id[2];
-        TriAttr &a = attr[s];
-        for (int c = 0; c < 3; ++c)
-            for (int k = 0; k < 3; ++k) { a.n[c][k] = vn[3 * id[c] + k]; a.cm[c][k] = cmap[3 * id[c] + k]; }
-        for (int c = 0; c < 3; ++c) a.vis[c] = vis[id[c]];
-        a.face = (int32_t)f; a.pad[0] = a.pad[1] = 0;
-        slot2face[s] = (int32_t)f;
+    // slot-ordered triangle records / attributes.  Every leaf owns exactly kLeafMax consecutive
+    // slots; short leaves are padded with copies of their last triangle (same face id, so a copy can
+    // never change the arg-min) whose vertex ids are -1 so the ray-parity scans skip them.
+    const int64_t n_leaves = (int64_t)bd.leaves.size();
+    const int64_t S = n_leaves * kLeafMax;
+    std::vector<TriRec> tris(S);
+    std::vector<TriAttr> attr(S);
+    std::vector<int32_t> slot2face(S);
+    std::vector<LeafRec> leafrec(n_leaves);
+    std::vector<int64_t> slot_src(S, -1);          // real slots: index into bd.order; padding: -1
+    for (int64_t L = 0; L < n_leaves; ++L) {
+        const int begin = bd.leaves[L].first, cnt = bd.leaves[L].second;
+        for (int t = 0; t < kLeafMax; ++t) {
+            const int64_t s = L * kLeafMax + t;
+            const bool real = t < cnt;
+            const int64_t f = bd.order[begin + std::min(t, cnt - 1)];
+            const int64_t id[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
+            TriRec &tr = tris[s];
+            for (int k = 0; k < 3; ++k) { tr.a[k] = verts[3 * id[0] + k]; tr.b[k] = verts[3 * id[1] + k]; tr.c[k] = verts[3 * id[2] + k]; }
+            tr.ia = real ? (int32_t)id[0] : -1; tr.ib = real ? (int32_t)id[1] : -1; tr.ic = real ? (int32_t)id[2] : -1;
+            TriAttr &a = attr[s];
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < 3; ++k) { a.n[c][k] = vn[3 * id[c] + k]; a.cm[c][k] = cmap[3 * id[c] + k]; }
+            for (int c = 0; c < 3; ++c) a.vis[c] = vis[id[c]];
+            a.face = (int32_t)f; a.pad[0] = a.pad[1] = 0;
+            slot2face[s] = (int32_t)f;
+            if (real) slot_src[s] = begin + t;
+            TriPre pre;
+            tri_setup(tr.a, tr.b, tr.c, (int32_t)f, pre);
+            const float *src = reinterpret_cast<const float *>(&pre);
+            for (int fld = 0; fld < 24; ++fld) leafrec[L].pair[t >> 1][fld][t & 1] = src[fld];
+        }
     }
 
     // (y,z) ray bins: every triangle is listed in all cells its (y,z) bounding box, grown by
@@ -246,11 +281,12 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     const float inv_y = (float)gy / (y1 - y0), inv_z = (float)gz / (z1 - z0);
     std::vector<int32_t> bin_start((size_t)gy * gz + 1, 0);
     auto range = [&](int64_t s, int &cy0, int &cy1, int &cz0, int &cz1) {
-        const Box &b = bd.tbox[bd.order[s]];
+        const Box &b = bd.tbox[bd.order[slot_src[s]]];
         cy0 = cell_of(b.lo[1] - eps, y0, inv_y, gy); cy1 = cell_of(b.hi[1] + eps, y0, inv_y, gy);
         cz0 = cell_of(b.lo[2] - eps, z0, inv_z, gz); cz1 = cell_of(b.hi[2] + eps, z0, inv_z, gz);
     };
-    for (int64_t s = 0; s < F; ++s) {
+    for (int64_t s = 0; s < S; ++s) {
+        if (slot_src[s] < 0) continue;
         int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
         for (int cz = cz0; cz <= cz1; ++cz)
             for (int cy = cy0; cy <= cy1; ++cy) bin_start[(size_t)cz * gy + cy + 1]++;
@@ -260,7 +296,8 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     std::vector<int32_t> bin_slots(bin_start.back());
     {
         std::vector<int32_t> fill(bin_start.begin(), bin_start.end() - 1);
-        for (int64_t s = 0; s < F; ++s) {   // ascending slot order inside every bin
+        for (int64_t s = 0; s < S; ++s) {   // ascending slot order inside every bin
+            if (slot_src[s] < 0) continue;
             int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
             for (int cz = cz0; cz <= cz1; ++cz)
                 for (int cy = cy0; cy <= cy1; ++cy) bin_slots[fill[(size_t)cz * gy + cy]++] = (int32_t)s;
@@ -272,7 +309,8 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     int rc;
     if ((rc = upload(&m->d_vnormals, vn, st)) || (rc = upload(&m->d_nodes, bd.nodes, st)) ||
         (rc = upload(&m->d_tris, tris, st)) || (rc = upload(&m->d_attr, attr, st)) ||
-        (rc = upload(&m->d_slot2face, slot2face, st)) || (rc = upload(&m->d_bin_start, bin_start, st)) ||
+        (rc = upload(&m->d_slot2face, slot2face, st)) || (rc = upload(&m->d_leaves, leafrec, st)) ||
+        (rc = upload(&m->d_bin_start, bin_start, st)) ||
         (rc = upload(&m->d_bin_slots, bin_slots, st))) {
         icon_mesh_destroy(m);
         return rc;
@@ -280,12 +318,14 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     ICON_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
     MeshDev &d = m->dev;
     d.nodes = m->d_nodes; d.tris = m->d_tris; d.attr = m->d_attr; d.slot2face = m->d_slot2face;
-    d.n_tris = (int32_t)F; d.root_is_leaf = root_is_leaf;
+    d.leaves = m->d_leaves;
+    d.n_tris = (int32_t)S; d.root_is_leaf = root_is_leaf;
     d.bin_start = m->d_bin_start; d.bin_slots = m->d_bin_slots;
     d.bin_y0 = y0; d.bin_z0 = z0; d.bin_y1 = y1; d.bin_z1 = z1; d.bin_inv_y = inv_y; d.bin_inv_z = inv_z;
     d.gy = gy; d.gz = gz;
     m->stats[0] = (int64_t)bd.nodes.size(); m->stats[1] = bd.max_depth;
     m->stats[2] = (int64_t)bin_slots.size(); m->stats[3] = max_bin;
+    m->stats[4] = n_leaves; m->stats[5] = S;
     *out = m;
     return ICON_OK;
 }
@@ -294,7 +334,7 @@ extern "C" int icon_mesh_destroy(icon_mesh_t *m)
 {
     if (!m) return ICON_OK;
     (void)hipFree(m->d_vnormals); (void)hipFree(m->d_nodes); (void)hipFree(m->d_tris); (void)hipFree(m->d_attr);
-    (void)hipFree(m->d_slot2face); (void)hipFree(m->d_bin_start); (void)hipFree(m->d_bin_slots);
+    (void)hipFree(m->d_slot2face); (void)hipFree(m->d_bin_start); (void)hipFree(m->d_bin_slots); (void)hipFree(m->d_leaves);
     delete m;
     return ICON_OK;
 }
@@ -306,9 +346,9 @@ extern "C" int icon_mesh_vertex_normals(const icon_mesh_t *m, float *d_out, void
     return ICON_OK;
 }
 
-extern "C" int icon_mesh_stats(const icon_mesh_t *m, int64_t out[4])
+extern "C" int icon_mesh_stats(const icon_mesh_t *m, int64_t out[6])
 {
     ICON_ARG(m && out, "icon_mesh_stats: null argument");
-    for (int k = 0; k < 4; ++k) out[k] = m->stats[k];
+    for (int k = 0; k < 6; ++k) out[k] = m->stats[k];
     return ICON_OK;
 }

@@ -14,6 +14,7 @@
 
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 
 namespace icon {
@@ -30,45 +31,99 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b)
     return mk3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
 }
 
-// S2: exact point-triangle squared distance, Voronoi-region form (same operation sequence as
-// the checker's orc_point_tri_dist2).
-__device__ __forceinline__ float pt_tri_dist2(f3 p, f3 a, f3 b, f3 c)
+// S2: exact point-triangle squared distance, "face or nearest edge" form on per-triangle constants
+// prepared by the host (TriPre).  Same operations on the same operands as the checker's
+// orc_tri_dist2, hence bit-identical results; no division, no branches:
+//   (s,t) = barycentrics of the plane projection; inside -> |p - (a + s ab + t ac)|^2,
+//   else min over the three segments of |p - (origin + clamp(t,0,1) * edge)|^2.
+struct TriC {   // TriPre fields as values (SGPRs when read through the constant address space)
+    f3 a, b, ab, ac, bc;
+    float i00, i11, ibc, a00, a01, a11, inn;
+};
+
+__device__ __forceinline__ float seg_dist2(f3 p, f3 o, f3 e, float dot_e_po, float inv_len2)
 {
-    const f3 ab = sub3(b, a), ac = sub3(c, a);
-    const f3 ap = sub3(p, a), bp = sub3(p, b), cp = sub3(p, c);
-    const float d1 = dot3(ab, ap), d2 = dot3(ac, ap);
-    const float d3 = dot3(ab, bp), d4 = dot3(ac, bp);
-    const float d5 = dot3(ab, cp), d6 = dot3(ac, cp);
-    const float va = fmaf(d3, d6, -(d5 * d4));
-    const float vb = fmaf(d5, d2, -(d1 * d6));
-    const float vc = fmaf(d1, d4, -(d3 * d2));
-    float v, w;
-    if (d1 <= 0.0f && d2 <= 0.0f) { v = 0.0f; w = 0.0f; }
-    else if (d3 >= 0.0f && d4 <= d3) { v = 1.0f; w = 0.0f; }
-    else if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {
-        const float inv = 1.0f / (d1 - d3);
-        v = d1 * inv; w = 0.0f;
-    }
-    else if (d6 >= 0.0f && d5 <= d6) { v = 0.0f; w = 1.0f; }
-    else if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {
-        const float inv = 1.0f / (d2 - d6);
-        v = 0.0f; w = d2 * inv;
-    }
-    else if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {
-        const float n = d4 - d3;
-        const float inv = 1.0f / (n + (d5 - d6));
-        w = n * inv; v = 1.0f - w;
-    }
-    else {
-        const float inv = 1.0f / ((va + vb) + vc);
-        v = vb * inv; w = vc * inv;
-    }
-    f3 q;
-    q.x = fmaf(ac.x, w, fmaf(ab.x, v, a.x));
-    q.y = fmaf(ac.y, w, fmaf(ab.y, v, a.y));
-    q.z = fmaf(ac.z, w, fmaf(ab.z, v, a.z));
+    const float t = fminf(fmaxf(dot_e_po * inv_len2, 0.0f), 1.0f);
+    const f3 q = mk3(fmaf(e.x, t, o.x), fmaf(e.y, t, o.y), fmaf(e.z, t, o.z));
     const f3 d = sub3(p, q);
     return dot3(d, d);
+}
+
+__device__ __forceinline__ float tri_dist2(f3 p, const TriC &t)
+{
+    const f3 ap = sub3(p, t.a), bp = sub3(p, t.b);
+    const float d1 = dot3(t.ab, ap), d2 = dot3(t.ac, ap), d3 = dot3(t.bc, bp);
+    const float s = fmaf(t.a11, d1, -(t.a01 * d2)) * t.inn;
+    const float u = fmaf(t.a00, d2, -(t.a01 * d1)) * t.inn;
+    const bool inside = (s >= 0.0f) & (u >= 0.0f) & (s + u <= 1.0f);
+    const f3 q = mk3(fmaf(t.ac.x, u, fmaf(t.ab.x, s, t.a.x)), fmaf(t.ac.y, u, fmaf(t.ab.y, s, t.a.y)),
+                     fmaf(t.ac.z, u, fmaf(t.ab.z, s, t.a.z)));
+    const f3 df = sub3(p, q);
+    float d_face = dot3(df, df);
+    const float e0 = seg_dist2(p, t.a, t.ab, d1, t.i00);
+    const float e1 = seg_dist2(p, t.a, t.ac, d2, t.i11);
+    const float e2 = seg_dist2(p, t.b, t.bc, d3, t.ibc);
+    float d_edge = fminf(fminf(e0, e1), e2);
+    asm volatile("" : "+v"(d_face), "+v"(d_edge));    // keep the final choice a v_cndmask
+    return inside ? d_face : d_edge;
+}
+
+template <class Ptr>
+__device__ __forceinline__ TriC load_tric(Ptr q)   // q: 24 dwords of a TriPre
+{
+    TriC t;
+    t.a = mk3(q[0], q[1], q[2]); t.b = mk3(q[3], q[4], q[5]); t.ab = mk3(q[6], q[7], q[8]);
+    t.ac = mk3(q[9], q[10], q[11]); t.bc = mk3(q[12], q[13], q[14]);
+    t.i00 = q[15]; t.i11 = q[16]; t.ibc = q[17]; t.a00 = q[18]; t.a01 = q[19]; t.a11 = q[20]; t.inn = q[21];
+    return t;
+}
+
+// ---- two triangles per instruction: the same test on packed f32 (v_pk_add / v_pk_mul / v_pk_fma) ----
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(4))) const f2 cf2;
+struct f3x2 { f2 x, y, z; };
+__device__ __forceinline__ f2 bc2(float v) { f2 r; r.x = v; r.y = v; return r; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f3x2 sub3x2(f3x2 a, f3x2 b) { f3x2 r; r.x = a.x - b.x; r.y = a.y - b.y; r.z = a.z - b.z; return r; }
+__device__ __forceinline__ f2 dot3x2(f3x2 a, f3x2 b) { return fma2(a.z, b.z, fma2(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f2 clamp01x2(f2 v)
+{
+    f2 r; r.x = fminf(fmaxf(v.x, 0.0f), 1.0f); r.y = fminf(fmaxf(v.y, 0.0f), 1.0f); return r;
+}
+__device__ __forceinline__ f2 seg_dist2x2(f3x2 p, f3x2 o, f3x2 e, f2 dot_e_po, f2 inv_len2)
+{
+    const f2 t = clamp01x2(dot_e_po * inv_len2);
+    f3x2 q; q.x = fma2(e.x, t, o.x); q.y = fma2(e.y, t, o.y); q.z = fma2(e.z, t, o.z);
+    const f3x2 d = sub3x2(p, q);
+    return dot3x2(d, d);
+}
+
+// q: 24 f2 fields of one leaf pair (constant address space -> SGPR pairs)
+__device__ __forceinline__ f2 tri_dist2_pair(f3 p1, cf2 *q)
+{
+    f3x2 p; p.x = bc2(p1.x); p.y = bc2(p1.y); p.z = bc2(p1.z);
+    f3x2 a, b, ab, ac, bc;
+    a.x = q[0]; a.y = q[1]; a.z = q[2]; b.x = q[3]; b.y = q[4]; b.z = q[5];
+    ab.x = q[6]; ab.y = q[7]; ab.z = q[8]; ac.x = q[9]; ac.y = q[10]; ac.z = q[11]; bc.x = q[12]; bc.y = q[13]; bc.z = q[14];
+    const f2 i00 = q[15], i11 = q[16], ibc = q[17], a00 = q[18], a01 = q[19], a11 = q[20], inn = q[21];
+    const f3x2 ap = sub3x2(p, a), bp = sub3x2(p, b);
+    const f2 d1 = dot3x2(ab, ap), d2 = dot3x2(ac, ap), d3 = dot3x2(bc, bp);
+    const f2 s = fma2(a11, d1, -(a01 * d2)) * inn;
+    const f2 u = fma2(a00, d2, -(a01 * d1)) * inn;
+    const f2 su = s + u;
+    f3x2 qf; qf.x = fma2(ac.x, u, fma2(ab.x, s, a.x)); qf.y = fma2(ac.y, u, fma2(ab.y, s, a.y)); qf.z = fma2(ac.z, u, fma2(ab.z, s, a.z));
+    const f3x2 df = sub3x2(p, qf);
+    f2 d_face = dot3x2(df, df);
+    const f2 e0 = seg_dist2x2(p, a, ab, d1, i00);
+    const f2 e1 = seg_dist2x2(p, a, ac, d2, i11);
+    const f2 e2 = seg_dist2x2(p, b, bc, d3, ibc);
+    f2 d_edge; d_edge.x = fminf(fminf(e0.x, e1.x), e2.x); d_edge.y = fminf(fminf(e0.y, e1.y), e2.y);
+    const bool in0 = (s.x >= 0.0f) & (u.x >= 0.0f) & (su.x <= 1.0f);
+    const bool in1 = (s.y >= 0.0f) & (u.y >= 0.0f) & (su.y <= 1.0f);
+    float f0 = d_face.x, f1 = d_face.y, g0 = d_edge.x, g1 = d_edge.y;
+    asm volatile("" : "+v"(f0), "+v"(f1), "+v"(g0), "+v"(g1));
+    f2 r; r.x = in0 ? f0 : g0; r.y = in1 ? f1 : g1;
+    return r;
 }
 
 // S4: +x ray / triangle crossing with the canonical (lower vertex id first) edge rule.
@@ -138,6 +193,20 @@ __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float h
     return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
 }
 
+// both children of a node at once (packed f32): squared distance from p to each child's box
+__device__ __forceinline__ f2 box_dist2_pair(cf2 *q, f3 p)
+{
+    const f2 px = bc2(p.x), py = bc2(p.y), pz = bc2(p.z);
+    const f2 ax = q[0] - px, bx = px - q[3];
+    const f2 ay = q[1] - py, by = py - q[4];
+    const f2 az = q[2] - pz, bz = pz - q[5];
+    f2 dx, dy, dz;
+    dx.x = fmaxf(fmaxf(ax.x, bx.x), 0.0f); dx.y = fmaxf(fmaxf(ax.y, bx.y), 0.0f);
+    dy.x = fmaxf(fmaxf(ay.x, by.x), 0.0f); dy.y = fmaxf(fmaxf(ay.y, by.y), 0.0f);
+    dz.x = fmaxf(fmaxf(az.x, bz.x), 0.0f); dz.y = fmaxf(fmaxf(az.y, bz.y), 0.0f);
+    return fma2(dz, dz, fma2(dy, dy, dx * dx));
+}
+
 struct Nearest { float d2; int slot; int face; };
 
 // Pruning bound: a subtree may be skipped only if no triangle in it can tie or beat `best`.
@@ -149,58 +218,55 @@ __device__ __forceinline__ float prune_threshold(float best)
     return s * s * 1.000001f;
 }
 
-__device__ __forceinline__ void consider(const MeshDev &m, f3 p, int slot, Nearest &nr, float &thr)
-{
-    f3 a, b, c;
-    load_tri_pos(m.tris + slot, a, b, c);
-    const float d2 = pt_tri_dist2(p, a, b, c);
-    if (d2 <= nr.d2) {                       // NaN never passes
-        const int face = m.slot2face[slot];
-        if (d2 < nr.d2 || face < nr.face) {  // S3: exact ties go to the lowest face index
-            nr.d2 = d2; nr.slot = slot; nr.face = face;
-            thr = prune_threshold(d2);
-        }
-    }
-}
-
 // BVH2 PACKET traversal: the 64 lanes of a wavefront descend the tree TOGETHER.  Control flow, the
-// node / triangle addresses and the stack are wave-uniform (scalar registers, scalar loads, one
-// LDS word per stack entry per wave); every lane tests its own point against the shared node
-// boxes and triangles, and a subtree is entered when ANY lane still needs it.  In lattice mode a
-// wavefront owns a 4x4x4 block of lattice points, so the lanes' candidate sets nearly coincide and
-// there is no divergence at all.  Near child first, ordered by the block's centre lane.
+// node / leaf addresses and the stack are wave-uniform (scalar registers, scalar loads, one LDS
+// word per stack entry per wave); every lane tests its own point against the shared node boxes
+// and triangles, and a subtree is entered when ANY lane still needs it.  In lattice mode a
+// wavefront owns a 4x4x4 block of lattice points, so the lanes' candidate sets nearly coincide.
+// A leaf holds up to 4 TriPre records (96 B each, scalar loads); the distance test is branch-free.  Near child first, ordered by the block's centre lane.
 // `live` = false parks a padding lane: it never votes and its result is discarded.
-__device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */)
+template <bool STATS = false>
+__device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
+                                                  int *n_nodes = nullptr, int *n_tris = nullptr)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
+    unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
+    int slot = 0;
     float thr = live ? INFINITY : -INFINITY;
     int sp = 0;
     int cur = 0;
     while (true) {
         if (cur < 0) {
             const int code = ~cur;
-            const int first = code >> 3, cnt = (code & 7) + 1;
-            for (int t = 0; t < cnt; ++t) {
-                const int slot = first + t;
-                f3 a, b, c;
-                load_tri_pos_uniform(m.tris + slot, a, b, c);
-                const float d2 = pt_tri_dist2(p, a, b, c);
-                const bool cand = live && d2 <= nr.d2;            // NaN never passes
-                if (__any(cand)) {
-                    const int face = __float_as_int(as_const(m.slot2face)[slot]);
-                    if (cand && (d2 < nr.d2 || face < nr.face)) { // S3: exact ties -> lowest face index
-                        nr.d2 = d2; nr.slot = slot; nr.face = face;
-                        thr = prune_threshold(d2);
-                    }
-                }
+            const int leaf = code >> 2, cnt = (code & 3) + 1;
+            if (STATS) *n_tris += cnt;
+            const unsigned long long before = key;
+            for (int pr = 0; pr * 2 < cnt; ++pr) {
+                cf2 *q = reinterpret_cast<cf2 *>(as_const(&m.leaves[leaf].pair[pr]));
+                const f2 d2 = tri_dist2_pair(p, q);
+                const f2 fc = q[22];
+                // S3 as ONE unsigned 64-bit minimum: key = (bits of d^2) << 32 | face.  d^2 >= +0, so
+                // its bit pattern orders like the value; equal d^2 -> lower face id wins; NaN (bits
+                // above +inf) never wins; a padding copy has the same key as its original.
+                const unsigned long long k0 = ((unsigned long long)(unsigned)__float_as_int(d2.x) << 32) | (unsigned)__float_as_int(fc.x);
+                const unsigned long long k1 = ((unsigned long long)(unsigned)__float_as_int(d2.y) << 32) | (unsigned)__float_as_int(fc.y);
+                const bool u0 = live & (k0 < key);
+                key = u0 ? k0 : key; slot = u0 ? leaf * kLeafMax + 2 * pr : slot;
+                const bool u1 = live & (k1 < key);
+                key = u1 ? k1 : key; slot = u1 ? leaf * kLeafMax + 2 * pr + 1 : slot;
             }
+            const bool improved = key != before;
+            nr.d2 = __int_as_float((int)(key >> 32));
+            if (__any(improved)) thr = live ? prune_threshold(nr.d2) : thr;
             if (sp == 0) break;
             cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
         } else {
-            cfloat *q = as_const(m.nodes + cur);
-            const float d0 = box_dist2(q[0], q[1], q[2], q[3], q[4], q[5], p);
-            const float d1 = box_dist2(q[6], q[7], q[8], q[9], q[10], q[11], p);
-            const int c0 = __float_as_int(q[12]), c1 = __float_as_int(q[13]);
+            if (STATS) ++*n_nodes;
+            cf2 *q = reinterpret_cast<cf2 *>(as_const(m.nodes + cur));   // lo.x lo.y lo.z hi.x hi.y hi.z (children 0,1), ids
+            const f2 dd = box_dist2_pair(q, p);
+            const float d0 = dd.x, d1 = dd.y;
+            const f2 ids = q[6];
+            const int c0 = __float_as_int(ids.x), c1 = __float_as_int(ids.y);
             const bool v0 = __any(d0 <= thr), v1 = __any(d1 <= thr);
             if (v0 && v1) {
                 // order by the block's centre lane; non-negative floats order like their bit patterns
@@ -217,29 +283,30 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
             }
         }
     }
+    nr.d2 = __int_as_float((int)(key >> 32)); nr.slot = slot; nr.face = (int)(key & 0xffffffffu);
     return nr;
 }
 
 // Brute force over all triangle slots, staged through LDS in tiles (validation path).
+// Reads the same TriPre constants as the packet traversal (slot s = record s&3 of leaf s>>2).
+constexpr int kBruteTile = 128;   // 128 x 96 B = 12 KiB of LDS
 template <int BLOCK>
-__device__ __forceinline__ Nearest nearest_brute(const MeshDev &m, f3 p, float *tile /* LDS, BLOCK*12 floats */)
+__device__ __forceinline__ Nearest nearest_brute(const MeshDev &m, f3 p, float *tile /* LDS, kBruteTile*24 floats */)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
-    for (int base = 0; base < m.n_tris; base += BLOCK) {
+    const float *src = reinterpret_cast<const float *>(m.leaves);
+    for (int base = 0; base < m.n_tris; base += kBruteTile) {
         __syncthreads();
-        const int s = base + threadIdx.x;
-        if (s < m.n_tris) {
-            const float4 *q = reinterpret_cast<const float4 *>(m.tris + s);
-            float4 *dst = reinterpret_cast<float4 *>(tile + threadIdx.x * 12);
-            dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
-            dst[2].w = __int_as_float(m.slot2face[s]);   // vertex id ic not needed here
+        const int n = min(kBruteTile, m.n_tris - base);
+        for (int k = threadIdx.x; k < n * 24; k += BLOCK) {
+            const int s = base + k / 24, fld = k % 24;        // slot s = pair (s>>1)&1, lane s&1 of leaf s>>2
+            tile[k] = src[((size_t)(s >> 2) * 2 + ((s >> 1) & 1)) * 48 + fld * 2 + (s & 1)];
         }
         __syncthreads();
-        const int n = min(BLOCK, m.n_tris - base);
         for (int t = 0; t < n; ++t) {
-            const float *r = tile + t * 12;
-            const float d2 = pt_tri_dist2(p, mk3(r[0], r[1], r[2]), mk3(r[3], r[4], r[5]), mk3(r[6], r[7], r[8]));
-            const int face = __float_as_int(r[11]);
+            const float *r = tile + t * 24;
+            const float d2 = tri_dist2(p, load_tric(r));
+            const int face = __float_as_int(r[22]);
             if (d2 < nr.d2 || (d2 == nr.d2 && face < nr.face)) { nr.d2 = d2; nr.slot = base + t; nr.face = face; }
         }
     }
@@ -274,7 +341,7 @@ __device__ __forceinline__ bool inside_brute(const MeshDev &m, f3 p)
     for (int s = 0; s < m.n_tris; ++s) {
         f3 a, b, c; int ia, ib, ic;
         load_tri_full(m.tris + s, a, b, c, ia, ib, ic);
-        cnt += ray_hit(p, a, b, c, ia, ib, ic);
+        if (ia >= 0) cnt += ray_hit(p, a, b, c, ia, ib, ic);     // ia < 0: padding copy of a short leaf
     }
     return (cnt & 1) != 0;
 }
@@ -424,11 +491,14 @@ __device__ __forceinline__ void gather_planes_dyn(const FeatDev &f, int sel, flo
 // ---------------------------------------------------------------------------------------------
 // Lattice tiling: a wavefront owns a 4x4x4 block of lattice points (spatially compact, so its
 // 64 BVH traversals follow nearly the same path); a 256-thread workgroup owns 16x4x4.
-// Workgroups are numbered y-slowest and dealt to the 8 XCDs in contiguous runs, so each XCD's
-// private L2 keeps one horizontal band of the body mesh hot.
+// Workgroups are numbered y-slowest; consecutive workgroups go to different XCDs (hardware
+// round-robin), which balances the strongly position-dependent traversal cost.  The optional
+// contiguous-band-per-XCD remap (ICON_AMD_XCD_REMAP=1) keeps each L2 on one band of the body but
+// was measured 1.6x slower: the mesh fits every L2 anyway and the bands are unequal work.
 struct LatticeMap {
     int res, z0, nz;           // evaluated planes [z0, z0+nz)
     int tx, ty, tz;            // tile counts
+    int remap;                 // 1: contiguous run of tiles per XCD, 0: tiles interleaved over XCDs
 };
 
 __device__ __forceinline__ int xcd_remap(int b, int nb)
@@ -443,7 +513,7 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
 {
     const int nb = L.tx * L.ty * L.tz;
-    const int t = xcd_remap(blockIdx.x, nb);
+    const int t = L.remap ? xcd_remap(blockIdx.x, nb) : (int)blockIdx.x;
     const int bty = t / (L.tz * L.tx);
     const int rem = t - bty * (L.tz * L.tx);
     const int btz = rem / L.tx, btx = rem - btz * L.tx;
@@ -501,7 +571,7 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
                                                       float *sdf, float *nrm, float *cm, float *vis,
                                                       int64_t *face, uint8_t *inside_out)
 {
-    __shared__ int lds[kBlock * 12];   // brute: triangle tile (12 floats x kBlock); packet: 4 wave stacks
+    __shared__ int lds[kBruteTile * 24];   // brute: TriPre tile; packet: 4 wave stacks
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < N;
     const int64_t ic = live ? i : (N - 1);
@@ -520,6 +590,31 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     if (inside_out) inside_out[i] = ins ? 1 : 0;
 }
 
+// Nearest-triangle search as its own launch: the packet traversal needs ~36 VGPRs, so it runs at
+// full occupancy (8 waves / SIMD hide the dependent scalar-load chain), which the register-heavier
+// attribute / gather code below would cap at 5.  Output: (slot, bits of d^2) per point, 8 B.
+template <bool LATTICE>
+__global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
+                                                    int2 *__restrict__ near)
+{
+    __shared__ int lds[(kBlock / 64) * kStackDepth];
+    int64_t i; bool live; f3 p;
+    if (LATTICE) {
+        int ix, iy, iz;
+        live = lattice_point(L, ix, iy, iz);
+        const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+        p = lattice_world(L.res, cx, cy, cz + L.z0);
+        i = ((int64_t)cz * L.res + cy) * L.res + cx;
+    } else {
+        i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+        live = i < N;
+        if (!live) i = N - 1;
+        p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    }
+    const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+    if (live) near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
+}
+
 // Feature assembly: one 16-float row per point,
 //   icon : [img(csel) | sdf | cmap r g b | norm x y z | 0.. | code]
 //   pamir: [img(C) | vol(Cv) | 0.. | code]      pifu: [img(C) | z | 0.. | code]
@@ -529,9 +624,9 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
                                                      const float *__restrict__ pts, int64_t N,
                                                      float sdf_clip, int cmap_local,
                                                      const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                                     float *__restrict__ X)
+                                                     const int2 *__restrict__ near, float *__restrict__ X)
 {
-    __shared__ int lds[(PRIOR == ICON_PRIOR_ICON) ? kBlock * 12 : 1];
+    __shared__ int lds[(PRIOR == ICON_PRIOR_ICON && BRUTE) ? kBruteTile * 24 : 1];
     int64_t i; bool live; f3 p;
     int64_t yz_row = 0;
     if (LATTICE) {
@@ -556,7 +651,8 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
         bool ins;
         if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
         else {
-            nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+            const int2 nn = near[i];                       // k_nearest ran on the same stream just before
+            nr.slot = nn.x; nr.d2 = __int_as_float(nn.y); nr.face = 0;
             ins = LATTICE ? inside_row(m, p, row_count, row_slots, yz_row) : inside_bins(m, p);
         }
         const SdfOut o = sdf_attrs(m, p, nr, ins);
@@ -590,6 +686,22 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
     }
     row[kCodeSlot] = __int_as_float((int)code);
     if (live) store_row(X, i, row);
+}
+
+// diagnostics: per-wavefront BVH work of the lattice traversal (DESIGN.md reports visited nodes / point)
+__global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMap L, unsigned long long *out /* [4] */)
+{
+    __shared__ int lds[(kBlock / 64) * kStackDepth];
+    int ix, iy, iz;
+    const bool live = lattice_point(L, ix, iy, iz);
+    const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+    const f3 p = lattice_world(L.res, cx, cy, cz + L.z0);
+    int nn = 0, nt = 0;
+    const Nearest nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], 1ull); atomicAdd(&out[1], (unsigned long long)nn); atomicAdd(&out[2], (unsigned long long)nt);
+    }
+    if (live && nr.slot < 0) atomicAdd(&out[3], 1ull);
 }
 
 // one thread per (y, z) row of the slab: triangles whose (y,z) projection covers the row
@@ -811,7 +923,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     delete w;
     return ICON_OK;
@@ -848,6 +960,8 @@ int ensure_work(icon_work *w, int64_t n_points)
     if (n_points > w->cap_points) {
         (void)hipFree(w->d_x); w->d_x = nullptr; w->cap_points = 0;
         ICON_HIP(hipMalloc((void **)&w->d_x, (size_t)n_points * kXRow * sizeof(float)));
+        (void)hipFree(w->d_near); w->d_near = nullptr;
+        ICON_HIP(hipMalloc((void **)&w->d_near, (size_t)n_points * 8));
         w->cap_points = n_points;
     }
     const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
@@ -915,7 +1029,12 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     const MeshDev md = mesh ? mesh->dev : MeshDev{};
     const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
     const bool brute = (search == ICON_SEARCH_BRUTE);
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, d_x)
+    int2 *near = nullptr;
+    if (prior == ICON_PRIOR_ICON && !brute) {
+        near = reinterpret_cast<int2 *>(work->d_near);
+        hipLaunchKernelGGL((k_nearest<LATTICE>), grid, block, 0, st, md, cal, L, d_points, N, near);
+    }
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, near, d_x)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
@@ -1009,6 +1128,8 @@ static int lattice_map(int res, int z0, int z1, LatticeMap *L)
     ICON_ARG(z0 >= 0 && z1 > z0 && z1 <= res, "bad z range");
     L->res = res; L->z0 = z0; L->nz = z1 - z0;
     L->tx = (res + 15) / 16; L->ty = (res + 3) / 4; L->tz = (L->nz + 3) / 4;
+    const char *e = getenv("ICON_AMD_XCD_REMAP");
+    L->remap = e ? atoi(e) : 0;   // interleaved is balanced; contiguous XCD bands measured 1.6x slower
     return ICON_OK;
 }
 
@@ -1068,6 +1189,24 @@ extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int
     const int rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
     mark(work, 3, st);
     return rc;
+}
+
+extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3])
+{
+    ICON_ARG(mesh && out, "icon_debug_traversal_stats: null argument");
+    LatticeMap L;
+    int rc = lattice_map(res, z0, z1, &L);
+    if (rc) return rc;
+    unsigned long long *d = nullptr;
+    ICON_HIP(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
+    ICON_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(k_traversal_stats, dim3((unsigned)(L.tx * L.ty * L.tz)), dim3(kBlock), 0, 0, mesh->dev, L, d);
+    unsigned long long h[4];
+    hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(ICON_ERR_HIP, std::string("traversal stats: ") + hipGetErrorString(e));
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    return ICON_OK;
 }
 
 extern "C" int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,

@@ -87,9 +87,16 @@ class MeshHandle(_Handle):
         return out
 
     def stats(self) -> dict:
-        arr = (C.c_int64 * 4)()
+        arr = (C.c_int64 * 6)()
         check(_lib.lib().icon_mesh_stats(self.h, arr), "icon_mesh_stats")
-        return dict(nodes=arr[0], depth=arr[1], bin_entries=arr[2], max_bin=arr[3])
+        return dict(nodes=arr[0], depth=arr[1], bin_entries=arr[2], max_bin=arr[3], leaves=arr[4], slots=arr[5])
+
+    def traversal_stats(self, res: int, z0: int = 0, z1: Optional[int] = None) -> dict:
+        arr = (C.c_uint64 * 3)()
+        check(_lib.lib().icon_debug_traversal_stats(self.h, C.c_int(res), C.c_int(z0), C.c_int(res if z1 is None else z1), arr),
+              "icon_debug_traversal_stats")
+        return dict(waves=arr[0], nodes=arr[1], tris=arr[2], nodes_per_wave=arr[1] / max(arr[0], 1),
+                    tris_per_wave=arr[2] / max(arr[0], 1))
 
     def sdf_query(self, points: torch.Tensor, search: str = "bvh"):
         """cal_sdf_batch (lib/dataset/mesh_util.py:357-396) for points [N,3] ->
@@ -182,7 +189,7 @@ class MlpHandle(_Handle):
                                          bn_ptrs[2], bn_ptrs[3], C.c_float(bn_eps), _stream(), C.byref(self.h)),
               "icon_mlp_create")
 
-    def forward(self, x: torch.Tensor, precision: str = "f32") -> torch.Tensor:
+    def forward(self, x: torch.Tensor, precision: str = "f16x3") -> torch.Tensor:
         """MLP.forward on point-major rows x [N,16] (slots >= c0 ignored) -> [N]"""
         x = _dev_f32(x, "x")
         if x.dim() != 2 or x.shape[1] != 16:
@@ -227,7 +234,7 @@ class IconQueryEngine:
 
     def __init__(self, prior_type: str = "icon", sdf_clip: float = 0.05,
                  smpl_feats: Sequence[str] = ("sdf", "norm", "vis", "cmap"),
-                 cmap_mode: str = "reference", search: str = "bvh", precision: str = "f32",
+                 cmap_mode: str = "reference", search: str = "bvh", precision: str = "f16x3",
                  res_layers: Sequence[int] = (2, 3, 4)):
         if prior_type not in _lib.PRIOR:
             raise IconAmdError(f"unknown prior_type {prior_type!r}")

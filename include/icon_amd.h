@@ -75,8 +75,9 @@ int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *d_faces, in
 int icon_mesh_destroy(icon_mesh_t *mesh);
 /* copy the area-weighted unit vertex normals [V,3] to a device buffer (for tests) */
 int icon_mesh_vertex_normals(const icon_mesh_t *mesh, float *d_out, void *stream);
-/* BVH statistics: out[0]=nodes, out[1]=max depth, out[2]=ray-bin entries, out[3]=max bin length */
-int icon_mesh_stats(const icon_mesh_t *mesh, int64_t out[4]);
+/* BVH statistics: out[0]=nodes, out[1]=max depth, out[2]=ray-bin entries, out[3]=max bin length,
+ * out[4]=leaves, out[5]=triangle slots (4 per leaf, short leaves padded) */
+int icon_mesh_stats(const icon_mesh_t *mesh, int64_t out[6]);
 
 /* ---------------------------------------------------------------------------------------------
  * cal_sdf_batch, per-point half (lib/dataset/mesh_util.py:374-396):
@@ -186,6 +187,11 @@ int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
 int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
                           const int8_t *d_signs_global, int64_t k_total, int64_t rank_offset,
                           float *d_occ, int precision, icon_work_t *work, void *stream);
+
+/* Diagnostics (synchronises): BVH work of the lattice traversal over planes [z0,z1):
+ * out[0] = wavefronts (4x4x4 point blocks), out[1] = BVH nodes visited, out[2] = triangles tested,
+ * both summed over wavefronts (every visit serves all 64 lanes of the wavefront). */
+int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3]);
 
 /* ---------------------------------------------------------------------------------------------
  * Seg3dLossless.export_mesh (lib/common/seg3d_lossless.py:583-604): marching cubes at 0.5 on

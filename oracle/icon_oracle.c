@@ -107,62 +107,84 @@ void orc_vertex_normals(const float *verts, int64_t V, const int64_t *faces, int
 }
 
 /* ------------------------------------------------------------------------------------------
- * S2  exact point-triangle squared distance (Voronoi-region form: vertex / edge / interior),
- *     one reciprocal, closest point c = a + ab*v + ac*w, result |p-c|^2.
+ * S2  exact point-triangle squared distance, "face or nearest edge" form.
+ *     Per-triangle constants (orc_tri_setup, evaluated once per triangle on the CPU in both the
+ *     checker and the product's mesh preparation): edge vectors, reciprocal squared edge lengths,
+ *     the Gram matrix of (ab, ac) and the reciprocal of its determinant; zero-length / zero-area
+ *     cases get a reciprocal of 0 (the formulas below then collapse to a vertex / an edge).
+ *     Per point: barycentrics of the plane projection (s, t); if 0 <= s, 0 <= t, s + t <= 1 the
+ *     result is |p - (a + s ab + t ac)|^2, otherwise the minimum over the three edge segments
+ *     of |p - (origin + clamp(t) * edge)|^2.  No division, no data-dependent branches: on the GPU
+ *     this is ~70 VALU operations (sub / mul / fma / max / min / select), all exactly rounded.
  * ---------------------------------------------------------------------------------------- */
-float orc_point_tri_dist2(const float *pp, const float *pa, const float *pb, const float *pc)
+typedef struct {
+    v3 a, b, ab, ac, bc;
+    float i00, i11, ibc;      /* 1/|ab|^2, 1/|ac|^2, 1/|bc|^2 (0 if the edge has zero length) */
+    float a00, a01, a11, inn; /* ab.ab, ab.ac, ac.ac, 1/(a00*a11 - a01^2) (0 if not positive)  */
+} orc_tri;
+
+void orc_tri_setup(const float *pa, const float *pb, const float *pc, orc_tri *t)
 {
-    const v3 p = ld3(pp, 0), a = ld3(pa, 0), b = ld3(pb, 0), c = ld3(pc, 0);
-    const v3 ab = v3_sub(b, a), ac = v3_sub(c, a);
-    const v3 ap = v3_sub(p, a), bp = v3_sub(p, b), cp = v3_sub(p, c);
-    const float d1 = v3_dot(ab, ap), d2 = v3_dot(ac, ap);
-    const float d3 = v3_dot(ab, bp), d4 = v3_dot(ac, bp);
-    const float d5 = v3_dot(ab, cp), d6 = v3_dot(ac, cp);
-    const float va = fmaf(d3, d6, -(d5 * d4));
-    const float vb = fmaf(d5, d2, -(d1 * d6));
-    const float vc = fmaf(d1, d4, -(d3 * d2));
-    float v, w;
-    if (d1 <= 0.0f && d2 <= 0.0f) { v = 0.0f; w = 0.0f; }                       /* vertex a */
-    else if (d3 >= 0.0f && d4 <= d3) { v = 1.0f; w = 0.0f; }                     /* vertex b */
-    else if (vc <= 0.0f && d1 >= 0.0f && d3 <= 0.0f) {                           /* edge ab  */
-        const float inv = 1.0f / (d1 - d3);
-        v = d1 * inv; w = 0.0f;
-    }
-    else if (d6 >= 0.0f && d5 <= d6) { v = 0.0f; w = 1.0f; }                     /* vertex c */
-    else if (vb <= 0.0f && d2 >= 0.0f && d6 <= 0.0f) {                           /* edge ac  */
-        const float inv = 1.0f / (d2 - d6);
-        v = 0.0f; w = d2 * inv;
-    }
-    else if (va <= 0.0f && (d4 - d3) >= 0.0f && (d5 - d6) >= 0.0f) {             /* edge bc  */
-        const float n = d4 - d3;
-        const float inv = 1.0f / (n + (d5 - d6));
-        w = n * inv; v = 1.0f - w;
-    }
-    else {                                                                       /* interior */
-        const float inv = 1.0f / ((va + vb) + vc);
-        v = vb * inv; w = vc * inv;
-    }
-    v3 q;
-    q.x = fmaf(ac.x, w, fmaf(ab.x, v, a.x));
-    q.y = fmaf(ac.y, w, fmaf(ab.y, v, a.y));
-    q.z = fmaf(ac.z, w, fmaf(ab.z, v, a.z));
+    t->a = ld3(pa, 0); t->b = ld3(pb, 0);
+    const v3 c = ld3(pc, 0);
+    t->ab = v3_sub(t->b, t->a); t->ac = v3_sub(c, t->a); t->bc = v3_sub(c, t->b);
+    t->a00 = v3_dot(t->ab, t->ab); t->a01 = v3_dot(t->ab, t->ac); t->a11 = v3_dot(t->ac, t->ac);
+    const float b11 = v3_dot(t->bc, t->bc);
+    t->i00 = (t->a00 > 0.0f) ? 1.0f / t->a00 : 0.0f;
+    t->i11 = (t->a11 > 0.0f) ? 1.0f / t->a11 : 0.0f;
+    t->ibc = (b11 > 0.0f) ? 1.0f / b11 : 0.0f;
+    const float nn = fmaf(t->a00, t->a11, -(t->a01 * t->a01));
+    t->inn = (nn > 0.0f) ? 1.0f / nn : 0.0f;
+}
+
+static inline float seg_dist2(v3 p, v3 o, v3 e, float dot_e_po, float inv_len2)
+{
+    const float t = fminf(fmaxf(dot_e_po * inv_len2, 0.0f), 1.0f);
+    v3 q; q.x = fmaf(e.x, t, o.x); q.y = fmaf(e.y, t, o.y); q.z = fmaf(e.z, t, o.z);
     const v3 d = v3_sub(p, q);
     return v3_dot(d, d);
+}
+
+float orc_tri_dist2(const float *pp, const orc_tri *t)
+{
+    const v3 p = ld3(pp, 0);
+    const v3 ap = v3_sub(p, t->a), bp = v3_sub(p, t->b);
+    const float d1 = v3_dot(t->ab, ap), d2 = v3_dot(t->ac, ap), d3 = v3_dot(t->bc, bp);
+    const float s = fmaf(t->a11, d1, -(t->a01 * d2)) * t->inn;
+    const float u = fmaf(t->a00, d2, -(t->a01 * d1)) * t->inn;
+    const int inside = (s >= 0.0f) & (u >= 0.0f) & (s + u <= 1.0f);
+    v3 q;
+    q.x = fmaf(t->ac.x, u, fmaf(t->ab.x, s, t->a.x));
+    q.y = fmaf(t->ac.y, u, fmaf(t->ab.y, s, t->a.y));
+    q.z = fmaf(t->ac.z, u, fmaf(t->ab.z, s, t->a.z));
+    const v3 df = v3_sub(p, q);
+    const float d_face = v3_dot(df, df);
+    const float e0 = seg_dist2(p, t->a, t->ab, d1, t->i00);
+    const float e1 = seg_dist2(p, t->a, t->ac, d2, t->i11);
+    const float e2 = seg_dist2(p, t->b, t->bc, d3, t->ibc);
+    const float d_edge = fminf(fminf(e0, e1), e2);
+    return inside ? d_face : d_edge;
+}
+
+float orc_point_tri_dist2(const float *pp, const float *pa, const float *pb, const float *pc)
+{
+    orc_tri t;
+    orc_tri_setup(pa, pb, pc, &t);
+    return orc_tri_dist2(pp, &t);
 }
 
 /* S3  argmin over faces, linear scan, strict '<' => lowest index wins exact ties; NaN never wins */
 void orc_nearest_brute(const float *verts, const int64_t *faces, int64_t F,
                        const float *pts, int64_t N, float *out_d2, int64_t *out_idx)
 {
-    float *tri = (float *)malloc(sizeof(float) * 9 * (size_t)F);
+    orc_tri *tri = (orc_tri *)malloc(sizeof(orc_tri) * (size_t)F);
     for (int64_t f = 0; f < F; ++f)
-        for (int k = 0; k < 3; ++k)
-            memcpy(tri + 9 * f + 3 * k, verts + 3 * faces[3 * f + k], 3 * sizeof(float));
+        orc_tri_setup(verts + 3 * faces[3 * f], verts + 3 * faces[3 * f + 1], verts + 3 * faces[3 * f + 2], tri + f);
 #pragma omp parallel for schedule(dynamic, 256)
     for (int64_t i = 0; i < N; ++i) {
         float best = INFINITY; int64_t bi = 0;
         for (int64_t f = 0; f < F; ++f) {
-            const float d = orc_point_tri_dist2(pts + 3 * i, tri + 9 * f, tri + 9 * f + 3, tri + 9 * f + 6);
+            const float d = orc_tri_dist2(pts + 3 * i, tri + f);
             if (d < best) { best = d; bi = f; }
         }
         out_d2[i] = best; out_idx[i] = bi;
