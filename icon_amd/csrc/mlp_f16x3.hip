@@ -37,13 +37,16 @@ constexpr int kF16Block = 512;                 // 8 waves x 32 points
 constexpr int kF16Pts = (kF16Block / 64) * 32; // 256 points per workgroup
 constexpr int kBufBytes = 40 * 1024;
 constexpr int kSideFloats = 512 + 256 + 128 + 144;   // b0 | b1 | b2 | w3, staged once per workgroup
-constexpr int kSideOff = 2 * kBufBytes;
-constexpr int kLdsBytes = kSideOff + 4352;           // 80 KiB operand double buffer + 4.25 KiB side arrays
+constexpr int kW0Off = 2 * kBufBytes;                // layer-0 operands, resident for the whole workgroup
+constexpr int kW0Bytes = 32 * 1024;
+constexpr int kSideOff = kW0Off + kW0Bytes;
+constexpr int kLdsBytes = kSideOff + 4352;           // 80 KiB double buffer + 32 KiB W0 + 4.25 KiB side arrays
 
-// chunk k: size in KiB and offset in KiB inside the packed image
-__host__ __device__ constexpr int chunk_units(int k) { return k < 16 ? 34 : (k < 19 ? 32 : 40); }
-__host__ __device__ constexpr int chunk_offset(int k) { return k < 16 ? 34 * k : 544 + 32 * (k - 16); }
-constexpr size_t kImageBytes = (size_t)(544 + 3 * 32 + 40) * 1024;   // 680 KiB
+// packed image: [W0: 32 KiB][layer-1 chunks 0..15: 32 KiB each][layer-2 chunks 16..18: 32 KiB, 19: 40 KiB]
+// chunk k: size in KiB and offset in KiB inside the image
+__host__ __device__ constexpr int chunk_units(int k) { return k < 19 ? 32 : 40; }
+__host__ __device__ constexpr int chunk_offset(int k) { return 32 + 32 * k; }
+constexpr size_t kImageBytes = (size_t)(32 + 19 * 32 + 40) * 1024;   // 680 KiB
 
 struct MlpF16Dev {
     const char *image;          // packed f16 hi/lo A operands, chunked
@@ -94,12 +97,14 @@ __device__ __forceinline__ half8 lds_op(const char *buf, int slot, int lane)
 }
 
 // every wave DMAs 1 KiB pieces round-robin: global [piece][lane][16 B] -> LDS, same order
-__device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k, int wave, int lane)
+__device__ __forceinline__ void issue_units(const char *src, char *buf, int units, int wave, int lane)
 {
-    const char *src = image + (size_t)chunk_offset(k) * 1024;
-    const int units = chunk_units(k);
     for (int u = wave; u < units; u += kF16Block / 64)
         __builtin_amdgcn_global_load_lds((gvoid_t *)(src + u * 1024 + lane * 16), (lvoid_t *)(buf + u * 1024), 16, 0, 0);
+}
+__device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k, int wave, int lane)
+{
+    issue_units(image + (size_t)chunk_offset(k) * 1024, buf, chunk_units(k), wave, lane);
 }
 
 // 3-term product group for 4 output tiles sharing one B operand pair
@@ -114,55 +119,109 @@ __device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k,
 // not drain the DMA queue (s_waitcnt vmcnt(0)) in front of every LDS read - the DMA for chunk k+1
 // stays in flight for the whole multiplication of chunk k and is only waited for at the barrier.
 
-// layers 0 + 1, chunk c (32 hidden channels)
-__device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__restrict__ nxt, const float *__restrict__ sb0c,
-                                          const char *image, int k_next, f32x16 (&acc1)[8], half8 xhi, half8 xlo,
-                                          float inv0, int h, int lane, int wave)
+// 3-term product group for 2 output tiles sharing one B operand pair
+#define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
+    ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
+    ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); \
+    ACC[M0] = MFMA16(AL[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]);
+
+// layer 0, hidden tile c (32 channels): 3 MFMAs from the resident W0 region
+__device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const float *__restrict__ sb0, int c, half8 xhi, half8 xlo,
+                                          int h, int lane)
 {
-    issue_chunk(image, nxt, k_next, wave, lane);
-    f32x16 h0 = ld16(sb0c + h * 16);
-    {
-        const half8 a_hi = lds_op(L, 32, lane), a_lo = lds_op(L, 33, lane);
-        h0 = MFMA16(a_hi, xhi, h0); h0 = MFMA16(a_hi, xlo, h0); h0 = MFMA16(a_lo, xhi, h0);
-    }
-    half8 bh[2], bl[2];
-    activate_split(h0, inv0, bh, bl);
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int mg = 0; mg < 2; ++mg) {
-            half8 ah[4], al[4];
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int slot = ((u * 8 + mg * 4 + i4) * 2);
-                ah[i4] = lds_op(L, slot, lane); al[i4] = lds_op(L, slot + 1, lane);
-            }
-            if (mg == 0) { TRIPLE4(acc1, 0, ah, al, bh[u], bl[u]) } else { TRIPLE4(acc1, 4, ah, al, bh[u], bl[u]) }
-        }
-    }
+    f32x16 h0 = ld16(sb0 + (c * 2 + h) * 16);
+    const half8 a_hi = lds_op(W0, 2 * c, lane), a_lo = lds_op(W0, 2 * c + 1, lane);
+    h0 = MFMA16(a_hi, xhi, h0); h0 = MFMA16(a_hi, xlo, h0); h0 = MFMA16(a_lo, xhi, h0);
+    return h0;
 }
 
-// layer 2, chunk 16+Q: hidden tiles 2Q, 2Q+1 (+ the raw-input k-step in the last chunk)
+// one eighth of the activation step of a finished layer-0 tile: values 2k, 2k+1 -> LeakyReLU ->
+// hi/lo halves -> pair (k&3) of the next B operand (u = k>>2)
+__device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, half8 (&nh)[2], half8 (&nl)[2])
+{
+    const float x0 = acc[2 * k] * inv, x1 = acc[2 * k + 1] * inv;
+    const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
+    fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
+    fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(v0 - (float)hh[0], v1 - (float)hh[1]);
+    // the (empty) volatile asm is ordered against the surrounding sched_barriers, which keeps this
+    // VALU work in the MFMA group it was written next to instead of being sunk to the end of the chunk
+    int hb = __builtin_bit_cast(int, hh), lb = __builtin_bit_cast(int, ll);
+    asm volatile("" : "+v"(hb), "+v"(lb));
+    hh = __builtin_bit_cast(fp16x2, hb); ll = __builtin_bit_cast(fp16x2, lb);
+    const int u = k >> 2, q = k & 3;
+    nh[u][2 * q] = (_Float16)hh[0]; nh[u][2 * q + 1] = (_Float16)hh[1];
+    nl[u][2 * q] = (_Float16)ll[0]; nl[u][2 * q + 1] = (_Float16)ll[1];
+}
+
+// A operands of MFMA group g of a layer-1 chunk: output tiles 2*(g&3), +1 for k-step u = g>>2
+__device__ __forceinline__ void load_group(const char *__restrict__ L, int g, int lane, half8 (&a)[4])
+{
+    const int slot = ((g >> 2) * 8 + (g & 3) * 2) * 2;
+    a[0] = lds_op(L, slot, lane); a[1] = lds_op(L, slot + 2, lane);        // hi of tile 0, 1
+    a[2] = lds_op(L, slot + 1, lane); a[3] = lds_op(L, slot + 3, lane);    // lo of tile 0, 1
+}
+
+// layer 1, chunk c (K = hidden channels 32c..32c+31, B operands bh/bl prepared one iteration
+// earlier) SOFTWARE-PIPELINED with layer 0 of chunk c+1: its three MFMAs are issued first; its
+// LeakyReLU + hi/lo split (pure VALU, 8 parts) is slotted between the eight 6-MFMA groups of this
+// chunk, and the LDS reads of group g+1 are issued ahead of the MFMAs of group g.  sched_barrier
+// pins that interleave so the matrix pipe and the VALU run side by side instead of alternating.
+__device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__restrict__ nxt, const char *__restrict__ W0,
+                                          const float *__restrict__ sb0, const char *image, int c, f32x16 (&acc1)[8],
+                                          half8 xhi, half8 xlo, float inv0, int h, int lane, int wave,
+                                          half8 (&bh)[2], half8 (&bl)[2])
+{
+    issue_chunk(image, nxt, c + 1, wave, lane);
+    const f32x16 h0n = l0_tile(W0, sb0, min(c + 1, 15), xhi, xlo, h, lane);   // c == 15: harmless repeat
+    half8 nh[2], nl[2];
+    half8 a[2][4];
+    load_group(L, 0, lane, a[0]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) load_group(L, g + 1, lane, a[(g + 1) & 1]);
+        const int u = g >> 2, m0 = (g & 3) * 2;
+        const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
+        TRIPLE2(acc1, m0, ah, al, bh[u], bl[u])
+        if (g >= 1) act_part(h0n, g - 1, inv0, nh, nl);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    act_part(h0n, 7, inv0, nh, nl);
+    bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
+}
+
+// layer 2, chunk 16+Q: hidden tiles 2Q, 2Q+1 (+ the raw-input k-step in the last chunk).
+// Same pipelining as layer 1: while the 24 MFMAs of hidden tile m run, the activation + split of
+// tile m+1 (the next B operand) is slotted between the four 6-MFMA groups, two parts per group.
 template <int Q>
 __device__ __forceinline__ void l2_chunk(const char *__restrict__ L, char *__restrict__ nxt, const char *image,
                                          f32x16 (&acc1)[8], f32x16 (&acc2)[4], half8 xhi, half8 xlo, float inv1,
-                                         int lane, int wave)
+                                         int lane, int wave, half8 (&bh)[2], half8 (&bl)[2])
 {
     if (Q < 3) issue_chunk(image, nxt, 17 + Q, wave, lane);
 #pragma unroll
     for (int mm = 0; mm < 2; ++mm) {
-        half8 bh[2], bl[2];
-        activate_split(acc1[2 * Q + mm], inv1, bh, bl);
+        constexpr int kLast = 7;
+        const int m = 2 * Q + mm;
+        half8 nh[2], nl[2];
+        half8 a[2][4];
+        auto load2 = [&](int g, half8 (&dst)[4]) {          // group g: k-step u = g>>1, output tiles 2*(g&1), +1
+            const int slot = (((mm * 2 + (g >> 1)) * 4 + (g & 1) * 2) * 2);
+            dst[0] = lds_op(L, slot, lane); dst[1] = lds_op(L, slot + 2, lane);
+            dst[2] = lds_op(L, slot + 1, lane); dst[3] = lds_op(L, slot + 3, lane);
+        };
+        load2(0, a[0]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            half8 ah[4], al[4];
-#pragma unroll
-            for (int i4 = 0; i4 < 4; ++i4) {
-                const int slot = (((mm * 2 + u) * 4 + i4) * 2);
-                ah[i4] = lds_op(L, slot, lane); al[i4] = lds_op(L, slot + 1, lane);
-            }
-            TRIPLE4(acc2, 0, ah, al, bh[u], bl[u])
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) load2(g + 1, a[(g + 1) & 1]);
+            const int u = g >> 1, m0 = (g & 1) * 2;
+            const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
+            TRIPLE2(acc2, m0, ah, al, bh[u], bl[u])
+            if (m < kLast) { act_part(acc1[m < kLast ? m + 1 : m], 2 * g, inv1, nh, nl); act_part(acc1[m < kLast ? m + 1 : m], 2 * g + 1, inv1, nh, nl); }
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (m < kLast) { bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1]; }
     }
     if (Q == 3) {
         half8 ah[4], al[4];
@@ -183,6 +242,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
 
     // side arrays -> LDS once: no ordinary global load may sit between an LDS-DMA and its consumer
     // (vmcnt retires in order, so waiting for such a load would drain the DMA queue as well)
+    issue_units(w.image, smem + kW0Off, kW0Bytes / 1024, wave, lane);     // resident layer-0 operands
     float *side = reinterpret_cast<float *>(smem + kSideOff);
     for (int i = threadIdx.x; i < kSideFloats; i += kF16Block) side[i] = w.side[i];
     const float *sb0 = side, *sb1 = side + 512, *sb2 = side + 768, *sw3 = side + 896;
@@ -210,9 +270,11 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     for (int m = 0; m < 8; ++m) acc1[m] = ld16(sb1 + (m * 2 + h) * 16);
 
     // ---- layers 0 + 1: one chunk = 32 hidden channels ------------------------------------------
+    half8 bh[2], bl[2];
+    activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
     for (int c = 0; c < 16; ++c) {
-        l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, sb0 + c * 32, w.image, c + 1, acc1, xhi, xlo,
-                  w.inv0, h, lane, wave);
+        l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
+                  w.inv0, h, lane, wave, bh, bl);
         __syncthreads();   // all waves done with this buffer AND the next chunk has landed
     }
 
@@ -220,13 +282,14 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     f32x16 acc2[4];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
-    l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave);
+    activate_split(acc1[0], w.inv1, bh, bl);
+    l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
     __syncthreads();
-    l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave);
+    l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
     __syncthreads();
-    l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave);
+    l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
     __syncthreads();
-    l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave);
+    l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
 
     // ---- layer 3 on the VALU (f32) ----------------------------------------------------------------
     const float *w3 = sw3 + h * 72;
@@ -304,7 +367,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
         const float ws = wv * scale;
         const uint16_t hi = f32_to_f16_rtn(ws);
         const uint16_t lo = f32_to_f16_rtn(ws - f16_to_f32(hi));
-        const size_t base = ((size_t)chunk_offset(chunk) + slot) * 512;   // in halves
+        const size_t base = ((size_t)(chunk < 0 ? 0 : chunk_offset(chunk)) + slot) * 512;   // in halves; chunk -1 = W0 region
         img[base + (size_t)lane * 8 + e] = hi;
         img[base + 512 + (size_t)lane * 8 + e] = lo;
     };
@@ -315,7 +378,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
             // layers 0+1, chunk c
             for (int c = 0; c < 16; ++c) {
                 const int slot0 = 8 * g + e;
-                put(c, 32, lane, e, slot0 < c0 ? W[0][(size_t)(32 * c + i) * c0 + slot0] : 0.f, s0);
+                put(-1, 2 * c, lane, e, slot0 < c0 ? W[0][(size_t)(32 * c + i) * c0 + slot0] : 0.f, s0);
                 for (int u = 0; u < 2; ++u)
                     for (int mm = 0; mm < 8; ++mm)
                         put(c, (u * 8 + mm) * 2, lane, e, W[1][(size_t)(32 * mm + i) * 512 + 32 * c + rho(8 * u + e, g)], s1);

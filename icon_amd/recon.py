@@ -136,6 +136,18 @@ class DenseReconEngine(nn.Module):
             occ = self._forward_sharded(be, im_feat, res, dist, world, rank)
         return self._none_if_empty(occ)
 
+    @staticmethod
+    def _all_gather(dist, t, world, group):
+        """all_gather of one equal-shaped tensor per rank -> list.  RCCL ('nccl') moves device tensors
+        directly; a gloo group (CPU tests, or debugging several ranks on one GPU) stages through the host."""
+        if t.is_cuda and dist.get_backend(group) == "gloo":
+            parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
+            dist.all_gather(parts, t.cpu(), group=group)
+            return [p.to(t.device) for p in parts]
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        return parts
+
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
         z0, z1, per = slab_bounds(res, world, rank)
@@ -148,14 +160,11 @@ class DenseReconEngine(nn.Module):
             else:
                 signs = torch.empty(0, dtype=torch.int8, device=dev)
                 count = torch.zeros(1, dtype=torch.int64, device=dev)
-            counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-            dist.all_gather(counts, count, group=g)
-            counts = [int(c.item()) for c in counts]
+            counts = [int(c.item()) for c in self._all_gather(dist, count, world, g)]
             kmax = max(max(counts), 1)
             mine = torch.zeros(kmax, dtype=torch.int8, device=dev)
             mine[:counts[rank]] = signs[:counts[rank]]
-            gathered = [torch.empty(kmax, dtype=torch.int8, device=dev) for _ in range(world)]
-            dist.all_gather(gathered, mine, group=g)
+            gathered = self._all_gather(dist, mine, world, g)
             signs_global = torch.cat([t[:c] for t, c in zip(gathered, counts)]) if sum(counts) else mine[:0]
             if z1 > z0:
                 be.slab_finish(res, z0, z1, signs_global.contiguous(), sum(counts), sum(counts[:rank]),
@@ -163,8 +172,7 @@ class DenseReconEngine(nn.Module):
             self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world)
         elif z1 > z0:
             be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
-        parts = [torch.empty_like(slab) for _ in range(world)]
-        dist.all_gather(parts, slab, group=g)
+        parts = self._all_gather(dist, slab, world, g)
         return torch.cat(parts, 0)[:res].contiguous()
 
     def _forward_generic(self, **kwargs):

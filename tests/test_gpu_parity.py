@@ -373,3 +373,43 @@ def test_dense_recon_engine_api(body):
     sd["filters.3.bias"] -= 10.0
     eng.set_regressor(sd)
     assert recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None) is None
+
+
+def _shard_worker(rank, world, port, cmap_mode, q):
+    import os, sys
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    from types import SimpleNamespace
+    from icon_amd.engine import query_func
+    from icon_amd.recon import DenseReconEngine
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        body = assets("body")
+        eng = make_engine(body, cmap_mode=cmap_mode)
+        recon = DenseReconEngine(query_func=query_func, resolutions=[33, 65], align_corners=True).to(dev())
+        occ = recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+        q.put((rank, occ.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+def test_zslab_sharding_two_ranks_one_gpu(body, cmap_mode):
+    """the real sharded path (HIP kernels + sign-list exchange + slab all_gather), two ranks on this
+    one GPU over a gloo group: every rank must end up with the single-process volume, bit for bit"""
+    import socket
+    import torch.multiprocessing as mp
+    single = make_engine(body, cmap_mode=cmap_mode).eval_slab(T(body.features), 65, 0, 65).cpu().numpy()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_shard_worker, args=(r, 2, port, cmap_mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, occ in res:
+        assert np.array_equal(occ, single), rank
