@@ -165,6 +165,7 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
 struct icon_work {
     float *d_x = nullptr;                 // [cap_points][16] MLP input rows
     void *d_near = nullptr;               // [cap_points] (slot, d^2 bits) from k_nearest
+    uint8_t *d_code8 = nullptr;           // [cap_points] byte copy of each row's code word
     int64_t cap_points = 0;
     int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
     int64_t *d_block_offsets = nullptr;   // exclusive prefix of the above

@@ -624,7 +624,8 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
                                                      const float *__restrict__ pts, int64_t N,
                                                      float sdf_clip, int cmap_local,
                                                      const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                                     const int2 *__restrict__ near, float *__restrict__ X)
+                                                     const int2 *__restrict__ near, float *__restrict__ X,
+                                                     uint8_t *__restrict__ code8)
 {
     __shared__ int lds[(PRIOR == ICON_PRIOR_ICON && BRUTE) ? kBruteTile * 24 : 1];
     int64_t i; bool live; f3 p;
@@ -685,7 +686,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
         }
     }
     row[kCodeSlot] = __int_as_float((int)code);
-    if (live) store_row(X, i, row);
+    if (live) { store_row(X, i, row); code8[i] = (uint8_t)code; }   // byte copy of the code word: the outlier passes stream 1 B/pt
 }
 
 // diagnostics: per-wavefront BVH work of the lattice traversal (DESIGN.md reports visited nodes / point)
@@ -741,11 +742,11 @@ __device__ __forceinline__ uint32_t row_code(const float *X, int64_t i)
     return (uint32_t)__float_as_int(X[i * kXRow + kCodeSlot]);
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_outlier_count(const float *__restrict__ X, int64_t N, int32_t *block_counts)
+__global__ __launch_bounds__(kScanBlock) void k_outlier_count(const uint8_t *__restrict__ code8, int64_t N, int32_t *block_counts)
 {
     __shared__ int wsum[kScanBlock / 64];
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
-    const bool o = (i < N) && (row_code(X, i) & kCodeOutlier);
+    const bool o = (i < N) && (code8[i] & kCodeOutlier);
     const unsigned long long b = __ballot(o);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
     __syncthreads();
@@ -791,25 +792,25 @@ __device__ __forceinline__ int64_t outlier_rank(bool o, const int64_t *block_off
     return block_offsets[blockIdx.x] + before;
 }
 
-__global__ __launch_bounds__(kScanBlock) void k_outlier_compact(const float *__restrict__ X, int64_t N,
+__global__ __launch_bounds__(kScanBlock) void k_outlier_compact(const uint8_t *__restrict__ code8, int64_t N,
                                                                 const int64_t *block_offsets, int8_t *signs)
 {
     __shared__ int wsum[kScanBlock / 64];
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
-    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const uint32_t code = (i < N) ? code8[i] : 0u;
     const bool o = code & kCodeOutlier;
     const int64_t r = outlier_rank(o, block_offsets, wsum);
     if (o) signs[r] = (int8_t)((int)((code >> kCodeSignShift) & 3u) - 1);
 }
 
 // cmap[j][k] = s[(3j + k) mod K]  with j = global outlier rank = rank_offset + local rank
-__global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict__ X, int64_t N, int cmap_slot,
+__global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict__ X, const uint8_t *__restrict__ code8, int64_t N, int cmap_slot,
                                                               const int64_t *block_offsets, const int8_t *signs_global,
                                                               int64_t k_total, int64_t rank_offset)
 {
     __shared__ int wsum[kScanBlock / 64];
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
-    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const uint32_t code = (i < N) ? code8[i] : 0u;
     const bool o = code & kCodeOutlier;
     const int64_t j = rank_offset + outlier_rank(o, block_offsets, wsum);
     if (o) {
@@ -923,7 +924,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     delete w;
     return ICON_OK;
@@ -962,6 +963,8 @@ int ensure_work(icon_work *w, int64_t n_points)
         ICON_HIP(hipMalloc((void **)&w->d_x, (size_t)n_points * kXRow * sizeof(float)));
         (void)hipFree(w->d_near); w->d_near = nullptr;
         ICON_HIP(hipMalloc((void **)&w->d_near, (size_t)n_points * 8));
+        (void)hipFree(w->d_code8); w->d_code8 = nullptr;
+        ICON_HIP(hipMalloc((void **)&w->d_code8, (size_t)n_points));
         w->cap_points = n_points;
     }
     const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
@@ -1034,7 +1037,7 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
         near = reinterpret_cast<int2 *>(work->d_near);
         hipLaunchKernelGGL((k_nearest<LATTICE>), grid, block, 0, st, md, cal, L, d_points, N, near);
     }
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, near, d_x)
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, near, d_x, work->d_code8)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
@@ -1047,9 +1050,9 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
 int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
 {
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, w->d_block_counts);
+    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
     hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_block_offsets, w->d_total);
-    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, w->d_block_offsets, signs);
+    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
@@ -1058,14 +1061,14 @@ int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
 
 namespace icon {
 // device-side K: same as k_outlier_patch but K and the list come from this call's own scan
-__global__ __launch_bounds__(kScanBlock) void k_outlier_patch_self(float *__restrict__ X, int64_t N, int cmap_slot,
+__global__ __launch_bounds__(kScanBlock) void k_outlier_patch_self(float *__restrict__ X, const uint8_t *__restrict__ code8, int64_t N, int cmap_slot,
                                                                    const int64_t *block_offsets, const int8_t *signs,
                                                                    const int64_t *k_total_dev)
 {
     __shared__ int wsum[kScanBlock / 64];
     const int64_t K = *k_total_dev;
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
-    const uint32_t code = (i < N) ? row_code(X, i) : 0u;
+    const uint32_t code = (i < N) ? code8[i] : 0u;
     const bool o = code & kCodeOutlier;
     const int64_t j = outlier_rank(o, block_offsets, wsum);
     if (o) {
@@ -1085,7 +1088,7 @@ namespace {
 int patch_only(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
 {
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(icon::k_outlier_patch_self, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, N, cmap_slot,
+    hipLaunchKernelGGL(icon::k_outlier_patch_self, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, w->d_code8, N, cmap_slot,
                        w->d_block_offsets, w->d_signs, w->d_total);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
@@ -1180,7 +1183,7 @@ extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int
     if (work->slab_needs_patch && k_total > 0) {
         ICON_ARG(d_signs_global != nullptr, "icon_grid_slab_finish: sign list is null");
         const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, N, work->slab_cmap_slot,
+        hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
                            work->d_block_offsets, d_signs_global, k_total, rank_offset);
         ICON_HIP(hipGetLastError());
     }

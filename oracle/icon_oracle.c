@@ -137,9 +137,15 @@ void orc_tri_setup(const float *pa, const float *pb, const float *pc, orc_tri *t
     t->inn = (nn > 0.0f) ? 1.0f / nn : 0.0f;
 }
 
+/* max / min as plain comparisons (libm's fmaxf/fminf are out-of-line calls without fast-math).
+ * For the finite operands that occur here they return exactly what fmaxf/fminf and the GPU's
+ * v_max_f32 / v_min_f32 return. */
+static inline float max_f(float a, float b) { return (a > b) ? a : b; }
+static inline float min_f(float a, float b) { return (b < a) ? b : a; }
+
 static inline float seg_dist2(v3 p, v3 o, v3 e, float dot_e_po, float inv_len2)
 {
-    const float t = fminf(fmaxf(dot_e_po * inv_len2, 0.0f), 1.0f);
+    const float t = min_f(max_f(dot_e_po * inv_len2, 0.0f), 1.0f);
     v3 q; q.x = fmaf(e.x, t, o.x); q.y = fmaf(e.y, t, o.y); q.z = fmaf(e.z, t, o.z);
     const v3 d = v3_sub(p, q);
     return v3_dot(d, d);
@@ -162,7 +168,7 @@ float orc_tri_dist2(const float *pp, const orc_tri *t)
     const float e0 = seg_dist2(p, t->a, t->ab, d1, t->i00);
     const float e1 = seg_dist2(p, t->a, t->ac, d2, t->i11);
     const float e2 = seg_dist2(p, t->b, t->bc, d3, t->ibc);
-    const float d_edge = fminf(fminf(e0, e1), e2);
+    const float d_edge = min_f(min_f(e0, e1), e2);
     return inside ? d_face : d_edge;
 }
 
@@ -180,14 +186,27 @@ void orc_nearest_brute(const float *verts, const int64_t *faces, int64_t F,
     orc_tri *tri = (orc_tri *)malloc(sizeof(orc_tri) * (size_t)F);
     for (int64_t f = 0; f < F; ++f)
         orc_tri_setup(verts + 3 * faces[3 * f], verts + 3 * faces[3 * f + 1], verts + 3 * faces[3 * f + 2], tri + f);
-#pragma omp parallel for schedule(dynamic, 256)
-    for (int64_t i = 0; i < N; ++i) {
-        float best = INFINITY; int64_t bi = 0;
-        for (int64_t f = 0; f < F; ++f) {
-            const float d = orc_tri_dist2(pts + 3 * i, tri + f);
-            if (d < best) { best = d; bi = f; }
+    /* blocked for cache reuse: 64 points x tiles of 128 triangles (11 KiB); every point still sees
+     * the faces in ascending order, so the strict '<' keeps the lowest index on exact ties */
+    const int64_t PB = 64, TB = 128;
+    const int64_t nblocks = (N + PB - 1) / PB;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < nblocks; ++blk) {
+        const int64_t i0 = blk * PB, i1 = (i0 + PB < N) ? i0 + PB : N;
+        float best[64]; int64_t bi[64];
+        for (int64_t i = i0; i < i1; ++i) { best[i - i0] = INFINITY; bi[i - i0] = 0; }
+        for (int64_t f0 = 0; f0 < F; f0 += TB) {
+            const int64_t f1 = (f0 + TB < F) ? f0 + TB : F;
+            for (int64_t i = i0; i < i1; ++i) {
+                float b = best[i - i0]; int64_t k = bi[i - i0];
+                for (int64_t f = f0; f < f1; ++f) {
+                    const float d = orc_tri_dist2(pts + 3 * i, tri + f);
+                    if (d < b) { b = d; k = f; }
+                }
+                best[i - i0] = b; bi[i - i0] = k;
+            }
         }
-        out_d2[i] = best; out_idx[i] = bi;
+        for (int64_t i = i0; i < i1; ++i) { out_d2[i] = best[i - i0]; out_idx[i] = bi[i - i0]; }
     }
     free(tri);
 }
@@ -247,14 +266,25 @@ int orc_ray_hit(const float *pp, int64_t ia, const float *pa, int64_t ib, const 
 void orc_check_sign(const float *verts, const int64_t *faces, int64_t F,
                     const float *pts, int64_t N, uint8_t *inside)
 {
-#pragma omp parallel for schedule(dynamic, 256)
-    for (int64_t i = 0; i < N; ++i) {
-        int cnt = 0;
-        for (int64_t f = 0; f < F; ++f) {
-            const int64_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
-            cnt += orc_ray_hit(pts + 3 * i, ia, verts + 3 * ia, ib, verts + 3 * ib, ic, verts + 3 * ic);
+    const int64_t PB = 64, TB = 256;
+    const int64_t nblocks = (N + PB - 1) / PB;
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int64_t blk = 0; blk < nblocks; ++blk) {
+        const int64_t i0 = blk * PB, i1 = (i0 + PB < N) ? i0 + PB : N;
+        int cnt[64];
+        for (int64_t i = i0; i < i1; ++i) cnt[i - i0] = 0;
+        for (int64_t f0 = 0; f0 < F; f0 += TB) {
+            const int64_t f1 = (f0 + TB < F) ? f0 + TB : F;
+            for (int64_t i = i0; i < i1; ++i) {
+                int c = 0;
+                for (int64_t f = f0; f < f1; ++f) {
+                    const int64_t ia = faces[3 * f], ib = faces[3 * f + 1], ic = faces[3 * f + 2];
+                    c += orc_ray_hit(pts + 3 * i, ia, verts + 3 * ia, ib, verts + 3 * ib, ic, verts + 3 * ic);
+                }
+                cnt[i - i0] += c;
+            }
         }
-        inside[i] = (uint8_t)(cnt & 1);
+        for (int64_t i = i0; i < i1; ++i) inside[i] = (uint8_t)(cnt[i - i0] & 1);
     }
 }
 

@@ -413,3 +413,35 @@ def test_zslab_sharding_two_ranks_one_gpu(body, cmap_mode):
         assert p.exitcode == 0
     for rank, occ in res:
         assert np.array_equal(occ, single), rank
+
+
+def test_mesh_chamfer_vs_reference(body):
+    """BASELINE metric, second half: 'mesh Chamfer vs ref' (definition: lib/dataset/Evaluator.py:200-230,
+    restated in tests/common.py; units = [-1,1]-cube units x 100).
+      (i)  dense GPU field -> mesh  vs  dense reference field (Seg3dLossless, resolutions=[65]) -> mesh: ~0
+      (ii) dense GPU field -> mesh  vs  the reference's ADAPTIVE field (resolutions=[33,65], last level
+           interpolated, SURVEY.md finding 1) -> mesh: small but non-zero by construction.
+    Tolerances: (i) <= 0.01, (ii) <= 1.6 (half the 65^3 voxel size 2/64*100 = 3.1)."""
+    from common import chamfer
+    from icon_amd.recon import export_mesh_numpy
+    res = 65
+    occ = make_engine(body).eval_slab(T(body.features), res, 0, res).cpu().numpy()
+    adaptive = golden("seg3d_body_adaptive_33_65.npz")["occ"]
+    dense_ref, _ = oracle_query(body, synth.lattice_points(res))
+    dense_ref = dense_ref.reshape(res, res, res)
+
+    def mesh(vol):
+        v, f = export_mesh_numpy(vol, 0.5)
+        v = v.numpy().astype(np.float64)
+        v = (v - (res - 1) / 2.0) / ((res - 1) / 2.0)          # apps/ICON.py:758-759
+        return v.astype(np.float32), f.numpy()
+
+    vg, fg = mesh(occ)
+    vr, fr = mesh(dense_ref)
+    va, fa = mesh(adaptive)
+    c_dense, _ = chamfer(vg, fg, vr, fr, n=20000)
+    c_adapt, p2s = chamfer(vg, fg, va, fa, n=20000)
+    print(f"chamfer dense-vs-dense {c_dense:.4f}, dense-vs-adaptive {c_adapt:.4f} (p2s {p2s:.4f}), faces {len(fg)}/{len(fa)}")
+    assert len(fg) == len(fr)
+    assert c_dense <= 0.01
+    assert c_adapt <= 1.6
