@@ -30,7 +30,7 @@ SYMBOLS = [
     "icon_work_create", "icon_work_destroy", "icon_work_profile", "icon_work_stage_ms",
     "icon_query_points",
     "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish",
-    "icon_export_mesh", "icon_debug_traversal_stats",
+    "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_debug_traversal_stats",
 ]
 
 _lib = None

@@ -154,6 +154,9 @@ struct icon_mlp {
 };
 
 namespace icon {
+// mc_device.hip
+struct McDevState;
+void mc_destroy(McDevState *s);
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
@@ -179,6 +182,7 @@ struct icon_work {
     // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
     int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
     bool slab_ready = false, slab_needs_patch = false;
+    icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
     bool prof = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

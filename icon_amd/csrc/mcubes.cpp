@@ -10,6 +10,7 @@
 // sharing the face => the output is watertight), loops are fan-triangulated, vertices are placed
 // by linear interpolation and shared between cubes through rolling per-plane edge maps.
 // Orientation: triangle normals point from inside (occ > level) to outside.
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstring>
@@ -119,6 +120,33 @@ void build_tables()
         }
     }
 }
+
+}  // namespace
+
+namespace icon {
+// flattened case table for mc_device.hip: [256][16] = triangle count, then up to 5 x 3 cube-edge ids;
+// edges[12][2] = (corner a, corner b), corner id = x + 2y + 4z
+void mc_tables(int8_t table[256][16], int8_t edges[12][2])
+{
+    std::call_once(g_once, build_tables);
+    for (int c = 0; c < 256; ++c) {
+        const auto &t = g_case_tris[c];
+        table[c][0] = (int8_t)t.size();
+        for (size_t k = 0; k < 5; ++k)
+            for (int q = 0; q < 3; ++q) table[c][1 + 3 * k + q] = (k < t.size()) ? (int8_t)t[k][q] : 0;
+    }
+    for (int e = 0; e < 12; ++e) { edges[e][0] = (int8_t)g_edges[e].a; edges[e][1] = (int8_t)g_edges[e].b; }
+}
+int mc_max_tris()
+{
+    std::call_once(g_once, build_tables);
+    size_t m = 0;
+    for (int c = 0; c < 256; ++c) m = std::max(m, g_case_tris[c].size());
+    return (int)m;
+}
+}  // namespace icon
+
+namespace {
 
 struct McResult {
     const float *occ = nullptr; int res = 0; float level = 0.f;

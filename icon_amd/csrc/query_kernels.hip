@@ -926,6 +926,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+    icon::mc_destroy(w->mc);
     delete w;
     return ICON_OK;
 }

@@ -206,8 +206,33 @@ class DenseReconEngine(nn.Module):
     def export_mesh(self, occupancys):
         """lib/common/seg3d_lossless.py:583-604: marching cubes at balance_value on occ[1:,1:,1:];
         returns (verts [Nv,3] float32 in voxel units, x,y,z order; faces [Nf,3] int64)."""
+        if occupancys.is_cuda:
+            verts, faces = export_mesh_device(occupancys, float(self.balance_value))
+            return verts.cpu(), faces.cpu()          # the reference returns CPU tensors (:601-602)
         occ = occupancys.detach().to("cpu", torch.float32).contiguous()
         return export_mesh_numpy(occ.numpy(), float(self.balance_value))
+
+
+_mc_work = None
+
+
+def export_mesh_device(occ: torch.Tensor, level: float = 0.5):
+    """Marching cubes on the GPU (icon_mc_count / icon_mc_emit): device tensors in, device tensors out."""
+    global _mc_work
+    from .engine import Workspace, _stream
+    occ = occ.detach().to(torch.float32).contiguous()
+    assert occ.dim() == 3 and occ.shape[0] == occ.shape[1] == occ.shape[2]
+    if _mc_work is None:
+        _mc_work = Workspace()
+    L = _lib.lib()
+    nv, nf = C.c_int64(0), C.c_int64(0)
+    check(L.icon_mc_count(_lib.ptr(occ), C.c_int(occ.shape[0]), C.c_float(level), _mc_work.h, _stream(), C.byref(nv), C.byref(nf)),
+          "icon_mc_count")
+    verts = torch.empty((max(nv.value, 1), 3), dtype=torch.float32, device=occ.device)
+    faces = torch.empty((max(nf.value, 1), 3), dtype=torch.int64, device=occ.device)
+    if nv.value and nf.value:
+        check(L.icon_mc_emit(_lib.ptr(verts), _lib.ptr(faces), _mc_work.h, _stream()), "icon_mc_emit")
+    return verts[: nv.value], faces[: nf.value]
 
 
 def export_mesh_numpy(occ: np.ndarray, level: float = 0.5):

@@ -203,6 +203,15 @@ int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1,
 int icon_export_mesh(const float *h_occ, int res, float level,
                      float *h_verts, int64_t *n_verts, int64_t *h_faces, int64_t *n_faces);
 
+/* The same on the device (the reference uses a CUDA marching cubes for grids <= 256^3,
+ * lib/common/seg3d_lossless.py:597-602): d_occ is the DEVICE volume [res,res,res].
+ * icon_mc_count classifies and scans, synchronises and returns the sizes; the caller allocates
+ * d_verts [n_verts,3] f32 and d_faces [n_faces,3] i64 and calls icon_mc_emit on the same workspace.
+ * Same vertices and triangles as icon_export_mesh (as sets; the order differs). */
+int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, void *stream,
+                  int64_t *n_verts, int64_t *n_faces);
+int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -445,3 +445,37 @@ def test_mesh_chamfer_vs_reference(body):
     assert len(fg) == len(fr)
     assert c_dense <= 0.01
     assert c_adapt <= 1.6
+
+
+def _canonical_mesh(v, f):
+    """order-independent form: vertices sorted lexicographically, faces re-indexed, rotated to start at
+    their smallest vertex (winding preserved) and sorted"""
+    order = np.lexsort((v[:, 2], v[:, 1], v[:, 0]))
+    inv = np.empty(len(v), np.int64); inv[order] = np.arange(len(v))
+    f = inv[f]
+    k = np.argmin(f, axis=1)
+    f = np.stack([f[np.arange(len(f)), (k + j) % 3] for j in range(3)], 1)
+    f = f[np.lexsort((f[:, 2], f[:, 1], f[:, 0]))]
+    return v[order], f
+
+
+@pytest.mark.parametrize("res", [33, 129])
+def test_gpu_marching_cubes_equals_host(body, res):
+    """device marching cubes == host marching cubes as sets (same vertices bit for bit, same triangles)"""
+    from icon_amd.recon import export_mesh_device, export_mesh_numpy
+    occ = make_engine(body).eval_slab(T(body.features), res, 0, res)
+    vd, fd = export_mesh_device(occ, 0.5)
+    vh, fh = export_mesh_numpy(occ.cpu().numpy(), 0.5)
+    assert vd.shape == vh.shape and fd.shape == fh.shape and len(fh) > 100
+    a = _canonical_mesh(vd.cpu().numpy(), fd.cpu().numpy())
+    b = _canonical_mesh(vh.numpy(), fh.numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # noise: every ambiguous configuration, still identical and watertight
+    noisy = occ + (torch.rand_like(occ) - 0.5) * 0.8
+    vd, fd = export_mesh_device(noisy, 0.5)
+    vh, fh = export_mesh_numpy(noisy.cpu().numpy(), 0.5)
+    a, b = _canonical_mesh(vd.cpu().numpy(), fd.cpu().numpy()), _canonical_mesh(vh.numpy(), fh.numpy())
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    # nothing above the level
+    v0, f0 = export_mesh_device(torch.zeros_like(occ), 0.5)
+    assert len(v0) == 0 and len(f0) == 0
