@@ -479,3 +479,50 @@ def test_gpu_marching_cubes_equals_host(body, res):
     # nothing above the level
     v0, f0 = export_mesh_device(torch.zeros_like(occ), 0.5)
     assert len(v0) == 0 and len(f0) == 0
+
+
+def test_adaptive_recon_matches_reference_volume(body):
+    """the reference's own coarse-to-fine reconEngine run verbatim on CPU (golden) vs
+    AdaptiveReconEngine + HIP query on the GPU: same batches, same order, same volume"""
+    from icon_amd.recon import AdaptiveReconEngine
+    from icon_amd.engine import query_func
+    from types import SimpleNamespace
+    g = golden("seg3d_body_adaptive_33_65.npz")
+    eng = make_engine(body)
+    recon = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                resolutions=[33, 65], align_corners=True, balance_value=0.5, faster=True).to(dev())
+    vol = recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert vol.shape == (65, 65, 65)
+    d = np.abs(vol.cpu().numpy() - g["occ"])
+    assert d.max() <= OCC_TOL, d.max()
+    assert recon.last_stats["queries"] == [33 ** 3]      # two levels: coarse lattice queried, last level interpolated
+    # three levels: the middle one queries only the boundary band - against the reference's volume again
+    g3 = golden("seg3d_body_adaptive_17_33_65.npz")
+    recon3 = AdaptiveReconEngine(query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
+    vol3 = recon3(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    q = recon3.last_stats["queries"]
+    assert q[0] == 17 ** 3 and 0 < q[1] < 33 ** 3 // 2
+    d3 = np.abs(vol3.cpu().numpy() - g3["occ"])
+    assert d3.max() <= OCC_TOL, (d3.max(), (d3 > OCC_TOL).sum())
+    dense = eng.eval_slab(T(body.features), 65, 0, 65)
+    agree = ((vol3 > 0.5) == (dense > 0.5)).float().mean().item()
+    assert agree > 0.995
+
+
+def test_lattice_513_properties(body):
+    """cfg 5 size (513^3 = 135,005,697 points, 8.6 GB of MLP input rows): 64-bit indexing, and
+    the even sub-lattice IS the 257^3 lattice (identical float coordinates), so in the per-point
+    cmap mode the two volumes must agree bit for bit there"""
+    feat = T(body.features)
+    eng = make_engine(body, cmap_mode="local")
+    big = eng.eval_slab(feat, 513, 0, 513)
+    assert big.shape == (513, 513, 513) and torch.isfinite(big).all()
+    small = eng.eval_slab(feat, 257, 0, 257)
+    assert torch.equal(big[::2, ::2, ::2], small)
+    assert (big[0] == 0).all() and (big[:, :, -1] == 0).all()
+    # reference cmap mode at this size: same numbers off the clipped set, finite everywhere
+    ref = make_engine(body, cmap_mode="reference").eval_slab(feat, 513, 250, 262)
+    assert torch.isfinite(ref).all()
+    sdf = eng._mesh_handle().sdf_query(T(synth.lattice_points(513, 256, 257)))["sdf"].view(513, 513)
+    near = sdf.abs() < body.sdf_clip
+    assert near.any() and torch.equal(ref[6][near], big[256][near])

@@ -65,7 +65,8 @@ def main():
 
     # ---- (c) Seg3dLossless, single-level (dense) and the reference's adaptive schedule -------
     with torch.no_grad():
-        for name, resolutions in (("dense17", [17]), ("dense33", [33]), ("adaptive_33_65", [33, 65])):
+        for name, resolutions in (("dense17", [17]), ("dense33", [33]), ("adaptive_33_65", [33, 65]),
+                                  ("adaptive_17_33_65", [17, 33, 65])):
             eng = ref.Seg3dLossless(query_func=ref.query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                                     resolutions=resolutions, align_corners=True, balance_value=0.5, faster=True)
             vol = eng(opt=cfg, netG=netG, features=[T(a.features)], proj_matrix=None)
