@@ -8,7 +8,9 @@
 // float32 arithmetic here follows the spec in DESIGN.md §"Arithmetic spec" (explicit fmaf, no
 // other contraction) so that the normals are bit-identical to the checker's.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -178,6 +180,12 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     ICON_ARG(V >= 3 && F >= 1, "icon_mesh_create: need V >= 3 and F >= 1");
     ICON_ARG(F < (1 << 27) && V < (1ll << 31), "icon_mesh_create: mesh too large");
     hipStream_t st = (hipStream_t)stream;
+    const bool verbose = getenv("ICON_AMD_VERBOSE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
 
     std::vector<float> verts(3 * V), cmap(3 * V), vis(V);
     std::vector<int64_t> faces(3 * F);
@@ -189,6 +197,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     for (int64_t i = 0; i < 3 * F; ++i)
         ICON_ARG(faces[i] >= 0 && faces[i] < V, "icon_mesh_create: face index out of range");
 
+    const auto t1 = now();
     // S1: vertex normals = sum over incident faces (ascending face index) of (v1-v0)x(v2-v0),
     // then v / max(|v|, 1e-6)  [pytorch3d verts_normals_padded + F.normalize(eps=1e-6)]
     std::vector<float> vn(3 * V, 0.f);
@@ -207,6 +216,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         vn[3 * v] = x / len; vn[3 * v + 1] = y / len; vn[3 * v + 2] = z / len;
     }
 
+    const auto t2 = now();
     // BVH
     Builder bd;
     bd.verts = verts.data(); bd.faces = faces.data();
@@ -234,6 +244,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     }
     if (bd.max_depth + 2 > kStackDepth) return fail(ICON_ERR_UNSUPPORTED, "icon_mesh_create: BVH too deep");
 
+    const auto t3 = now();
     // slot-ordered triangle records / attributes.  Every leaf owns exactly kLeafMax consecutive
     // slots; short leaves are padded with copies of their last triangle (same face id, so a copy can
     // never change the arg-min) whose vertex ids are -1 so the ray-parity scans skip them.
@@ -268,6 +279,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         }
     }
 
+    const auto t4 = now();
     // (y,z) ray bins: every triangle is listed in all cells its (y,z) bounding box, grown by
     // eps, overlaps.  cell_of() is monotone, so a query point inside the grown box lands in one
     // of those cells; eps covers the rounding of the float32 edge functions.
@@ -304,6 +316,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         }
     }
 
+    const auto t5 = now();
     icon_mesh *m = new icon_mesh();
     m->V = V; m->F = F;
     int rc;
@@ -326,6 +339,9 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     m->stats[0] = (int64_t)bd.nodes.size(); m->stats[1] = bd.max_depth;
     m->stats[2] = (int64_t)bin_slots.size(); m->stats[3] = max_bin;
     m->stats[4] = n_leaves; m->stats[5] = S;
+    if (verbose)
+        fprintf(stderr, "[icon_amd] mesh_create: d2h %.2f ms, normals %.2f, bvh %.2f, records %.2f, bins %.2f, upload %.2f\n",
+                ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, t5), ms(t5, now()));
     *out = m;
     return ICON_OK;
 }

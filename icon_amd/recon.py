@@ -137,16 +137,17 @@ class DenseReconEngine(nn.Module):
         return self._none_if_empty(occ)
 
     @staticmethod
-    def _all_gather(dist, t, world, group):
-        """all_gather of one equal-shaped tensor per rank -> list.  RCCL ('nccl') moves device tensors
-        directly; a gloo group (CPU tests, or debugging several ranks on one GPU) stages through the host."""
+    def _all_gather_cat(dist, t, world, group):
+        """all_gather of one equal-shaped tensor per rank, concatenated along dim 0 (ONE collective into
+        one output tensor, no per-rank list / cat copies).  RCCL ('nccl') moves device tensors directly;
+        a gloo group (CPU tests, or several ranks debugging on one GPU) stages device tensors through the host."""
         if t.is_cuda and dist.get_backend(group) == "gloo":
-            parts = [torch.empty(t.shape, dtype=t.dtype) for _ in range(world)]
-            dist.all_gather(parts, t.cpu(), group=group)
-            return [p.to(t.device) for p in parts]
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=group)
-        return parts
+            out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+            dist.all_gather_into_tensor(out, t.cpu().contiguous(), group=group)
+            return out.to(t.device)
+        out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out, t.contiguous(), group=group)
+        return out
 
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
@@ -160,20 +161,22 @@ class DenseReconEngine(nn.Module):
             else:
                 signs = torch.empty(0, dtype=torch.int8, device=dev)
                 count = torch.zeros(1, dtype=torch.int64, device=dev)
-            counts = [int(c.item()) for c in self._all_gather(dist, count, world, g)]
+            counts = self._all_gather_cat(dist, count.view(1), world, g).tolist()      # one host sync
             kmax = max(max(counts), 1)
             mine = torch.zeros(kmax, dtype=torch.int8, device=dev)
             mine[:counts[rank]] = signs[:counts[rank]]
-            gathered = self._all_gather(dist, mine, world, g)
-            signs_global = torch.cat([t[:c] for t, c in zip(gathered, counts)]) if sum(counts) else mine[:0]
+            gathered = self._all_gather_cat(dist, mine, world, g).view(world, kmax)
+            if sum(counts):
+                signs_global = torch.cat([gathered[r, :c] for r, c in enumerate(counts)]).contiguous()
+            else:
+                signs_global = mine[:0]
             if z1 > z0:
-                be.slab_finish(res, z0, z1, signs_global.contiguous(), sum(counts), sum(counts[:rank]),
+                be.slab_finish(res, z0, z1, signs_global, sum(counts), sum(counts[:rank]),
                                out=slab[: z1 - z0], device=dev)
             self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world)
         elif z1 > z0:
             be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
-        parts = self._all_gather(dist, slab, world, g)
-        return torch.cat(parts, 0)[:res].contiguous()
+        return self._all_gather_cat(dist, slab, world, g)[:res]
 
     def _forward_generic(self, **kwargs):
         """Any b_min/b_max/align_corners/proj_matrix: materialise the lattice coordinates exactly as
