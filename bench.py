@@ -35,9 +35,11 @@ sys.path.insert(0, ROOT)
 MLP_FLOP_PER_POINT = 344_602          # 2 * (13*512 + 512*256 + 269*128 + 141), SURVEY.md §8(d)
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks for the instruction each path issues
 PEAK_TFLOPS = {"f32": 157.3,          # v_mfma_f32_32x32x2_f32
-               "f16x3": 2500.0}       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
-KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_mlp_f16x3"}
-DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (f32 accumulate)"}
+               "f16x3": 2500.0,       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
+               "mx6": 2500.0}         # same f16 peak; 4 f16 + 2 fp6 MFMAs per K=64 (1.5 issue slots per K=16)
+KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_mlp_f16x3", "mx6": "k_mlp_mx6"}
+DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (f32 accumulate)",
+         "mx6": "f32 via f16 MFMA + block-scaled fp6 cross terms (f32 accumulate)"}
 
 
 def cpu_baseline(assets, res, budget_s=14.0):
@@ -96,7 +98,7 @@ def main():
     ap.add_argument("--res", type=int, default=257)
     ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "mx6"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

@@ -151,6 +151,8 @@ struct icon_mlp {
     // 3xf16 split-precision path (mlp_f16x3.hip): chunked hi/lo operand image + f32 side arrays
     char *d_f16 = nullptr;
     float f16_inv[3] = {1.f, 1.f, 1.f};
+    // f16 + MX-fp6 path (mlp_mx6.hip): f16 hi operands, block-scaled fp6 images of W and W - W_hi
+    char *d_mx6 = nullptr;
 };
 
 namespace icon {
@@ -163,6 +165,12 @@ int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out
 // mlp_f16x3.hip
 int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
 int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
+uint16_t f32_to_f16_rtn(float f);
+float f16_to_f32(uint16_t h);
+float pick_scale(const std::vector<float> &W);     // power of two that brings max|W| to ~8192
+// mlp_mx6.hip
+int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
+int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
 }  // namespace icon
 
 struct icon_work {

@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
 // ---------------------------------------------------------------------------------------------
 // host side: operand image
 // ---------------------------------------------------------------------------------------------
-static uint16_t f32_to_f16_rtn(float f)
+uint16_t f32_to_f16_rtn(float f)
 {
     uint32_t x; memcpy(&x, &f, 4);
     const uint32_t sign = (x >> 16) & 0x8000u;
@@ -332,7 +332,7 @@ static uint16_t f32_to_f16_rtn(float f)
     return (uint16_t)(sign | out);
 }
 
-static float f16_to_f32(uint16_t h)
+float f16_to_f32(uint16_t h)
 {
     const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
     const int e = (h >> 10) & 31;
@@ -344,7 +344,7 @@ static float f16_to_f32(uint16_t h)
     return sign ? -v : v;
 }
 
-static float pick_scale(const std::vector<float> &W)
+float pick_scale(const std::vector<float> &W)
 {
     float mx = 0.f;
     for (float v : W) mx = std::max(mx, std::fabs(v));

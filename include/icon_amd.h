@@ -45,8 +45,10 @@ enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
 
 /* MLP arithmetic.  F32: v_mfma_f32_32x32x2_f32, bit-for-bit an f32 fma chain.  F16X3: every
  * product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with f32 accumulation
- * (22-bit operands; ~1e-6 of the f32 result, 5x the rate). */
-enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1 };
+ * (22-bit operands; ~1e-6 of the f32 result, 5x the rate).  MX6: a_hi*b_hi on the f16 MFMA and
+ * the two 2^-11 cross terms on the block-scaled fp6 MFMA v_mfma_scale_f32_32x32x64_f8f6f4
+ * (half the matrix-pipe time of F16X3; <= ~3e-5 from the float64 MLP on the occupancy). */
+enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1, ICON_PRECISION_MX6 = 2 };
 
 /* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
 enum { ICON_SEARCH_BVH = 0, ICON_SEARCH_BRUTE = 1 };

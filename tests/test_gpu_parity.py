@@ -106,10 +106,11 @@ def test_sdf_golden_reference(body):
 # ---------------------------------------------------------------------------------------------
 # MLP
 # ---------------------------------------------------------------------------------------------
-PRECISIONS = ["f32", "f16x3"]
+PRECISIONS = ["f32", "f16x3", "mx6"]
 # f32: exact-f32 MFMA chain (differs from the float64 oracle by f32 round-off only);
-# f16x3: 22-bit split operands on the f16 matrix cores, f32 accumulate
-MLP_TOL = {"f32": 1e-5, "f16x3": 2e-5}
+# f16x3: 22-bit split operands on the f16 matrix cores, f32 accumulate;
+# mx6: f16 main term + block-scaled fp6 cross terms (tools/sim_mx6.py predicts <= ~2.5e-5)
+MLP_TOL = {"f32": 1e-5, "f16x3": 2e-5, "mx6": 6e-5}
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -149,6 +150,18 @@ def test_mlp_f16x3_error_statistics(body):
     print(f"max/mean |err|/max(1,|ref|): f32 {np.max(e32 / scale):.2e}/{np.mean(e32 / scale):.2e}  "
           f"f16x3 {np.max(e16 / scale):.2e}/{np.mean(e16 / scale):.2e}")
     assert np.max(e16 / scale) <= 2e-5 and np.mean(e16 / scale) <= 2e-6
+    e6 = np.abs(mlp.forward(T(rows16(x)), precision="mx6").cpu().numpy() - ref)
+    print(f"mx6 {np.max(e6 / scale):.2e}/{np.mean(e6 / scale):.2e}  p99.9 {np.quantile(e6 / scale, 0.999):.2e}")
+    big = np.argmax(e6 / scale)
+    print(f"worst mx6 sample: |x|max {np.abs(x[big]).max():.1f} ref {ref[big]:.3f} err {e6[big]:.2e}")
+    for lim in (2.0, 5.0, 20.0):
+        sel = np.abs(x).max(1) <= lim
+        print(f"  |x|<={lim}: n {sel.sum()} max {np.max((e6 / scale)[sel]):.2e} mean {np.mean((e6 / scale)[sel]):.2e}")
+    # the fp6 cross terms make the error proportional to the activations' magnitude: bound it against
+    # the input scale for the wide-range samples and absolutely for in-distribution inputs
+    xs = np.maximum(scale, np.abs(x).max(1))
+    assert np.max(e6 / xs) <= 2e-5 and np.mean(e6 / xs) <= 2e-6
+    assert np.max(e6[np.abs(x).max(1) <= 5.0]) <= 3e-5
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -167,7 +180,10 @@ def test_mlp_transpose_detecting(precision):
     x = rng.normal(0, 1, (4096, 13)).astype(np.float32)
     y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x)), precision=precision).cpu().numpy()
     ref = orc.Mlp(sd).forward(x, f64=True)[:, 0]
-    assert np.abs(y - ref).max() <= MLP_TOL[precision]
+    # single-term sums: no averaging of the fp6 rounding of the cross terms (2^-4 * 2^-11 per layer), so
+    # mx6 is bounded relative to the activations' magnitude here; a routing slip would be an O(1) error
+    tol = MLP_TOL[precision] if precision != "mx6" else 1e-4 * max(1.0, float(np.abs(x).max()))
+    assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max()
 
 
 # ---------------------------------------------------------------------------------------------
