@@ -17,15 +17,21 @@
 //  * a chunk is K=64 hidden channels: 32 KiB f16 hi operands + 2 x 12 KiB fp6 operands + 1 KiB of
 //    e8m0 scales, DMA'd global->LDS into a double buffer (2 x 57 KiB) while the previous chunk is
 //    being multiplied.
-//  * no software pipelining inside a wavefront.  Each wave alternates a VALU phase V(k) (layer-0
-//    tiles of chunk k -> LeakyReLU -> f16 hi / residual -> block exponent -> fp6) and an MFMA phase
-//    M(k) (48 MFMAs).  The two waves that share a SIMD (wave w and w+4 of the 512-thread workgroup)
-//    run the SAME instruction stream with the per-chunk barrier at different points of it - waves
-//    0-3 do V(k) M(k) | barrier, waves 4-7 do M(k) V(k+1) | barrier - so in every barrier interval
-//    one wave of the SIMD is in its VALU phase while the other feeds the matrix pipe.
+//  * phases instead of fine-grained software pipelining: per chunk a wave runs an MFMA phase M(k)
+//    (48 MFMAs, operands prefetched through a rotating register window) and then a VALU phase V(k+1)
+//    (LeakyReLU -> f16 hi / residual -> block exponent -> fp6 of the NEXT chunk's B operands).  The
+//    six layer-0 MFMAs that produce V(k+1)'s input are issued inside the tail of M(k), where their
+//    dependency latency is covered by the fp6 MFMAs around them.  256 registers per wave (2 waves per
+//    SIMD) leave no room for a second B operand set, which is what interleaving V into M would need.
+//  * persistent workgroups: one per CU, looping over point tiles.  Layer-0 weights and the side
+//    arrays are staged once; chunk 0 and the input rows of the next tile are requested during the
+//    last layer-2 step of the current one, so a tile starts without a cold prologue.
 #include "common.h"
 
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 
 namespace icon {
@@ -47,6 +53,7 @@ constexpr int kMxW0Off = 2 * kMxBuf;
 constexpr int kMxW0Bytes = 32 * 1024;
 constexpr int kMxSideOff = kMxW0Off + kMxW0Bytes;
 constexpr int kMxSideFloats = 512 + 256 + 128 + 144;          // b0 | b1 | b2 | w3 (same as mlp_f16x3)
+constexpr int kDmaFirst = 20;                                 // of 57: pieces issued by the V-first waves
 constexpr int kMxLds = kMxSideOff + 4352;                     // 150.25 KiB
 
 // image: [W0 32 KiB][layer-1 chunks 0..7: 57 KiB][layer-2 chunks 8..10: 29 KiB, 11: 37 KiB]
@@ -69,8 +76,8 @@ struct MlpMx6Dev {
     const char *image;
     const float *side;
     float b3;
-    float inv0, inv1, inv2;
     int c0;
+    unsigned long long *trace;     // debug (ICON_AMD_MX6_TRACE): s_memtime stamps of workgroup 0, second tile
 };
 
 __device__ __forceinline__ f32x16 mx_ld16(const float *p)
@@ -83,6 +90,7 @@ __device__ __forceinline__ f32x16 mx_ld16(const float *p)
     return v;
 }
 
+#define MX_STAMP(slot) if (tr) { tr[slot] = __builtin_amdgcn_s_memtime(); }
 #define MX_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 // fp6 (e2m3) x fp6, byte OPA of the A scale register, byte 0 of the B scale register
 #define MX_MFMA6(a, b, c, OPA, sa, sb) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4((a), (b), (c), 2, 2, (OPA), (sa), 0, (sb))
@@ -104,13 +112,15 @@ __device__ __forceinline__ i32x8 mx_op6(const char *buf, int offA, int offB, int
 // pending global_load_lds as a "flat" access and from then on turns EVERY LDS wait into
 // lgkmcnt(0) / vmcnt(0), which serialises the operand prefetch of the MFMA phase.  Hidden from that
 // pass, the ds_read waits are counted ones; mx_dma_wait() supplies the vmcnt(0) before the barrier.
+// one piece: 64 lanes x 16 B from g (wave-uniform) + lane * 16 -> LDS at lds (wave-uniform) + lane * 16
+__device__ __forceinline__ void mx_issue_piece(const char *g, char *lds, int lane16)
+{
+    const uint32_t l = (uint32_t)(uintptr_t)(lvoid_t *)lds;
+    asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" : : "s"(l), "v"(lane16), "s"(g) : "memory");
+}
 __device__ __forceinline__ void mx_issue_units(const char *src, char *buf, int units, int wave, int lane)
 {
-    for (int u = wave; u < units; u += kMxBlock / 64) {
-        const char *g = src + u * 1024 + lane * 16;
-        const uint32_t l = (uint32_t)(uintptr_t)(lvoid_t *)(buf + u * 1024);
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, off" : : "s"(l), "v"(g) : "memory");
-    }
+    for (int u = wave; u < units; u += kMxBlock / 64) mx_issue_piece(src + u * 1024, buf + u * 1024, lane * 16);
 }
 __device__ __forceinline__ void mx_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 __device__ __forceinline__ void mx_issue_chunk(const char *image, char *buf, int k, int wave, int lane)
@@ -139,8 +149,18 @@ struct MxB {
     int sh, sl;       // e8m0 block scales
 };
 
-// VALU phase: two finished accumulator tiles -> LeakyReLU -> MxB
-__device__ __forceinline__ void mx_make_b(const f32x16 &ta, const f32x16 &tb, float inv, MxB &b)
+// VALU phase: two finished accumulator tiles -> LeakyReLU -> MxB.  (The accumulators carry the
+// layer's power-of-two weight scale; LeakyReLU commutes with it and the next layer's packed weights
+// divide it out, so there is no rescaling multiply here.)
+// DMA: the LDS-DMA of the next chunk is issued from here, one 1 KiB piece per value pair - a piece
+// costs its wave 50-100+ issue cycles, which inside the MFMA stream were matrix-pipe bubbles.  The
+// waves that run this phase first in a barrier interval take the first kDmaFirst pieces, their SIMD
+// partners (whose VALU phase comes after their MFMA phase and is off the interval's critical path)
+// the rest.
+struct MxDma { const char *src; char *dst; int first, last, widx, lane16; };    // pieces [first, last) of the chunk, 4 issuing waves
+
+template <bool DMA>
+__device__ __forceinline__ void mx_make_b(const f32x16 &ta, const f32x16 &tb, MxB &b, const MxDma &dma)
 {
     half32 hi, lo;
     float mx = 0.0f;
@@ -148,16 +168,27 @@ __device__ __forceinline__ void mx_make_b(const f32x16 &ta, const f32x16 &tb, fl
     for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const float a0 = T ? tb[2 * q] : ta[2 * q], a1 = T ? tb[2 * q + 1] : ta[2 * q + 1];
-            const float x0 = a0 * inv, x1 = a1 * inv;
+            const float x0 = T ? tb[2 * q] : ta[2 * q], x1 = T ? tb[2 * q + 1] : ta[2 * q + 1];
             const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
             const f32x2 vv = {v0, v1};
             const half2v hh = __builtin_convertvector(vv, half2v);          // v_cvt_pk_f16_f32 (RTN)
-            const f32x2 rr = {v0 - (float)hh[0], v1 - (float)hh[1]};        // exact
-            const half2v ll = __builtin_convertvector(rr, half2v);
-            mx = fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1)));
+            // residual v - hi (exact in f32) rounded once to f16, written straight into the packed pair:
+            // fma(hi.f16, -1.0, v.f32) -> f16 low / high half.  The compiler's own selection for
+            // `v - (float)hi` is 2 x v_cvt_f32_f16 + v_pk_add_f32 + v_cvt_pk_f16_f32 (5 issue slots).
+            const int hb = __builtin_bit_cast(int, hh);
+            int lb;
+            asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(v0));
+            asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v1));
+            const half2v ll = __builtin_bit_cast(half2v, lb);
+            const _Float16 l0 = ll[0], l1 = ll[1];
+            mx = __builtin_fmaxf(__builtin_fmaxf(mx, __builtin_fabsf(v0)), __builtin_fabsf(v1));   // v_max3_f32 |.|
             hi[16 * T + 2 * q] = hh[0]; hi[16 * T + 2 * q + 1] = hh[1];
-            lo[16 * T + 2 * q] = ll[0]; lo[16 * T + 2 * q + 1] = ll[1];
+            lo[16 * T + 2 * q] = l0; lo[16 * T + 2 * q + 1] = l1;
+            if (DMA) {
+                const int p = 8 * T + q;                                          // slot 0..15 of this wave
+                const int u = min(dma.first + dma.widx + 4 * p, dma.last - 1);     // past the end: repeat the final piece
+                if (dma.first + 4 * p < dma.last + 3) mx_issue_piece(dma.src + u * 1024, dma.dst + u * 1024, dma.lane16);
+            }
         }
     }
     // shared exponent: 2^(E-2) with E = floor(log2(max|h|)) puts the block maximum in [4, 8) of the
@@ -183,22 +214,50 @@ __device__ __forceinline__ i32x8 mx_ld6(const char *__restrict__ L, int j, int l
 }
 
 // fp6 MFMA J of the chunk (J literal: the scale byte select must be an integer constant)
+// layer-0 work slotted into the fp6 stage of an M phase: hidden tiles 2*cn, 2*cn+1 from l0.xhi/xlo into
+// l0.h0n.  Layer-1 chunks (NT == 8): tile 0 before fp6 ops 2/4/6, tile 1 before ops 10/12/14 (a
+// layer-2 chunk with L0H: ops 1/2/3 and 5/6/7 - measured slower, the extra live registers spill).  Operands are requested 1-2 ops earlier.
+#define MX_L0_HOOK(NT, J)                                                                                           \
+    if constexpr (NT == 8 || L0H) {                                                                                 \
+        constexpr int half_ops = NT, step = NT / 4;          /* 8 ops per tile, MFMAs every 2nd op; or 4 and every op */ \
+        constexpr int tl = (J) / half_ops, r = (J) % half_ops;                                                       \
+        if (r == 0) {                                                                                               \
+            const int c0t = 2 * l0.cn + tl;                                                                         \
+            l0.h0n[tl] = mx_ld16(l0.sb0 + (c0t * 2 + l0.h) * 16);                                                   \
+            l0a_hi = mx_op(l0.W0, 2 * c0t, lane); l0a_lo = mx_op(l0.W0, 2 * c0t + 1, lane);                         \
+        }                                                                                                           \
+        if (r == 1 * step) l0.h0n[tl] = MX_MFMA16(l0a_hi, l0.xhi, l0.h0n[tl]);                                       \
+        if (r == 2 * step) l0.h0n[tl] = MX_MFMA16(l0a_hi, l0.xlo, l0.h0n[tl]);                                       \
+        if (r == 3 * step) l0.h0n[tl] = MX_MFMA16(l0a_lo, l0.xhi, l0.h0n[tl]);                                       \
+    }
+
 #define MX_OP6(NT, J)                                                                                               \
     if constexpr ((J) < 2 * NT) {                                                                                   \
         constexpr int t6 = (J) % NT;                                                                                \
         const i32x8 cur = w6[(J) & 3];                                                                              \
         if ((J) + 4 < 2 * NT) w6[(J) & 3] = mx_ld6<NT>(L, (J) + 4, lane);                                           \
+        MX_L0_HOOK(NT, J)                                                                                           \
         if ((J) < NT) acc[t6] = MX_MFMA6(cur, b.l6, acc[t6], t6 & 3, scw[t6 >> 2], b.sl);                            \
         else          acc[t6] = MX_MFMA6(cur, b.h6, acc[t6], t6 & 3, scl[t6 >> 2], b.sh);                            \
         __builtin_amdgcn_sched_barrier(0);                                                                          \
     }
 
+// what the layer-0 hook needs: resident W0 operands, biases, the raw-input operands, which pair of
+// hidden tiles to produce, and where to leave them
+struct MxL0 {
+    const char *W0;
+    const float *sb0;
+    half8 xhi, xlo;
+    int cn, h;
+    f32x16 h0n[2];
+};
+
 // MFMA phase of a chunk with NT output tiles, K-major: for each of the four f16 k-steps all tiles,
 // then fp6(W) x fp6(h_lo) for all tiles, then fp6(W_lo) x fp6(h).  Consecutive MFMAs hit different
 // accumulators; every A operand is requested 8 (f16) / 4 (fp6) MFMAs ahead of its use through a
 // rotating register window, so only ~32 operand registers are live beside the accumulators.
-template <int NT>
-__device__ __forceinline__ void mx_m_phase(const char *__restrict__ L, int lane, f32x16 (&acc)[NT], const MxB &b)
+template <int NT, bool L0H>
+__device__ __forceinline__ void mx_m_phase(const char *__restrict__ L, int lane, f32x16 (&acc)[NT], const MxB &b, MxL0 &l0)
 {
     int scw[2], scl[2];
     if (NT == 8) {
@@ -210,6 +269,7 @@ __device__ __forceinline__ void mx_m_phase(const char *__restrict__ L, int lane,
     }
     half8 a[8];
     i32x8 w6[4];
+    half8 l0a_hi, l0a_lo;
 #pragma unroll
     for (int i = 0; i < 8; ++i) a[i] = mx_op(L, i, lane);
     __builtin_amdgcn_sched_barrier(0);
@@ -240,144 +300,173 @@ __device__ __forceinline__ f32x16 mx_l0_tile(const char *__restrict__ W0, const 
     h0 = MX_MFMA16(a_hi, xhi, h0); h0 = MX_MFMA16(a_hi, xlo, h0); h0 = MX_MFMA16(a_lo, xhi, h0);
     return h0;
 }
-__device__ __forceinline__ void mx_v_l1(const char *__restrict__ W0, const float *__restrict__ sb0, int k, half8 xhi, half8 xlo,
-                                        float inv0, int h, int lane, MxB &b)
-{
-    const f32x16 ta = mx_l0_tile(W0, sb0, 2 * k, xhi, xlo, h, lane);
-    const f32x16 tb = mx_l0_tile(W0, sb0, 2 * k + 1, xhi, xlo, h, lane);
-    mx_make_b(ta, tb, inv0, b);
-}
-
 // one barrier interval of layer 1: chunk k is multiplied while chunk k+1 lands in the other buffer.
-// `late` waves (4-7) arrive with b = B(k) already built and leave with B(k+1) (or the first layer-2
-// operands when k == 7).
-__device__ __forceinline__ void mx_l1_step(const char *__restrict__ cur, char *__restrict__ nxt, const char *__restrict__ W0,
-                                           const float *__restrict__ sb0, const char *image, int k, f32x16 (&acc1)[8],
-                                           half8 xhi, half8 xlo, float inv0, float inv1, int h, int lane, int wave, bool late,
-                                           MxB &b)
+// The two waves that share a SIMD (w and w+4) run the same stream with the barrier at different
+// points of it: "early" waves (0-3) build B(k) from l0.h0n and then multiply, "late" waves (4-7)
+// arrive with B(k) built and build B(k+1) after multiplying - so while one of them is in its VALU
+// phase the other one has the matrix pipe to itself.
+__device__ __forceinline__ void mx_l1_step(const char *__restrict__ cur, char *__restrict__ nxt, const char *image, int k,
+                                           f32x16 (&acc1)[8], MxL0 &l0, int lane, int wave, bool late, MxB &b, unsigned long long *tr)
 {
-    mx_issue_chunk(image, nxt, k + 1, wave, lane);
-    if (!late) mx_v_l1(W0, sb0, k, xhi, xlo, inv0, h, lane, b);
-    mx_m_phase<8>(cur, lane, acc1, b);
+    const char *src = image + (size_t)mx_chunk_offset(k + 1) * 1024;
+    const int units = mx_chunk_units(k + 1), split = min(kDmaFirst, units);
+    if (!late) mx_make_b<true>(l0.h0n[0], l0.h0n[1], b, MxDma{src, nxt, 0, split, wave & 3, lane * 16});
+    l0.cn = min(k + 1, 7);                        // k == 7: harmless repeat of the last pair
+    MX_STAMP(0)
+    mx_m_phase<8, true>(cur, lane, acc1, b, l0);
+    MX_STAMP(1)
     if (late) {
-        if (k < 7) mx_v_l1(W0, sb0, k + 1, xhi, xlo, inv0, h, lane, b);
-        else mx_make_b(acc1[0], acc1[1], inv1, b);
+        const MxDma dma = {src, nxt, split, units, wave & 3, lane * 16};
+        if (k < 7) mx_make_b<true>(l0.h0n[0], l0.h0n[1], b, dma);
+        else mx_make_b<true>(acc1[0], acc1[1], b, dma);
     }
 }
 
 template <int Q>
-__device__ __forceinline__ void mx_l2_step(const char *__restrict__ cur, char *__restrict__ nxt, const char *image,
-                                           f32x16 (&acc1)[8], f32x16 (&acc2)[4], float inv1, int lane, int wave, bool late, MxB &b)
+__device__ __forceinline__ void mx_l2_step(const char *__restrict__ cur, char *__restrict__ nxt, const char *image, f32x16 (&acc1)[8],
+                                           f32x16 (&acc2)[4], MxL0 &l0, int lane, int wave, bool late, MxB &b)
 {
-    if (Q < 3) mx_issue_chunk(image, nxt, 9 + Q, wave, lane);
-    if (!late) mx_make_b(acc1[2 * Q], acc1[2 * Q + 1], inv1, b);
-    mx_m_phase<4>(cur, lane, acc2, b);
-    if (late && Q < 3) mx_make_b(acc1[Q < 3 ? 2 * Q + 2 : 0], acc1[Q < 3 ? 2 * Q + 3 : 1], inv1, b);
+    // next chunk: 9 + Q of this tile, or chunk 0 of the next tile
+    constexpr int kNext = Q < 3 ? 9 + Q : 0;
+    const char *src = image + (size_t)mx_chunk_offset(kNext) * 1024;
+    constexpr int units = mx_chunk_units(kNext);
+    // the M-first waves have no VALU phase after the last chunk: there the V-first waves issue everything
+    constexpr int split = Q < 3 ? (kDmaFirst < units ? kDmaFirst : units) : units;
+    if (!late) mx_make_b<true>(acc1[2 * Q], acc1[2 * Q + 1], b, MxDma{src, nxt, 0, split, wave & 3, lane * 16});
+    mx_m_phase<4, false>(cur, lane, acc2, b, l0);
+    if (late && Q < 3) mx_make_b<true>(acc1[Q < 3 ? 2 * Q + 2 : 0], acc1[Q < 3 ? 2 * Q + 3 : 1], b, MxDma{src, nxt, split, units, wave & 3, lane * 16});
+}
+
+__device__ __forceinline__ void mx_load_row(const float *X, int64_t pi, int h, int c0, float (&xr)[8])
+{
+    const float4 *q = reinterpret_cast<const float4 *>(X + pi * kXRow + 8 * h);
+    const float4 a = q[0], c = q[1];
+    xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w; xr[4] = c.x; xr[5] = c.y; xr[6] = c.z; xr[7] = c.w;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xr[s] = (s + 8 * h < c0) ? xr[s] : 0.0f;
 }
 
 template <bool MASK>
-__global__ __launch_bounds__(kMxBlock, 2) void k_mlp_mx6(const float *__restrict__ X, int64_t N, float *__restrict__ out, MlpMx6Dev w)
+__global__ __launch_bounds__(kMxBlock, 2) void k_mlp_mx6(const float *__restrict__ X, int64_t N, float *__restrict__ out, MlpMx6Dev w,
+                                                         int ntiles)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
-    const bool late = wave >= 4;                  // waves w and w+4 share a SIMD
-    const int64_t base = ((int64_t)blockIdx.x * (kMxBlock / 64) + wave) * 32;
-    const int64_t pi = min(base + j, N - 1);      // waves past the end still help with the DMA + barriers
+    const bool late = wave < 4;                   // waves w and w+4 share a SIMD; the older one (arbitration winner) multiplies first
 
     mx_issue_units(w.image, smem + kMxW0Off, kMxW0Bytes / 1024, wave, lane);     // resident layer-0 operands
     float *side = reinterpret_cast<float *>(smem + kMxSideOff);
     for (int i = threadIdx.x; i < kMxSideFloats; i += kMxBlock) side[i] = w.side[i];
     const float *sb0 = side, *sb1 = side + 512, *sb2 = side + 768, *sw3 = side + 896;
 
-    half8 xhi, xlo;
+    MxL0 l0;
+    l0.W0 = smem + kMxW0Off; l0.sb0 = sb0; l0.h = h; l0.cn = 0;
+    int tile = blockIdx.x;
     {
+        const int64_t base = ((int64_t)tile * (kMxBlock / 64) + wave) * 32;
         float xr[8];
-        const float4 *q = reinterpret_cast<const float4 *>(X + pi * kXRow + 8 * h);
-        const float4 a = q[0], b = q[1];
-        xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w; xr[4] = b.x; xr[5] = b.y; xr[6] = b.z; xr[7] = b.w;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) xr[s] = (s + 8 * h < w.c0) ? xr[s] : 0.0f;
-        mx_split8(xr, xhi, xlo);
+        mx_load_row(X, min(base + j, N - 1), h, w.c0, xr);
+        mx_split8(xr, l0.xhi, l0.xlo);
     }
     mx_issue_chunk(w.image, smem, 0, wave, lane);
     mx_dma_wait();
-    __syncthreads();   // side arrays visible, W0 + chunk 0 landed (the barrier's release waits for the LDS-DMA)
+    __syncthreads();   // side arrays visible, W0 + chunk 0 landed
 
-    f32x16 acc1[8];
+    int iter = 0;
+    for (; tile < ntiles; tile += gridDim.x, ++iter) {
+        unsigned long long *tr = (w.trace && blockIdx.x == 0 && iter == 1 && lane == 0) ? w.trace + wave * 64 : nullptr;
+        MX_STAMP(0)
+        const int64_t base = ((int64_t)tile * (kMxBlock / 64) + wave) * 32;
+        const int64_t pi = min(base + j, N - 1);      // waves past the end still help with the DMA + barriers
+        f32x16 acc1[8];
 #pragma unroll
-    for (int m = 0; m < 8; ++m) acc1[m] = mx_ld16(sb1 + (m * 2 + h) * 16);
+        for (int m = 0; m < 8; ++m) acc1[m] = mx_ld16(sb1 + (m * 2 + h) * 16);
 
-    // ---- layers 0 + 1: one chunk = 64 hidden channels ---------------------------------------------
-    MxB b;
-    if (late) mx_v_l1(smem + kMxW0Off, sb0, 0, xhi, xlo, w.inv0, h, lane, b);
-    else { b.hi = (half32)(_Float16)0; b.h6 = i32x8{0, 0, 0, 0, 0, 0, 0, 0}; b.l6 = b.h6; b.sh = 127; b.sl = 127; }
-    for (int k = 0; k < 8; ++k) {
-        mx_l1_step(smem + (k & 1) * kMxBuf, smem + ((k + 1) & 1) * kMxBuf, smem + kMxW0Off, sb0, w.image, k, acc1, xhi, xlo,
-                   w.inv0, w.inv1, h, lane, wave, late, b);
+        // ---- layers 0 + 1: one chunk = 64 hidden channels ---------------------------------------------
+        MxB b;
+        l0.h0n[0] = mx_l0_tile(l0.W0, sb0, 0, l0.xhi, l0.xlo, h, lane);
+        l0.h0n[1] = mx_l0_tile(l0.W0, sb0, 1, l0.xhi, l0.xlo, h, lane);
+        if (late) mx_make_b<false>(l0.h0n[0], l0.h0n[1], b, MxDma{nullptr, nullptr, 0, 0, 0, 0});
+        else { b.hi = (half32)(_Float16)0; b.h6 = i32x8{0, 0, 0, 0, 0, 0, 0, 0}; b.l6 = b.h6; b.sh = 127; b.sl = 127; }
+        MX_STAMP(1)
+        for (int k = 0; k < 8; ++k) {
+            mx_l1_step(smem + (k & 1) * kMxBuf, smem + ((k + 1) & 1) * kMxBuf, w.image, k, acc1, l0, lane, wave, late, b, tr ? tr + 2 + 4 * k : nullptr);
+            mx_dma_wait();
+            MX_STAMP(2 + 4 * k + 2)
+            __syncthreads();   // all waves done with this buffer AND the next chunk has landed
+            MX_STAMP(2 + 4 * k + 3)
+        }
+
+        // ---- layer 2: K = 256 (registers) + 16 (raw input) ---------------------------------------------
+        f32x16 acc2[4];
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = mx_ld16(sb2 + (m2 * 2 + h) * 16);
+        mx_l2_step<0>(smem, smem + kMxBuf, w.image, acc1, acc2, l0, lane, wave, late, b);
         mx_dma_wait();
-    __syncthreads();   // all waves done with this buffer AND the next chunk has landed
-    }
+        __syncthreads();
+        MX_STAMP(34)
+        mx_l2_step<1>(smem + kMxBuf, smem, w.image, acc1, acc2, l0, lane, wave, late, b);
+        mx_dma_wait();
+        __syncthreads();
+        MX_STAMP(35)
+        mx_l2_step<2>(smem, smem + kMxBuf, w.image, acc1, acc2, l0, lane, wave, late, b);
+        mx_dma_wait();
+        __syncthreads();
+        MX_STAMP(36)
+        // last step: this tile's input row again (raw-input k-step, layer 3) and the next tile's
+        // (chunk 0 of the next tile goes into the free buffer from inside the last MFMA phase)
+        float xr[8], xn[8];
+        float maskf = 1.0f;
+        {
+            const float *Xp = X;
+            asm volatile("" : "+s"(Xp));      // fresh loads, not values kept alive across the layers
+            mx_load_row(Xp, pi, h, w.c0, xr);
+            const int64_t nbase = ((int64_t)(tile + gridDim.x) * (kMxBlock / 64) + wave) * 32;
+            mx_load_row(Xp, min(nbase + j, N - 1), h, w.c0, xn);
+            if (MASK) {
+                const uint32_t code = (uint32_t)__float_as_int(Xp[pi * kXRow + kCodeSlot]);
+                maskf = (code & kCodeInCube) ? 1.0f : 0.0f;
+            }
+        }
+        mx_l2_step<3>(smem + kMxBuf, smem, w.image, acc1, acc2, l0, lane, wave, late, b);
+        MX_STAMP(37)
 
-    // ---- layer 2: K = 256 (registers) + 16 (raw input) ---------------------------------------------
-    f32x16 acc2[4];
+        // raw-input k-step of layer 2 (3 x f16) and layer 3 on the VALU
+        {
+            const char *L = smem + kMxBuf + MxLay<4>::RAW;
 #pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = mx_ld16(sb2 + (m2 * 2 + h) * 16);
-    mx_l2_step<0>(smem, smem + kMxBuf, w.image, acc1, acc2, w.inv1, lane, wave, late, b);
-    mx_dma_wait();
-    __syncthreads();
-    mx_l2_step<1>(smem + kMxBuf, smem, w.image, acc1, acc2, w.inv1, lane, wave, late, b);
-    mx_dma_wait();
-    __syncthreads();
-    mx_l2_step<2>(smem, smem + kMxBuf, w.image, acc1, acc2, w.inv1, lane, wave, late, b);
-    mx_dma_wait();
-    __syncthreads();
-    mx_l2_step<3>(smem + kMxBuf, smem, w.image, acc1, acc2, w.inv1, lane, wave, late, b);
-
-    // raw-input k-step of layer 2 (3 x f16) and layer 3 on the VALU; the input row is re-read here
-    // (no LDS-DMA is in flight any more) instead of being kept in registers through layers 1-2
-    float xr[8];
-    {
-        const float *Xp = X;
-        asm volatile("" : "+s"(Xp));      // a fresh load, not the prologue's value kept alive across layers 1-2
-        const float4 *q = reinterpret_cast<const float4 *>(Xp + pi * kXRow + 8 * h);
-        const float4 a = q[0], c = q[1];
-        xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w; xr[4] = c.x; xr[5] = c.y; xr[6] = c.z; xr[7] = c.w;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) xr[s] = (s + 8 * h < w.c0) ? xr[s] : 0.0f;
-        mx_split8(xr, xhi, xlo);
-    }
-    {
-        const char *L = smem + kMxBuf + MxLay<4>::RAW;
+            for (int m2 = 0; m2 < 4; ++m2) {
+                const half8 a_hi = mx_op(L, 2 * m2, lane), a_lo = mx_op(L, 2 * m2 + 1, lane);
+                acc2[m2] = MX_MFMA16(a_hi, l0.xhi, acc2[m2]);
+                acc2[m2] = MX_MFMA16(a_hi, l0.xlo, acc2[m2]);
+                acc2[m2] = MX_MFMA16(a_lo, l0.xhi, acc2[m2]);
+            }
+        }
+        const float *w3 = sw3 + h * 72;
+        float part = 0.0f;
 #pragma unroll
         for (int m2 = 0; m2 < 4; ++m2) {
-            const half8 a_hi = mx_op(L, 2 * m2, lane), a_lo = mx_op(L, 2 * m2 + 1, lane);
-            acc2[m2] = MX_MFMA16(a_hi, xhi, acc2[m2]);
-            acc2[m2] = MX_MFMA16(a_hi, xlo, acc2[m2]);
-            acc2[m2] = MX_MFMA16(a_lo, xhi, acc2[m2]);
+            const f32x16 wv = mx_ld16(w3 + m2 * 16);
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                const float x = acc2[m2][t];
+                part = fmaf(wv[t], fmaxf(x, 0.01f * x), part);
+            }
         }
-    }
-    float maskf = 1.0f;
-    if (MASK) {
-        const uint32_t code = (uint32_t)__float_as_int(X[pi * kXRow + kCodeSlot]);
-        maskf = (code & kCodeInCube) ? 1.0f : 0.0f;
-    }
-    const float *w3 = sw3 + h * 72;
-    float part = 0.0f;
 #pragma unroll
-    for (int m2 = 0; m2 < 4; ++m2) {
-        const f32x16 wv = mx_ld16(w3 + m2 * 16);
-#pragma unroll
-        for (int t = 0; t < 16; ++t) {
-            const float x = acc2[m2][t] * w.inv2;
-            part = fmaf(wv[t], fmaxf(x, 0.01f * x), part);
-        }
+        for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
+        const float other = __shfl_xor(part, 32);
+        const float y = (part + other) + w.b3;
+        if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
+
+        mx_split8(xn, l0.xhi, l0.xlo);
+        MX_STAMP(38)
+        mx_dma_wait();
+        MX_STAMP(39)
+        __syncthreads();   // chunk 0 of the next tile landed; everyone is done with the raw-input operands
+        MX_STAMP(40)
     }
-#pragma unroll
-    for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
-    const float other = __shfl_xor(part, 32);
-    const float y = (part + other) + w.b3;
-    if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -427,7 +516,17 @@ static uint8_t fp6_block(const float *v, uint32_t *out6)
 int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st)
 {
     const int c0 = m->c0;
-    const float s0 = pick_scale(W[0]), s1 = pick_scale(W[1]), s2 = pick_scale(W[2]);
+    // power-of-two weight scales: 1 unless a layer's weights are tiny (f16 would lose their low bits).
+    // Accumulators of layer l carry s_l; LeakyReLU is positively homogeneous, so the next layer's
+    // weights are packed as W * s_{l+1} / s_l and nothing is rescaled at run time.
+    auto lift = [](const std::vector<float> &Wl) {
+        float mx = 0.f;
+        for (float v : Wl) mx = std::max(mx, std::fabs(v));
+        if (!(mx > 0.f) || !std::isfinite(mx) || mx >= 0.015625f) return 1.0f;
+        int ex; (void)std::frexp(mx, &ex);
+        return std::ldexp(1.0f, std::min(1 - ex, 24));        // brings max|W| into [1, 2)
+    };
+    const float s0 = lift(W[0]), s1 = lift(W[1]), s2 = lift(W[2]);
     std::vector<uint8_t> img(kMxImageBytes, 0);
     auto rho = [](int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; };
     auto put16 = [&](size_t byte_off, int lane, int e, uint16_t v) { memcpy(&img[byte_off + (size_t)lane * 16 + 2 * e], &v, 2); };
@@ -474,8 +573,8 @@ int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const st
                 img[cb + sc + (size_t)lane * (2 * nt) + nt + tile] = el;
             }
     };
-    for (int c = 0; c < 8; ++c) pack_chunk(c, 8, W[1], 512, 64 * c, s1);
-    for (int q = 0; q < 4; ++q) pack_chunk(8 + q, 4, W[2], ci2, 64 * q, s2);
+    for (int c = 0; c < 8; ++c) pack_chunk(c, 8, W[1], 512, 64 * c, s1 / s0);
+    for (int q = 0; q < 4; ++q) pack_chunk(8 + q, 4, W[2], ci2, 64 * q, s2 / s1);
 
     std::vector<float> side(kMxSideFloats, 0.f);
     float *b0 = side.data(), *b1 = b0 + 512, *b2 = b1 + 256, *w3 = b2 + 128;
@@ -487,7 +586,7 @@ int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const st
         }
     for (int h = 0; h < 2; ++h) {
         for (int m2 = 0; m2 < 4; ++m2)
-            for (int t = 0; t < 16; ++t) w3[h * 72 + m2 * 16 + t] = W[3][32 * m2 + rho(t, h)];
+            for (int t = 0; t < 16; ++t) w3[h * 72 + m2 * 16 + t] = W[3][32 * m2 + rho(t, h)] / s2;
         for (int s = 0; s < 8; ++s) w3[h * 72 + 64 + s] = (s + 8 * h < c0) ? W[3][128 + s + 8 * h] : 0.f;
     }
     const size_t side_bytes = side.size() * sizeof(float);
@@ -504,17 +603,39 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
     MlpMx6Dev w;
     w.image = mlp->d_mx6;
     w.side = reinterpret_cast<const float *>(mlp->d_mx6 + kMxImageBytes);
-    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
-    const int64_t nb = (N + kMxPts - 1) / kMxPts;
-    ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
-    static bool attr_set = false;
-    if (!attr_set) {
+    w.b3 = mlp->b3; w.c0 = mlp->c0; w.trace = nullptr;
+    static const bool want_trace = getenv("ICON_AMD_MX6_TRACE") != nullptr;
+    if (want_trace) { ICON_HIP(hipMalloc((void **)&w.trace, 8 * 64 * 8)); ICON_HIP(hipMemsetAsync(w.trace, 0, 8 * 64 * 8, st)); }
+    const int64_t nt = (N + kMxPts - 1) / kMxPts;
+    ICON_ARG(nt < (1ll << 31), "mlp: N too large for one launch");
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        ICON_HIP(hipGetDevice(&dev));
+        ICON_HIP(hipGetDeviceProperties(&prop, dev));
+        n_cu = prop.multiProcessorCount;
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
-        attr_set = true;
     }
-    if (mask) hipLaunchKernelGGL(k_mlp_mx6<true>, dim3((unsigned)nb), dim3(kMxBlock), kMxLds, st, d_x, N, d_out, w);
-    else      hipLaunchKernelGGL(k_mlp_mx6<false>, dim3((unsigned)nb), dim3(kMxBlock), kMxLds, st, d_x, N, d_out, w);
+    const unsigned nb = (unsigned)std::min<int64_t>(nt, n_cu);      // one persistent workgroup per CU (LDS-limited)
+    if (mask) hipLaunchKernelGGL(k_mlp_mx6<true>, dim3(nb), dim3(kMxBlock), kMxLds, st, d_x, N, d_out, w, (int)nt);
+    else      hipLaunchKernelGGL(k_mlp_mx6<false>, dim3(nb), dim3(kMxBlock), kMxLds, st, d_x, N, d_out, w, (int)nt);
+    if (want_trace) {
+        unsigned long long t[8 * 64];
+        ICON_HIP(hipStreamSynchronize(st));
+        ICON_HIP(hipMemcpy(t, w.trace, sizeof(t), hipMemcpyDeviceToHost));
+        (void)hipFree(w.trace);
+        for (int wv = 0; wv < 8; wv += 4) {
+            const unsigned long long *r = t + wv * 64;
+            fprintf(stderr, "mx6 trace wave %d (cycles): V0 %llu |", wv, r[1] - r[0]);
+            for (int k = 0; k < 8; ++k)
+                fprintf(stderr, " k%d issue %llu M %llu V %llu wait %llu bar %llu |", k, r[2 + 4 * k] - (k ? r[2 + 4 * k - 1] : r[1]),
+                        r[3 + 4 * k] - r[2 + 4 * k], r[4 + 4 * k] - r[3 + 4 * k], 0ull, r[5 + 4 * k] - r[4 + 4 * k]);
+            fprintf(stderr, " L2 steps %llu %llu %llu %llu | epilogue %llu dma-wait %llu barrier %llu | tile total %llu\n", r[34] - r[33], r[35] - r[34],
+                    r[36] - r[35], r[37] - r[36], r[38] - r[37], r[39] - r[38], r[40] - r[39], r[40] - r[0]);
+        }
+    }
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
