@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--res", type=int, default=257)
     ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "mx6"])
+    ap.add_argument("--precision", default="mx6", choices=["f32", "f16x3", "mx6"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 

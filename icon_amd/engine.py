@@ -189,7 +189,7 @@ class MlpHandle(_Handle):
                                          bn_ptrs[2], bn_ptrs[3], C.c_float(bn_eps), _stream(), C.byref(self.h)),
               "icon_mlp_create")
 
-    def forward(self, x: torch.Tensor, precision: str = "f16x3") -> torch.Tensor:
+    def forward(self, x: torch.Tensor, precision: str = "mx6") -> torch.Tensor:
         """MLP.forward on point-major rows x [N,16] (slots >= c0 ignored) -> [N]"""
         x = _dev_f32(x, "x")
         if x.dim() != 2 or x.shape[1] != 16:
@@ -234,7 +234,7 @@ class IconQueryEngine:
 
     def __init__(self, prior_type: str = "icon", sdf_clip: float = 0.05,
                  smpl_feats: Sequence[str] = ("sdf", "norm", "vis", "cmap"),
-                 cmap_mode: str = "reference", search: str = "bvh", precision: str = "f16x3",
+                 cmap_mode: str = "reference", search: str = "bvh", precision: str = "mx6",
                  res_layers: Sequence[int] = (2, 3, 4)):
         if prior_type not in _lib.PRIOR:
             raise IconAmdError(f"unknown prior_type {prior_type!r}")
