@@ -31,6 +31,7 @@ SYMBOLS = [
     "icon_query_points",
     "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish",
     "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_debug_traversal_stats",
+    "icon_visibility",
 ]
 
 _lib = None

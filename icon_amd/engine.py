@@ -421,3 +421,28 @@ def query_func(opt, netG, features, points, proj_matrix=None):
     if type(preds) is list:
         preds = preds[0]
     return preds
+
+
+def get_visibility(xy: torch.Tensor, z: torch.Tensor, faces: torch.Tensor, image_size: int = 2 ** 12) -> torch.Tensor:
+    """Drop-in for ``lib.dataset.mesh_util.get_visibility`` (mesh_util.py:280-316): ``xy [N,2]``,
+    ``z [N,1]``, ``faces [F,3]`` -> ``vis_mask [N,1]`` float32 in {0,1} (1 = the vertex belongs to a
+    face that owns a pixel of the 4096^2 orthographic rasterisation; ``faces[-1]`` is always marked,
+    as in the reference).  Inputs may live on the host (the reference's call sites pass CPU tensors,
+    TestDataset.py:134-137) - they are moved to the current HIP device; the result comes back on
+    the device of ``z``.  No pytorch3d involved."""
+    if not torch.cuda.is_available():
+        raise IconAmdError("get_visibility needs the HIP device (there is no CPU fallback)")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    out_dev = z.device
+    xy_d = xy.detach().to(dev, torch.float32).reshape(-1, 2).contiguous()
+    z_d = z.detach().to(dev, torch.float32).reshape(-1).contiguous()
+    f_d = faces.detach().to(dev, torch.int64).reshape(-1, 3).contiguous()
+    if xy_d.shape[0] != z_d.shape[0]:
+        raise IconAmdError("get_visibility: xy and z disagree on the vertex count")
+    if f_d.numel() and (int(f_d.min()) < 0 or int(f_d.max()) >= z_d.shape[0]):
+        raise IconAmdError("get_visibility: face index out of range")
+    vis = torch.empty(z_d.shape[0], device=dev, dtype=torch.float32)
+    _lib.check(_lib.lib().icon_visibility(C.c_void_p(xy_d.data_ptr()), C.c_void_p(z_d.data_ptr()), C.c_int64(z_d.shape[0]),
+                                          C.c_void_p(f_d.data_ptr()), C.c_int64(f_d.shape[0]), C.c_int(int(image_size)),
+                                          C.c_void_p(vis.data_ptr()), _stream()), "icon_visibility")
+    return vis[:, None].to(out_dev)

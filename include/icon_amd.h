@@ -214,6 +214,14 @@ int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, v
                   int64_t *n_verts, int64_t *n_faces);
 int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream);
 
+/* ---- SMPL vertex visibility ----------------------------------------------------------------------
+ * replaces get_visibility (lib/dataset/mesh_util.py:280-316: pytorch3d rasterisation at 2^12 squared,
+ * cull_backfaces, 1 face per pixel; vis[faces[unique(pix_to_face)]] = 1, faces[-1] included).
+ * d_xy [V,2], d_z [V] exactly as the reference passes them (TestDataset.py:136-137 passes -z),
+ * d_faces [F,3] int64, d_vis [V] float32 out in {0,1}.  Synchronises the stream (frees its z-buffer). */
+int icon_visibility(const float *d_xy, const float *d_z, int64_t V, const int64_t *d_faces, int64_t F,
+                    int image_size, float *d_vis, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -202,3 +202,15 @@ def query_vol(feat, vol, mlp: Mlp, pts, calib=None, f64=False):
                         C.c_int(Hv), C.c_int(Wv), C.byref(mlp.struct), _p(cal), _p(pts), C.c_int64(n),
                         _p(occ), _p(X), C.c_int(int(f64)))
     return occ, X
+
+
+def visibility(xy, z, faces, image_size: int = 4096, return_faces: bool = False):
+    """get_visibility (lib/dataset/mesh_util.py:280-316): xy [V,2], z [V] or [V,1], faces [F,3] ->
+    vis [V,1] float32 in {0,1} (and the winning face per pixel of the [0,1]^2 quadrant)."""
+    xy, z, faces = _f32(xy).reshape(-1, 2), _f32(z).reshape(-1), _i64(faces).reshape(-1, 3)
+    vis = np.empty(len(xy), np.float32)
+    h = image_size // 2
+    pf = np.empty((h, h), np.int64) if return_faces else None
+    lib().orc_visibility(_p(xy), _p(z), C.c_int64(len(xy)), _p(faces), C.c_int64(len(faces)), C.c_int(image_size),
+                         _p(vis), _p(pf) if return_faces else None)
+    return (vis[:, None], pf) if return_faces else vis[:, None]

@@ -1,0 +1,124 @@
+"""get_visibility (lib/dataset/mesh_util.py:280-316) - SURVEY.md section 8f row 3.
+
+The rasteriser under the reference function is pytorch3d (absent, unpinned): the oracle restates
+its published per-pixel rule (oracle/icon_oracle.c: orc_visibility, "PARITY UNPINNED" for the leaf).
+CPU tests pin the oracle against an independent float64 z-buffer and against geometric facts; the
+GPU tests require the HIP rasteriser to return exactly the oracle's vertex set."""
+import numpy as np
+import pytest
+import torch
+
+from common import assets, orc, synth
+
+
+def _brute_pixel_faces(xy, z, faces, S):
+    """independent float64 z-buffer of the same rule (vectorised over pixels, loop over faces)"""
+    X = (xy[:, 0].astype(np.float64) + 1) / 2; Y = (xy[:, 1].astype(np.float64) + 1) / 2; Z = (-z.astype(np.float64) + 1) / 2
+    H = S // 2
+    c = -1 + (2 * np.arange(H, S) + 1) / S
+    PX, PY = np.meshgrid(c, c)
+    best = np.full((H, H), np.inf); bf = np.full((H, H), -1)
+
+    def ef(px, py, ax, ay, bx, by):
+        return (px - ax) * (by - ay) - (py - ay) * (bx - ax)
+    for fi, (a, b, cc) in enumerate(faces):
+        area = ef(X[cc], Y[cc], X[a], Y[a], X[b], Y[b])
+        if area <= 1e-8:
+            continue
+        w0 = ef(PX, PY, X[b], Y[b], X[cc], Y[cc]) / area; w1 = ef(PX, PY, X[cc], Y[cc], X[a], Y[a]) / area
+        w2 = ef(PX, PY, X[a], Y[a], X[b], Y[b]) / area
+        t0 = w0 * Z[b] * Z[cc]; t1 = Z[a] * w1 * Z[cc]; t2 = Z[a] * Z[b] * w2
+        dn = np.maximum(t0 + t1 + t2, 1e-8)
+        pz = (t0 * Z[a] + t1 * Z[b] + t2 * Z[cc]) / dn
+        m = (w0 > 0) & (w1 > 0) & (w2 > 0) & (pz >= 0) & (pz < best)
+        best[m] = pz[m]; bf[m] = fi
+    return bf
+
+
+def _mesh(name):
+    if name == "body":
+        a = assets("body")
+        return a.smpl_verts[0], a.smpl_faces[0]
+    v, f = synth.icosphere(3, radius=0.55, center=(0.05, -0.1, 0.02))
+    return v.astype(np.float32), f.astype(np.int64)
+
+
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+@pytest.mark.parametrize("size", [128, 512])
+def test_oracle_pixels_match_float64_zbuffer(mesh, size):
+    v, f = _mesh(mesh)
+    _, pf = orc.visibility(v[:, :2], -v[:, 2], f, size, return_faces=True)
+    bf = _brute_pixel_faces(v[:, :2], -v[:, 2], f, size)
+    # float32 vs float64 may disagree on a pixel centre that lies within rounding of an edge
+    assert (pf != bf).mean() <= 2e-4
+
+
+def test_oracle_convex_mesh_visible_set_is_the_front_hemisphere():
+    """on a convex mesh nothing is occluded: visible faces = front faces (those the culling keeps),
+    provided they are large enough to own a pixel centre"""
+    v, f = _mesh("ico")
+    vis = orc.visibility(v[:, :2], -v[:, 2], f, 4096)[:, 0]
+    tri = v[f].astype(np.float64)
+    nz = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])[:, 2]
+    # get_visibility(xy, -z): NDC z = world z, nearest = smallest z, kept faces have n_z < 0 (see oracle header)
+    def verts_of(mask):
+        out = np.zeros(len(v), bool)
+        out[np.unique(f[mask])] = True
+        out[f[-1]] = True                          # faces[-1] (background index) is always marked
+        return out
+    got = vis > 0.5
+    assert not (got & ~verts_of(nz < 0)).any()      # nothing behind the silhouette
+    assert not (verts_of(nz < -1e-4) & ~got).any()  # every front face that is more than a grazing sliver
+
+
+def test_oracle_marks_last_face_and_flips_with_depth_sign():
+    v, f = _mesh("body")
+    vis_a = orc.visibility(v[:, :2], -v[:, 2], f, 2048)[:, 0] > 0.5
+    assert vis_a[f[-1]].all()
+    # reversing depth AND winding shows the other side of the body: the two sets cover all vertices
+    # and overlap only along the silhouette
+    vis_b = orc.visibility(v[:, :2], v[:, 2], f[:, [0, 2, 1]], 2048)[:, 0] > 0.5
+    assert (vis_a | vis_b).mean() > 0.995
+    assert (vis_a & vis_b).mean() < 0.12
+    assert 0.4 < vis_a.mean() < 0.6
+
+
+def test_oracle_resolution_convergence():
+    """the visible set at 4096 (the reference's size) contains the one at 1024 except near the silhouette"""
+    v, f = _mesh("body")
+    hi = orc.visibility(v[:, :2], -v[:, 2], f, 4096)[:, 0] > 0.5
+    lo = orc.visibility(v[:, :2], -v[:, 2], f, 1024)[:, 0] > 0.5
+    assert (lo & ~hi).mean() < 2e-3 and (hi & ~lo).mean() < 0.05
+
+
+# ---------------------------------------------------------------------------------------------
+# GPU
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+@pytest.mark.parametrize("size", [64, 1024, 4096])
+@pytest.mark.parametrize("neg", [True, False])
+def test_gpu_visibility_equals_oracle(mesh, size, neg):
+    from icon_amd.engine import get_visibility
+    v, f = _mesh(mesh)
+    z = -v[:, 2:3] if neg else v[:, 2:3]
+    ref = orc.visibility(v[:, :2], z, f, size)
+    out = get_visibility(torch.from_numpy(v[:, :2].copy()), torch.from_numpy(z.copy()), torch.from_numpy(f), image_size=size)
+    assert out.shape == (len(v), 1) and out.dtype == torch.float32 and out.device.type == "cpu"
+    assert np.array_equal(out.numpy(), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_visibility_reference_call_pattern_and_errors():
+    """TestDataset.compute_vis_cmap: (xy, z) = verts.split([2,1], 1); get_visibility(xy, -z, faces.long())"""
+    from icon_amd.engine import get_visibility, IconAmdError
+    v, f = _mesh("body")
+    verts = torch.from_numpy(v).cuda()
+    xy, z = verts.split([2, 1], dim=1)
+    out = get_visibility(xy, -z, torch.from_numpy(f).cuda().long())
+    assert out.is_cuda and out.shape == (len(v), 1)
+    assert np.array_equal(out.cpu().numpy(), orc.visibility(v[:, :2], -v[:, 2], f, 4096))
+    with pytest.raises(IconAmdError):
+        get_visibility(xy, -z, torch.from_numpy(f + len(v)).cuda())
+    with pytest.raises(IconAmdError):
+        get_visibility(xy[:-1], -z, torch.from_numpy(f).cuda())
