@@ -227,12 +227,12 @@ __device__ __forceinline__ float prune_threshold(float best)
 // `live` = false parks a padding lane: it never votes and its result is discarded.
 template <bool STATS = false>
 __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
-                                                  int *n_nodes = nullptr, int *n_tris = nullptr)
+                                                  int *n_nodes = nullptr, int *n_tris = nullptr, float thr0 = INFINITY)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
     unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
     int slot = 0;
-    float thr = live ? INFINITY : -INFINITY;
+    float thr = live ? thr0 : -INFINITY;
     int sp = 0;
     int cur = 0;
     while (true) {
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
 }
 
 // diagnostics: per-wavefront BVH work of the lattice traversal (DESIGN.md reports visited nodes / point)
-__global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMap L, unsigned long long *out /* [4] */)
+__global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMap L, unsigned long long *out /* [4] */, int seeded)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int ix, iy, iz;
@@ -698,7 +698,19 @@ __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMa
     const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
     const f3 p = lattice_world(L.res, cx, cy, cz + L.z0);
     int nn = 0, nt = 0;
-    const Nearest nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt);
+    Nearest nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt);
+    if (seeded) {       // experiment: the work of a traversal that starts from the final bound (seeded == 1) or from the
+                        // bound a coarse pass would give: best distance at the tile's centre lane + tile radius (seeded == 2)
+        nn = 0; nt = 0;
+        float thr0 = prune_threshold(nr.d2);
+        if (seeded == 2) {
+            const float dc = sqrtf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(nr.d2), 21)));
+            const float h = 2.0f / (float)(L.res - 1);
+            const float rad = 2.6f * h;                       // > half diagonal of a 4x4x4 block (sqrt(3) * 1.5 h)
+            thr0 = prune_threshold((dc + rad) * (dc + rad));
+        }
+        nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt, thr0);
+    }
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(&out[0], 1ull); atomicAdd(&out[1], (unsigned long long)nn); atomicAdd(&out[2], (unsigned long long)nt);
     }
@@ -1204,7 +1216,8 @@ extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int 
     unsigned long long *d = nullptr;
     ICON_HIP(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
     ICON_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(k_traversal_stats, dim3((unsigned)(L.tx * L.ty * L.tz)), dim3(kBlock), 0, 0, mesh->dev, L, d);
+    hipLaunchKernelGGL(k_traversal_stats, dim3((unsigned)(L.tx * L.ty * L.tz)), dim3(kBlock), 0, 0, mesh->dev, L, d,
+                       getenv("ICON_AMD_STATS_SEEDED") ? atoi(getenv("ICON_AMD_STATS_SEEDED")) : 0);
     unsigned long long h[4];
     hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);
