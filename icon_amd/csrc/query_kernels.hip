@@ -837,6 +837,42 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict_
     }
 }
 
+// The same patch with the global sign list left where the all_gather put it: rank r's message is
+// gathered + r * stride = [int64 count_r][int8 signs_r ...] (multi-GPU path, recon.py).  K, this
+// rank's offset and the segment of every index are derived on the device from the headers, so the
+// host never has to read the counts (no synchronisation between the exchange and the MLP launch).
+constexpr int kMaxWorld = 64;
+__global__ __launch_bounds__(kScanBlock) void k_outlier_patch_seg(float *__restrict__ X, const uint8_t *__restrict__ code8, int64_t N, int cmap_slot,
+                                                                  const int64_t *block_offsets, const int8_t *__restrict__ gathered,
+                                                                  int64_t stride, int world, int rank)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    __shared__ int64_t off[kMaxWorld + 1];
+    if (threadIdx.x == 0) {
+        int64_t a = 0;
+        for (int r = 0; r < world; ++r) { off[r] = a; a += *reinterpret_cast<const int64_t *>(gathered + (int64_t)r * stride); }
+        off[world] = a;
+    }
+    __syncthreads();
+    const int64_t K = off[world];
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t code = (i < N) ? code8[i] : 0u;
+    const bool o = code & kCodeOutlier;
+    const int64_t j = off[rank] + outlier_rank(o, block_offsets, wsum);
+    if (o && K > 0) {
+        float *row = X + i * kXRow + cmap_slot;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            int64_t mm = 3 * j + k;                 // j < K  =>  mm < 3K
+            if (mm >= K) mm -= K;
+            if (mm >= K) mm -= K;
+            int r = 0;
+            while (mm >= off[r + 1]) ++r;
+            row[k] = (float)gathered[(int64_t)r * stride + 8 + (mm - off[r])];
+        }
+    }
+}
+
 // repack feature planes [C][H][W] -> [n_select][H][W][cpad] (channel-last, zero padded)
 __global__ void k_pack_planes(const float *__restrict__ src, int C, int H, int W, int n_select, int csel, int cpad, float *dst)
 {
@@ -1198,6 +1234,32 @@ extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int
         const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
         hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
                            work->d_block_offsets, d_signs_global, k_total, rank_offset);
+        ICON_HIP(hipGetLastError());
+    }
+    mark(work, 2, st);
+    work->slab_ready = false;
+    const int rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    mark(work, 3, st);
+    return rc;
+}
+
+extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1,
+                                              const int8_t *d_gathered, int64_t stride, int world, int rank,
+                                              float *d_occ, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(mlp && work && d_occ, "icon_grid_slab_finish_gathered: null argument");
+    ICON_ARG(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "icon_grid_slab_finish_gathered: bad world / rank");
+    ICON_ARG(stride >= 8 && (stride & 7) == 0, "icon_grid_slab_finish_gathered: stride must be a multiple of 8 (int64 header)");
+    if (!work->slab_ready || work->slab_res != res || work->slab_z0 != z0 || work->slab_z1 != z1)
+        return fail(ICON_ERR_STATE, "icon_grid_slab_finish_gathered: no matching icon_grid_slab_features call on this workspace");
+    ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_slab_finish_gathered: MLP input width does not match the feature layout");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)(z1 - z0) * res * res;
+    if (work->slab_needs_patch) {
+        ICON_ARG(d_gathered != nullptr, "icon_grid_slab_finish_gathered: gathered messages are null");
+        const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+        hipLaunchKernelGGL(k_outlier_patch_seg, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
+                           work->d_block_offsets, d_gathered, stride, world, rank);
         ICON_HIP(hipGetLastError());
     }
     mark(work, 2, st);

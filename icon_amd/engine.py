@@ -379,12 +379,17 @@ class IconQueryEngine:
             self._work().h, _stream()), "icon_grid_eval_slab")
         return out
 
-    def slab_features(self, im_feat, res: int, z0: int, z1: int):
-        """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device)"""
+    def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None):
+        """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device);
+        ``signs`` / ``count`` may be views into a caller-owned message buffer (recon.py)."""
         mesh, feat = self._mesh_handle(), self._feat_handle(im_feat)
         n = (z1 - z0) * res * res
-        signs = torch.empty(n, dtype=torch.int8, device=im_feat.device)
-        count = torch.zeros(1, dtype=torch.int64, device=im_feat.device)
+        if signs is None:
+            signs = torch.empty(n, dtype=torch.int8, device=im_feat.device)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64, device=im_feat.device)
+        if signs.numel() < n or signs.dtype != torch.int8 or count.dtype != torch.int64 or not signs.is_contiguous():
+            raise IconAmdError("slab_features: signs must be a contiguous int8 buffer of >= slab points, count int64")
         check(_lib.lib().icon_grid_slab_features(
             mesh.h if mesh is not None else C.c_void_p(0), feat.h, C.c_int(_lib.PRIOR[self.prior_type]),
             C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
@@ -402,6 +407,19 @@ class IconQueryEngine:
             mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), ptr(signs_global) if signs_global is not None else C.c_void_p(0),
             C.c_int64(k_total), C.c_int64(rank_offset), ptr(out), C.c_int(_lib.PRECISION[self.precision]),
             self._work().h, _stream()), "icon_grid_slab_finish")
+        return out
+
+
+    def slab_finish_gathered(self, res: int, z0: int, z1: int, gathered: torch.Tensor, stride: int, world: int, rank: int,
+                             regressor=None, out=None) -> torch.Tensor:
+        """Phase 2 on the all_gather output itself: ``gathered`` int8 [world * stride], message r =
+        [int64 count_r][int8 signs_r]; nothing is read back to the host."""
+        mlp = self._mlp_handle(regressor)
+        if out is None:
+            out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=gathered.device)
+        check(_lib.lib().icon_grid_slab_finish_gathered(
+            mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), ptr(gathered), C.c_int64(stride), C.c_int(world), C.c_int(rank),
+            ptr(out), C.c_int(_lib.PRECISION[self.precision]), self._work().h, _stream()), "icon_grid_slab_finish_gathered")
         return out
 
 

@@ -155,7 +155,21 @@ class DenseReconEngine(nn.Module):
         dev = im_feat.device
         slab = torch.zeros((per, res, res), dtype=torch.float32, device=dev)
         need_exchange = getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
-        if need_exchange:
+        if need_exchange and hasattr(be, "slab_finish_gathered"):
+            # ONE collective, no host synchronisation: every rank contributes a fixed-size message
+            # [int64 count][int8 signs, padded to the largest slab]; phase 1 writes straight into it and
+            # phase 2 consumes the gathered buffer as it is (K, rank offset and segment lookup happen
+            # in the patch kernel), so the exchange and the MLP launch are enqueued back to back.
+            stride = 8 + (per * res * res + 7) // 8 * 8
+            msg = torch.zeros(stride, dtype=torch.int8, device=dev)
+            n = (z1 - z0) * res * res
+            if z1 > z0:
+                be.slab_features(im_feat, res, z0, z1, signs=msg[8:8 + n], count=msg[:8].view(torch.int64))
+            gathered = self._all_gather_cat(dist, msg, world, g)
+            if z1 > z0:
+                be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0])
+            self.last_stats = dict(exchanged_bytes=stride * world, collectives=2)   # sign messages + the volume
+        elif need_exchange:
             if z1 > z0:
                 signs, count = be.slab_features(im_feat, res, z0, z1)
             else:

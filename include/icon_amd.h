@@ -189,6 +189,13 @@ int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
 int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
                           const int8_t *d_signs_global, int64_t k_total, int64_t rank_offset,
                           float *d_occ, int precision, icon_work_t *work, void *stream);
+/* The same phase 2 with the sign lists left where ONE all_gather put them: rank r's message is
+ * d_gathered + r * stride = [int64 count_r][int8 signs_r[count_r] ...] (what icon_grid_slab_features
+ * writes when d_signs = msg + 8 and d_count = msg).  K, the rank offset and the segment of every
+ * index are computed on the device: no host read of the counts between the exchange and the MLP. */
+int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1,
+                                   const int8_t *d_gathered, int64_t stride, int world, int rank,
+                                   float *d_occ, int precision, icon_work_t *work, void *stream);
 
 /* Diagnostics (synchronises): BVH work of the lattice traversal over planes [z0,z1):
  * out[0] = wavefronts (4x4x4 point blocks), out[1] = BVH nodes visited, out[2] = triangles tested,

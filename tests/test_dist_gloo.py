@@ -49,12 +49,31 @@ class OracleBackend:
             return out
         return t
 
-    def slab_features(self, im_feat, res, z0, z1):
+    def slab_features(self, im_feat, res, z0, z1, signs=None, count=None):
         self.calls.append(("features", z0, z1))
         lst = self._local_list(z0, z1)
-        signs = torch.zeros((z1 - z0) * res * res, dtype=torch.int8)
+        if signs is None:
+            signs = torch.zeros((z1 - z0) * res * res, dtype=torch.int8)
+        if count is None:
+            count = torch.zeros(1, dtype=torch.int64)
+        assert signs.numel() == (z1 - z0) * res * res and signs.dtype == torch.int8 and count.dtype == torch.int64
         signs[: len(lst)] = torch.from_numpy(lst.copy())
-        return signs, torch.tensor([len(lst)], dtype=torch.int64)
+        signs[len(lst):] = 99                       # garbage past the count must never be used
+        count[0] = len(lst)
+        return signs, count
+
+    def slab_finish_gathered(self, res, z0, z1, gathered, stride, world, rank, out=None):
+        """the single-collective protocol: message r = [int64 count_r][int8 signs_r ...] at r * stride"""
+        self.calls.append(("finish", z0, z1))
+        assert gathered.dtype == torch.int8 and gathered.numel() == world * stride and stride % 8 == 0
+        g = gathered.numpy()
+        counts = [int(g[r * stride: r * stride + 8].view(np.int64)[0]) for r in range(world)]
+        lst = np.concatenate([g[r * stride + 8: r * stride + 8 + c] for r, c in enumerate(counts)])
+        exp = self._local_list(0, res)
+        assert sum(counts) == len(exp)
+        assert np.array_equal(lst, exp), "global sign list differs from lattice order"
+        assert sum(counts[:rank]) == int(self.out_mask[:z0].sum())
+        return self.eval_slab(None, res, z0, z1, out=out)
 
     def slab_finish(self, res, z0, z1, signs_global, k_total, rank_offset, out=None, device=None):
         self.calls.append(("finish", z0, z1))
@@ -73,7 +92,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cmap_mode, q):
+def _worker(rank, world, port, cmap_mode, q, legacy=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -82,8 +101,18 @@ def _worker(rank, world, port, cmap_mode, q):
         a = assets("ico")
         be = OracleBackend(a, cmap_mode)
         be.cmap_mode = cmap_mode
+        if legacy:
+            class _NoGathered:                   # proxy without slab_finish_gathered -> legacy two-step exchange
+                def __init__(self, inner): self._i = inner
+                def __getattr__(self, name):
+                    if name == "slab_finish_gathered":
+                        raise AttributeError(name)
+                    return getattr(self._i, name)
+            be_used = _NoGathered(be)
+        else:
+            be_used = be
         recon = DenseReconEngine(query_func=None, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
-                                 resolutions=[9, RES], align_corners=True, backend=be)
+                                 resolutions=[9, RES], align_corners=True, backend=be_used)
         occ = recon(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)
         ok = occ is not None and occ.shape == (RES, RES, RES) and np.array_equal(occ.numpy(), be.full)
         z0, z1, _ = slab_bounds(RES, world, rank)
@@ -95,13 +124,13 @@ def _worker(rank, world, port, cmap_mode, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+@pytest.mark.parametrize("cmap_mode,legacy", [("reference", False), ("reference", True), ("local", False)])
 @pytest.mark.parametrize("world", [2, 3])
-def test_zslab_sharding_gloo(cmap_mode, world):
+def test_zslab_sharding_gloo(cmap_mode, legacy, world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, legacy)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

@@ -335,6 +335,35 @@ def test_lattice_slab_split_equals_single_call(body):
     assert np.array_equal(signs.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_lattice_slab_split_gathered_messages(body, world):
+    """the single-collective protocol of the multi-GPU path: every 'rank' writes [int64 count][signs]
+    into a fixed-size message, the concatenation (what all_gather returns) goes to phase 2 as it is"""
+    from icon_amd.recon import slab_bounds
+    res = 33
+    feat = T(body.features)
+    full = make_engine(body).eval_slab(feat, res, 0, res)
+    engines = [make_engine(body) for _ in range(world)]
+    per = slab_bounds(res, world, 0)[2]
+    stride = 8 + (per * res * res + 7) // 8 * 8
+    msgs = []
+    for r, e in enumerate(engines):
+        z0, z1, _ = slab_bounds(res, world, r)
+        msg = torch.full((stride,), 77, dtype=torch.int8, device=dev())      # garbage past the count must not matter
+        msg[:8] = 0
+        n = (z1 - z0) * res * res
+        if z1 > z0:
+            e.slab_features(feat, res, z0, z1, signs=msg[8:8 + n], count=msg[:8].view(torch.int64))
+        msgs.append(msg)
+    gathered = torch.cat(msgs).contiguous()
+    parts = []
+    for r, e in enumerate(engines):
+        z0, z1, _ = slab_bounds(res, world, r)
+        if z1 > z0:
+            parts.append(e.slab_finish_gathered(res, z0, z1, gathered, stride, world, r))
+    assert torch.equal(torch.cat(parts), full)
+
+
 @pytest.mark.parametrize("precision", PRECISIONS)
 def test_lattice_257_properties(body, precision):
     """BASELINE.json's full size (257^3 = 16,974,593 points): size-independent properties"""
