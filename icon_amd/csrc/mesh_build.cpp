@@ -14,7 +14,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <atomic>
 #include <numeric>
+#include <thread>
 
 #include "common.h"
 
@@ -50,23 +52,23 @@ struct Box {
 struct Builder {
     const float *verts;
     const int64_t *faces;
-    std::vector<Box> tbox;
-    std::vector<float> cen;        // [F][3]
-    std::vector<int32_t> order;    // permutation of faces; leaves index into it
+    const Box *tbox;               // [F]
+    const float *cen;              // [F][3]
+    int32_t *order;                // permutation of faces (shared; every (sub)build owns a disjoint range); leaves index into it
     std::vector<BvhNode> nodes;
     std::vector<std::pair<int, int>> leaves;   // (first index into `order`, count 1..kLeafMax)
     int max_depth = 0;
     int leaf_cap = kLeafMax;                   // triangles per leaf (tuning knob ICON_AMD_LEAF, 1..kLeafMax)
 
-    // returns child reference (>=0 node, <0 leaf code); fills `box`
-    int32_t build(int begin, int end, int depth, Box &box)
+    // partitions order[begin, end) (binned SAH, median fallback) and returns the split position;
+    // fills the range's box.  Returns -1 when the range becomes a leaf.
+    int split(int begin, int end, int depth, Box &box)
     {
-        max_depth = std::max(max_depth, depth);
         box = Box();
         Box cb;
         for (int i = begin; i < end; ++i) { box.grow(tbox[order[i]]); cb.grow(&cen[3 * order[i]]); }
         const int n = end - begin;
-        if (n <= leaf_cap) { leaves.emplace_back(begin, n); return ~(int32_t)(((leaves.size() - 1) << 2) | (size_t)(n - 1)); }
+        if (n <= leaf_cap) return -1;
 
         int axis = 0, mid = -1;
         const bool force_median = depth >= kStackDepth - 6;
@@ -96,12 +98,12 @@ struct Builder {
             if (best_axis >= 0) {
                 axis = best_axis;
                 const float lo = cb.lo[axis], ext = cb.hi[axis] - cb.lo[axis];
-                auto it = std::partition(order.begin() + begin, order.begin() + end, [&](int32_t f) {
+                auto it = std::partition(order + begin, order + end, [&](int32_t f) {
                     int b = (int)((cen[3 * f + axis] - lo) / ext * 16);
                     b = std::min(std::max(b, 0), 15);
                     return b <= best_bin;
                 });
-                mid = (int)(it - order.begin());
+                mid = (int)(it - order);
             }
         }
         if (mid <= begin || mid >= end) {   // median split on the widest centroid axis
@@ -109,21 +111,117 @@ struct Builder {
             for (int ax = 1; ax < 3; ++ax)
                 if (cb.hi[ax] - cb.lo[ax] > cb.hi[axis] - cb.lo[axis]) axis = ax;
             mid = begin + n / 2;
-            std::nth_element(order.begin() + begin, order.begin() + mid, order.begin() + end,
+            std::nth_element(order + begin, order + mid, order + end,
                              [&](int32_t a, int32_t b) {
                                  const float ca = cen[3 * a + axis], cb2 = cen[3 * b + axis];
                                  return ca < cb2 || (ca == cb2 && a < b);
                              });
         }
+        return mid;
+    }
+
+    // returns child reference (>=0 node, <0 leaf code); fills `box`.  Nodes and leaves are numbered in
+    // depth-first pre-order.
+    int32_t build(int begin, int end, int depth, Box &box)
+    {
+        max_depth = std::max(max_depth, depth);
+        const int mid = split(begin, end, depth, box);
+        if (mid < 0) { leaves.emplace_back(begin, end - begin); return ~(int32_t)(((leaves.size() - 1) << 2) | (size_t)(end - begin - 1)); }
         const int32_t me = (int32_t)nodes.size();
         nodes.emplace_back();
         Box b0, b1;
         const int32_t c0 = build(begin, mid, depth + 1, b0);
         const int32_t c1 = build(mid, end, depth + 1, b1);
-        BvhNode &nd = nodes[me];
+        set_node(nodes[me], c0, c1, b0, b1);
+        return me;
+    }
+
+    static void set_node(BvhNode &nd, int32_t c0, int32_t c1, const Box &b0, const Box &b1)
+    {
         for (int k = 0; k < 3; ++k) { nd.lo[k][0] = b0.lo[k]; nd.hi[k][0] = b0.hi[k]; nd.lo[k][1] = b1.lo[k]; nd.hi[k][1] = b1.hi[k]; }
         nd.child0 = c0; nd.child1 = c1; nd.pad[0] = nd.pad[1] = 0;
+    }
+
+    // ---- the same tree, built by several threads ---------------------------------------------------
+    // The top of the tree is split sequentially down to kParDepth; every subtree below is an independent
+    // job on a disjoint range of `order` (own node / leaf vectors).  A final pass emits top nodes and
+    // job results in depth-first pre-order with rebased indices, so the arrays are IDENTICAL to what
+    // build() produces (same node numbering, same leaf numbering, same `order`).
+    static constexpr int kParDepth = 5;
+    struct Job { int begin, end, depth; Builder *sub; int32_t ref; Box box; };
+    struct Plan { int mid; int left, right; bool is_job; int job; Box box; };     // index into plans
+
+    int plan(int begin, int end, int depth, std::vector<Plan> &plans, std::vector<Job> &jobs)
+    {
+        const int me = (int)plans.size();
+        plans.emplace_back();
+        if (depth >= kParDepth || end - begin <= 64) {
+            plans[me].is_job = true; plans[me].job = (int)jobs.size();
+            jobs.push_back(Job{begin, end, depth, nullptr, 0, Box()});
+            return me;
+        }
+        Box box;
+        const int mid = split(begin, end, depth, box);
+        if (mid < 0) {          // cannot happen for n > 64 >= leaf_cap, kept for safety: a leaf-sized job
+            plans[me].is_job = true; plans[me].job = (int)jobs.size();
+            jobs.push_back(Job{begin, end, depth, nullptr, 0, Box()});
+            return me;
+        }
+        max_depth = std::max(max_depth, depth);
+        plans[me].is_job = false; plans[me].mid = mid; plans[me].box = box;
+        const int l = plan(begin, mid, depth + 1, plans, jobs);
+        const int r = plan(mid, end, depth + 1, plans, jobs);
+        plans[me].left = l; plans[me].right = r;
         return me;
+    }
+
+    int32_t emit(int pi, const std::vector<Plan> &plans, std::vector<Job> &jobs, Box &box)
+    {
+        const Plan &p = plans[pi];
+        if (p.is_job) {
+            Job &j = jobs[p.job];
+            const int32_t nbase = (int32_t)nodes.size(), lbase = (int32_t)leaves.size();
+            auto rebase = [&](int32_t c) {
+                if (c >= 0) return c + nbase;
+                const int32_t code = ~c;
+                return ~(int32_t)((((code >> 2) + lbase) << 2) | (code & 3));
+            };
+            for (const BvhNode &n : j.sub->nodes) { BvhNode m = n; m.child0 = rebase(n.child0); m.child1 = rebase(n.child1); nodes.push_back(m); }
+            leaves.insert(leaves.end(), j.sub->leaves.begin(), j.sub->leaves.end());
+            max_depth = std::max(max_depth, j.sub->max_depth);
+            box = j.box;
+            return rebase(j.ref);
+        }
+        const int32_t me = (int32_t)nodes.size();
+        nodes.emplace_back();
+        Box b0, b1;
+        const int32_t c0 = emit(p.left, plans, jobs, b0);
+        const int32_t c1 = emit(p.right, plans, jobs, b1);
+        set_node(nodes[me], c0, c1, b0, b1);
+        box = p.box;
+        return me;
+    }
+
+    int32_t build_parallel(int F, Box &box, int n_threads)
+    {
+        std::vector<Plan> plans;
+        std::vector<Job> jobs;
+        const int root = plan(0, F, 0, plans, jobs);
+        std::vector<Builder> subs(jobs.size(), *this);
+        for (size_t i = 0; i < jobs.size(); ++i) { subs[i].nodes.clear(); subs[i].leaves.clear(); subs[i].max_depth = 0; jobs[i].sub = &subs[i]; }
+        std::atomic<int> next{0};
+        auto worker = [&]() {
+            for (int i = next.fetch_add(1); i < (int)jobs.size(); i = next.fetch_add(1)) {
+                Job &j = jobs[i];
+                j.ref = j.sub->build(j.begin, j.end, j.depth, j.box);
+            }
+        };
+        std::vector<std::thread> pool;
+        const int nt = std::max(1, std::min(n_threads, (int)jobs.size()));
+        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+        worker();
+        for (std::thread &t : pool) t.join();
+        return emit(root, plans, jobs, box);
     }
 };
 
@@ -220,18 +318,37 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     // BVH
     Builder bd;
     bd.verts = verts.data(); bd.faces = faces.data();
-    bd.tbox.resize(F); bd.cen.resize(3 * F); bd.order.resize(F);
-    std::iota(bd.order.begin(), bd.order.end(), 0);
+    std::vector<Box> tbox(F);
+    std::vector<float> cen(3 * F);
+    std::vector<int32_t> order(F);
+    std::iota(order.begin(), order.end(), 0);
     Box mesh_box;
     for (int64_t f = 0; f < F; ++f) {
-        for (int k = 0; k < 3; ++k) bd.tbox[f].grow(&verts[3 * faces[3 * f + k]]);
-        for (int k = 0; k < 3; ++k) bd.cen[3 * f + k] = 0.5f * (bd.tbox[f].lo[k] + bd.tbox[f].hi[k]);
-        mesh_box.grow(bd.tbox[f]);
+        for (int k = 0; k < 3; ++k) tbox[f].grow(&verts[3 * faces[3 * f + k]]);
+        for (int k = 0; k < 3; ++k) cen[3 * f + k] = 0.5f * (tbox[f].lo[k] + tbox[f].hi[k]);
+        mesh_box.grow(tbox[f]);
     }
+    bd.tbox = tbox.data(); bd.cen = cen.data(); bd.order = order.data();
     bd.nodes.reserve(F);
     if (const char *e = getenv("ICON_AMD_LEAF")) bd.leaf_cap = std::min(std::max(atoi(e), 1), kLeafMax);
     Box root_box;
-    int32_t root = bd.build(0, (int)F, 0, root_box);
+    // ICON_AMD_BUILD_THREADS (default: up to 16 hardware threads; 1 = the sequential builder, same tree)
+    int n_threads = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("ICON_AMD_BUILD_THREADS")) n_threads = std::max(atoi(e), 1);
+    int32_t root = (n_threads > 1 && F >= 2048) ? bd.build_parallel((int)F, root_box, n_threads) : bd.build(0, (int)F, 0, root_box);
+    if (getenv("ICON_AMD_BUILD_CHECK")) {      // self-test: the threaded builder must reproduce the sequential arrays exactly
+        Builder sq = bd;
+        std::vector<int32_t> order2(F);
+        std::iota(order2.begin(), order2.end(), 0);
+        sq.order = order2.data(); sq.nodes.clear(); sq.leaves.clear(); sq.max_depth = 0;
+        Box rb;
+        const int32_t r2 = sq.build(0, (int)F, 0, rb);
+        const bool same = r2 == root && sq.nodes.size() == bd.nodes.size() && sq.leaves == bd.leaves && order2 == order &&
+                          sq.max_depth == bd.max_depth &&
+                          (sq.nodes.empty() || memcmp(sq.nodes.data(), bd.nodes.data(), sq.nodes.size() * sizeof(BvhNode)) == 0) &&
+                          memcmp(&rb, &root_box, sizeof(Box)) == 0;
+        if (!same) return fail(ICON_ERR_STATE, "icon_mesh_create: threaded BVH build differs from the sequential build");
+    }
     int32_t root_is_leaf = 0;
     if (root < 0) {   // tiny mesh: wrap the single leaf in a node with an empty second child
         BvhNode nd{};
@@ -260,7 +377,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         for (int t = 0; t < kLeafMax; ++t) {
             const int64_t s = L * kLeafMax + t;
             const bool real = t < cnt;
-            const int64_t f = bd.order[begin + std::min(t, cnt - 1)];
+            const int64_t f = order[begin + std::min(t, cnt - 1)];
             const int64_t id[3] = {faces[3 * f], faces[3 * f + 1], faces[3 * f + 2]};
             TriRec &tr = tris[s];
             for (int k = 0; k < 3; ++k) { tr.a[k] = verts[3 * id[0] + k]; tr.b[k] = verts[3 * id[1] + k]; tr.c[k] = verts[3 * id[2] + k]; }
@@ -293,7 +410,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     const float inv_y = (float)gy / (y1 - y0), inv_z = (float)gz / (z1 - z0);
     std::vector<int32_t> bin_start((size_t)gy * gz + 1, 0);
     auto range = [&](int64_t s, int &cy0, int &cy1, int &cz0, int &cz1) {
-        const Box &b = bd.tbox[bd.order[slot_src[s]]];
+        const Box &b = tbox[order[slot_src[s]]];
         cy0 = cell_of(b.lo[1] - eps, y0, inv_y, gy); cy1 = cell_of(b.hi[1] + eps, y0, inv_y, gy);
         cz0 = cell_of(b.lo[2] - eps, z0, inv_z, gz); cz1 = cell_of(b.hi[2] + eps, z0, inv_z, gz);
     };

@@ -335,6 +335,25 @@ def test_lattice_slab_split_equals_single_call(body):
     assert np.array_equal(signs.cpu().numpy(), exp)
 
 
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+def test_threaded_bvh_build_equals_sequential(mesh, monkeypatch):
+    """the multi-threaded SAH builder must emit exactly the sequential builder's arrays (checked inside
+    icon_mesh_create under ICON_AMD_BUILD_CHECK) and, of course, the same query results"""
+    from icon_amd.engine import MeshHandle
+    a = assets(mesh)
+    args = (T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    pts = T(synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 3000, seed=3))
+    monkeypatch.setenv("ICON_AMD_BUILD_THREADS", "1")
+    seq = MeshHandle(*args)
+    monkeypatch.setenv("ICON_AMD_BUILD_THREADS", "7")
+    monkeypatch.setenv("ICON_AMD_BUILD_CHECK", "1")
+    par = MeshHandle(*args)                       # raises if the arrays differ
+    assert seq.stats() == par.stats()
+    o1, o2 = seq.sdf_query(pts), par.sdf_query(pts)
+    for k in o1:
+        assert torch.equal(o1[k], o2[k]), k
+
+
 @pytest.mark.parametrize("world", [2, 3, 5])
 def test_lattice_slab_split_gathered_messages(body, world):
     """the single-collective protocol of the multi-GPU path: every 'rank' writes [int64 count][signs]
