@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -156,6 +157,8 @@ struct icon_mlp {
 };
 
 namespace icon {
+// host helper: fn(i) for i in [0, n) on up to 16 threads (operand packing, BVH subtrees)
+void parallel_for(int n, const std::function<void(int)> &fn);
 // mc_device.hip
 struct McDevState;
 void mc_destroy(McDevState *s);

@@ -27,6 +27,20 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 const char *last_error_cstr() { return g_err.c_str(); }
 
+void parallel_for(int n, const std::function<void(int)> &fn)
+{
+    int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char *e = getenv("ICON_AMD_BUILD_THREADS")) nt = std::max(atoi(e), 1);
+    nt = std::min(nt, n);
+    if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
+    std::atomic<int> next{0};
+    auto worker = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+    worker();
+    for (std::thread &t : pool) t.join();
+}
+
 namespace {
 
 struct V3 { float x, y, z; };

@@ -372,7 +372,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
         img[base + 512 + (size_t)lane * 8 + e] = lo;
     };
     const int ci2 = 256 + c0;
-    for (int lane = 0; lane < 64; ++lane) {
+    parallel_for(64, [&](int lane) {       // every lane owns its own 16-byte column of each slot
         const int i = lane & 31, g = lane >> 5;
         for (int e = 0; e < 8; ++e) {
             // layers 0+1, chunk c
@@ -395,7 +395,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
                 put(19, 32 + m2 * 2, lane, e, slot0 < c0 ? W[2][(size_t)(32 * m2 + i) * ci2 + 256 + slot0] : 0.f, s2);
             }
         }
-    }
+    });
     // f32 side arrays: scaled biases (accumulator initial values) and the last layer
     std::vector<float> side(16 * 2 * 16 + 8 * 2 * 16 + 4 * 2 * 16 + 2 * 72, 0.f);
     float *b0 = side.data(), *b1 = b0 + 512, *b2 = b1 + 256, *w3 = b2 + 128;

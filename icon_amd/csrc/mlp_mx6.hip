@@ -573,8 +573,10 @@ int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const st
                 img[cb + sc + (size_t)lane * (2 * nt) + nt + tile] = el;
             }
     };
-    for (int c = 0; c < 8; ++c) pack_chunk(c, 8, W[1], 512, 64 * c, s1 / s0);
-    for (int q = 0; q < 4; ++q) pack_chunk(8 + q, 4, W[2], ci2, 64 * q, s2 / s1);
+    parallel_for(12, [&](int k) {          // chunks write disjoint parts of the image
+        if (k < 8) pack_chunk(k, 8, W[1], 512, 64 * k, s1 / s0);
+        else pack_chunk(k, 4, W[2], ci2, 64 * (k - 8), s2 / s1);
+    });
 
     std::vector<float> side(kMxSideFloats, 0.f);
     float *b0 = side.data(), *b1 = b0 + 512, *b2 = b1 + 256, *w3 = b2 + 128;
