@@ -162,6 +162,8 @@ void parallel_for(int n, const std::function<void(int)> &fn);
 // mc_device.hip
 struct McDevState;
 void mc_destroy(McDevState *s);
+// sort_points.hip: perm[k] = index of the k-th point in Morton order of the projected positions (device array owned by w)
+int morton_order(icon_work *w, const float *d_points, const float *calib12, int64_t N, hipStream_t st, const int32_t **perm);
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
@@ -190,6 +192,12 @@ struct icon_work {
     int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
     int32_t *d_row_slots = nullptr;       // [rows][kRowCap]
     int64_t cap_rows = 0;
+    // point mode: Morton order of the query points (sort_points.hip), so that a wavefront's 64 points are neighbours
+    uint32_t *d_sort_keys = nullptr;      // [2][cap_sort]
+    int32_t *d_sort_idx = nullptr;        // [2][cap_sort]
+    void *d_sort_tmp = nullptr;
+    size_t sort_tmp_bytes = 0;
+    int64_t cap_sort = 0;
     // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
     int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
     bool slab_ready = false, slab_needs_patch = false;

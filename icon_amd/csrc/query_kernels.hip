@@ -287,6 +287,65 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
     return nr;
 }
 
+// BVH2 traversal, ONE LANE PER POINT: every lane walks its own path (own stack column in LDS, vector
+// loads of its own nodes / triangle records).  This is the search for sparse or unordered point
+// sets - query() batches of Seg3dLossless's coarse levels, a few thousand sample points - where the
+// 64 points of a wavefront are far apart and the packet traversal above would have every lane visit
+// the union of 64 unrelated candidate sets (33^3 coarse lattice: 0.74 ms as packets).
+// Same S2 distance, same (d^2, face) key and pruning bound as the packet version -> same results.
+constexpr int kLaneBlock = 128;
+constexpr int64_t kPacketMinPoints = 2000000;
+__device__ __forceinline__ Nearest nearest_lane(const MeshDev &m, f3 p, int *stack /* LDS: [kStackDepth][kLaneBlock], this lane's column */)
+{
+    Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
+    unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
+    int slot = 0;
+    float thr = INFINITY;
+    int sp = 0;
+    int cur = 0;
+    while (true) {
+        if (cur < 0) {
+            const int code = ~cur;
+            const int leaf = code >> 2, cnt = (code & 3) + 1;
+            const float *lr = reinterpret_cast<const float *>(m.leaves + leaf);
+            const unsigned long long before = key;
+            for (int t = 0; t < cnt; ++t) {
+                const float *q = lr + (t >> 1) * 48 + (t & 1);          // field f of triangle t: q[2 f]
+                TriC tc;
+                tc.a = mk3(q[0], q[2], q[4]); tc.b = mk3(q[6], q[8], q[10]); tc.ab = mk3(q[12], q[14], q[16]);
+                tc.ac = mk3(q[18], q[20], q[22]); tc.bc = mk3(q[24], q[26], q[28]);
+                tc.i00 = q[30]; tc.i11 = q[32]; tc.ibc = q[34]; tc.a00 = q[36]; tc.a01 = q[38]; tc.a11 = q[40]; tc.inn = q[42];
+                const float d2 = tri_dist2(p, tc);
+                const unsigned long long k = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(q[44]);
+                if (k < key) { key = k; slot = leaf * kLeafMax + t; }
+            }
+            if (key != before) thr = prune_threshold(__int_as_float((int)(key >> 32)));
+            if (sp == 0) break;
+            cur = stack[(--sp) * kLaneBlock];
+        } else {
+            const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + cur);
+            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];             // lo.x(c0,c1) lo.y lo.z hi.x hi.y hi.z
+            const float2 ids = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(m.nodes + cur) + 12);
+            const float d0 = box_dist2(n0.x, n0.z, n1.x, n1.z, n2.x, n2.z, p);
+            const float d1 = box_dist2(n0.y, n0.w, n1.y, n1.w, n2.y, n2.w, p);
+            const int c0 = __float_as_int(ids.x), c1 = __float_as_int(ids.y);
+            const bool v0 = d0 <= thr, v1 = d1 <= thr;
+            if (v0 && v1) {
+                const bool first0 = d0 <= d1;
+                stack[(sp++) * kLaneBlock] = first0 ? c1 : c0;
+                cur = first0 ? c0 : c1;
+            } else if (v0) cur = c0;
+            else if (v1) cur = c1;
+            else {
+                if (sp == 0) break;
+                cur = stack[(--sp) * kLaneBlock];
+            }
+        }
+    }
+    nr.d2 = __int_as_float((int)(key >> 32)); nr.slot = slot; nr.face = (int)(key & 0xffffffffu);
+    return nr;
+}
+
 // Brute force over all triangle slots, staged through LDS in tiles (validation path).
 // Reads the same TriPre constants as the packet traversal (slot s = record s&3 of leaf s>>2).
 constexpr int kBruteTile = 128;   // 128 x 96 B = 12 KiB of LDS
@@ -590,12 +649,42 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     if (inside_out) inside_out[i] = ins ? 1 : 0;
 }
 
+// point mode, one lane per point (see nearest_lane)
+__global__ __launch_bounds__(kLaneBlock) void k_nearest_lane(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near)
+{
+    __shared__ int stack[kStackDepth * kLaneBlock];
+    const int64_t i = (int64_t)blockIdx.x * kLaneBlock + threadIdx.x;
+    if (i >= N) return;
+    const f3 p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    const Nearest nr = nearest_lane(m, p, stack + threadIdx.x);
+    near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
+}
+
+__global__ __launch_bounds__(kLaneBlock) void k_sdf_query_lane(MeshDev m, const float *__restrict__ pts, int64_t N,
+                                                               float *sdf, float *nrm, float *cm, float *vis,
+                                                               int64_t *face, uint8_t *inside_out)
+{
+    __shared__ int stack[kStackDepth * kLaneBlock];
+    const int64_t i = (int64_t)blockIdx.x * kLaneBlock + threadIdx.x;
+    if (i >= N) return;
+    const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const Nearest nr = nearest_lane(m, p, stack + threadIdx.x);
+    const bool ins = inside_bins(m, p);
+    const SdfOut o = sdf_attrs(m, p, nr, ins);
+    sdf[i] = o.sdf;
+    nrm[3 * i] = o.nrm.x; nrm[3 * i + 1] = o.nrm.y; nrm[3 * i + 2] = o.nrm.z;
+    cm[3 * i] = o.cm.x; cm[3 * i + 1] = o.cm.y; cm[3 * i + 2] = o.cm.z;
+    vis[i] = o.vis;
+    if (face) face[i] = nr.face;
+    if (inside_out) inside_out[i] = ins ? 1 : 0;
+}
+
 // Nearest-triangle search as its own launch: the packet traversal needs ~36 VGPRs, so it runs at
 // full occupancy (8 waves / SIMD hide the dependent scalar-load chain), which the register-heavier
 // attribute / gather code below would cap at 5.  Output: (slot, bits of d^2) per point, 8 B.
 template <bool LATTICE>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
-                                                    int2 *__restrict__ near)
+                                                    int2 *__restrict__ near, const int32_t *__restrict__ perm)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
@@ -609,6 +698,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         live = i < N;
         if (!live) i = N - 1;
+        if (perm) i = perm[i];          // Morton order: the wave's 64 points are neighbours (sort_points.hip)
         p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     }
     const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
@@ -906,6 +996,9 @@ extern "C" int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, in
     if (search == ICON_SEARCH_BRUTE)
         hipLaunchKernelGGL(k_sdf_query<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
                            d_cmap, d_vis, d_face, d_inside);
+    else if (N < kPacketMinPoints)      // sparse / unordered points: one lane per point (see nearest_lane)
+        hipLaunchKernelGGL(k_sdf_query_lane, dim3((unsigned)((N + kLaneBlock - 1) / kLaneBlock)), dim3(kLaneBlock), 0, st, mesh->dev, d_points, N,
+                           d_sdf, d_norm, d_cmap, d_vis, d_face, d_inside);
     else
         hipLaunchKernelGGL(k_sdf_query<false>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
                            d_cmap, d_vis, d_face, d_inside);
@@ -973,6 +1066,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
+    (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
     delete w;
@@ -1084,7 +1178,18 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     int2 *near = nullptr;
     if (prior == ICON_PRIOR_ICON && !brute) {
         near = reinterpret_cast<int2 *>(work->d_near);
-        hipLaunchKernelGGL((k_nearest<LATTICE>), grid, block, 0, st, md, cal, L, d_points, N, near);
+        // point mode: sparse batches walk the tree one lane per point; a batch dense enough for a wave's 64
+        // Morton neighbours to be close together (>= ~2M points in the cube) goes through the packet kernel
+        const int32_t *perm = nullptr;
+        if (!LATTICE && N < kPacketMinPoints) {
+            hipLaunchKernelGGL(k_nearest_lane, dim3((unsigned)((N + kLaneBlock - 1) / kLaneBlock)), dim3(kLaneBlock), 0, st, md, cal, d_points, N, near);
+        } else {
+            if (!LATTICE) {
+                const int rc = morton_order(work, d_points, cal.m, N, st, &perm);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL((k_nearest<LATTICE>), grid, block, 0, st, md, cal, L, d_points, N, near, perm);
+        }
     }
 #define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, near, d_x, work->d_code8)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }

@@ -300,12 +300,18 @@ class AdaptiveReconEngine(DenseReconEngine):
                 occ = torch.stack(occ)
             return occ
 
-        def dilate(mask, k):                         # SmoothConv3D(k) > 0  ==  box dilation
-            w = torch.ones((1, 1, k, k, k), dtype=torch.float32, device=dev) / float(k ** 3)
-            return (F.conv3d(mask, w, padding=(k - 1) // 2) > 0)[0, 0]
+        def dilate(mask, k):
+            # SmoothConv3D(k) > 0 (seg3d_utils.py:169-181: a k^3 box filter of a 0/1 mask) == box dilation;
+            # a box is separable, so three 1-D max filters give exactly the same voxel set as the
+            # reference's dense conv3d (which cost 1.9 of the 6 ms of this schedule)
+            r = (k - 1) // 2
+            m = F.max_pool3d(mask, (k, 1, 1), stride=1, padding=(r, 0, 0))
+            m = F.max_pool3d(m, (1, k, 1), stride=1, padding=(0, r, 0))
+            m = F.max_pool3d(m, (1, 1, k), stride=1, padding=(0, 0, r))
+            return (m > 0)[0, 0]
 
-        occupancys = coords_accum = None
-        self.last_stats = dict(queries=[])
+        occupancys = done = None                     # done[z,y,x]: voxel already evaluated (the reference keeps a
+        self.last_stats = dict(queries=[])           # sorted coordinate list, coords_accum, for the same purpose)
         for level, res in enumerate(res_list):
             stride = (last - 1) // (res - 1)
             if level == 0:
@@ -316,17 +322,18 @@ class AdaptiveReconEngine(DenseReconEngine):
                 self.last_stats["queries"].append(int(coords.shape[1]))
                 if (occupancys > 0.5).sum() == 0:
                     return None
-                coords_accum = coords / stride
+                done = torch.ones((res, res, res), dtype=torch.bool, device=dev)
                 continue
+            if level == len(res_list) - 1:           # "last step no examine" (seg3d_lossless.py:157,186-203)
+                occupancys = F.interpolate(occupancys.float(), size=(res, res, res), mode="trilinear", align_corners=True)
+                break
             valid = F.interpolate((occupancys > self.balance_value).float(), size=(res, res, res), mode="trilinear",
                                   align_corners=True)
             occupancys = F.interpolate(occupancys.float(), size=(res, res, res), mode="trilinear", align_corners=True)
-            if level == len(res_list) - 1:
-                break                                # "last step no examine" (seg3d_lossless.py:157,186-203)
-            coords_accum = coords_accum * 2
+            prev_done, done = done, torch.zeros((res, res, res), dtype=torch.bool, device=dev)
+            done[::2, ::2, ::2] = prev_done          # coords_accum * 2
             is_boundary = dilate(((valid > 0.0) & (valid < 1.0)).float(), 9 if level == 1 else (7 if level == 2 else 3))
-            ca = coords_accum.long()
-            is_boundary[ca[0, :, 2], ca[0, :, 1], ca[0, :, 0]] = False
+            is_boundary &= ~done
             point_coords = is_boundary.permute(2, 1, 0).nonzero(as_tuple=False).unsqueeze(0)    # (x,y,z), z fastest
             if point_coords.size(1) == 0:
                 continue
@@ -334,5 +341,5 @@ class AdaptiveReconEngine(DenseReconEngine):
             vals = batch_eval(point_coords * stride)
             self.last_stats["queries"].append(int(point_coords.shape[1]))
             occupancys = occupancys.reshape(1, 1, -1).scatter_(2, idx.unsqueeze(1), vals).view(1, 1, res, res, res)
-            coords_accum = torch.cat([point_coords.float(), coords_accum.float()], dim=1).unique(dim=1)
+            done.view(-1)[idx.view(-1)] = True
         return occupancys[0, 0]
