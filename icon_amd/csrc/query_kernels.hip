@@ -287,61 +287,132 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
     return nr;
 }
 
-// BVH2 traversal, ONE LANE PER POINT: every lane walks its own path (own stack column in LDS, vector
-// loads of its own nodes / triangle records).  This is the search for sparse or unordered point
-// sets - query() batches of Seg3dLossless's coarse levels, a few thousand sample points - where the
-// 64 points of a wavefront are far apart and the packet traversal above would have every lane visit
-// the union of 64 unrelated candidate sets (33^3 coarse lattice: 0.74 ms as packets).
-// Same S2 distance, same (d^2, face) key and pruning bound as the packet version -> same results.
-constexpr int kLaneBlock = 128;
-constexpr int64_t kPacketMinPoints = 2000000;
-__device__ __forceinline__ Nearest nearest_lane(const MeshDev &m, f3 p, int *stack /* LDS: [kStackDepth][kLaneBlock], this lane's column */)
+// BVH2 traversal, ONE WAVEFRONT PER POINT: the 64 lanes expand 64 tree nodes / test 64 triangles of the
+// SAME query point per round.  A point far from the surface has hundreds of leaves whose boxes are
+// closer than its nearest triangle; walked one after the other by a single lane that is a chain of
+// ~500 dependent loads (0.5 ms for a single wave), here it is ~10-20 rounds.  Per point this costs
+// about 3x the amortised work of the lattice packets, independent of how the points are ordered.
+//   1. greedy descent (near child first) to one leaf -> initial bound
+//   2. LIFO frontier of node references in LDS: a round pops up to 64 entries, every lane tests the
+//      two child boxes of its node against the current bound and pushes the survivors (inner nodes
+//      back on the frontier, leaves with their box distance on a leaf list); whenever the leaf
+//      list holds 16 leaves (64 triangle slots), or the frontier is empty, a leaf round runs: one
+//      lane per triangle, the wave minimum of the (d^2, face) keys goes through one LDS atomic.
+// Same S2 distance, same key, same pruning bound as the other traversals -> same results.
+// point mode: batches below this size go one wavefront per point, larger ones through Morton-ordered packets
+// (measured crossover on MI355X, tools/time_query_points.py: 60k points 0.56 vs 0.67 ms, 200k 1.69 vs 0.70 ms)
+constexpr int64_t kPacketMinPoints = 65536;
+constexpr int kCoopWaves = 2;                  // wavefronts (= points) per workgroup (2 x 18 KB of LDS)
+constexpr int kCoopFrontier = 4096;            // >= 64 * (kStackDepth + 2): LIFO bound for 64-wide expansion
+constexpr int kCoopLeaves = 256;               // leaf list (ref, box distance)
+struct CoopLds {
+    int frontier[kCoopFrontier];
+    int leaf_ref[kCoopLeaves];
+    float leaf_d[kCoopLeaves];
+    unsigned long long best;
+    int best_slot;
+};
+
+__device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds *S)
 {
-    Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
-    unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    unsigned long long key = 0x7f8000007fffffffull;
     int slot = 0;
-    float thr = INFINITY;
-    int sp = 0;
+    // test triangle (leaf, t) if t < cnt; returns key (or +inf key)
+    auto tri_key = [&](int leaf, int t, int cnt, int &out_slot) -> unsigned long long {
+        if (t >= cnt) return 0x7f8000007fffffffull;
+        const float *q = reinterpret_cast<const float *>(m.leaves + leaf) + (t >> 1) * 48 + (t & 1);
+        TriC tc;
+        tc.a = mk3(q[0], q[2], q[4]); tc.b = mk3(q[6], q[8], q[10]); tc.ab = mk3(q[12], q[14], q[16]);
+        tc.ac = mk3(q[18], q[20], q[22]); tc.bc = mk3(q[24], q[26], q[28]);
+        tc.i00 = q[30]; tc.i11 = q[32]; tc.ibc = q[34]; tc.a00 = q[36]; tc.a01 = q[38]; tc.a11 = q[40]; tc.inn = q[42];
+        const float d2 = tri_dist2(p, tc);
+        out_slot = leaf * kLeafMax + t;
+        return ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(q[44]);
+    };
+    // wave minimum of (key, slot) -> uniform
+    auto wave_min = [&](unsigned long long k, int sl) {
+        if (lane == 0) { *reinterpret_cast<volatile unsigned long long *>(&S->best) = key; *reinterpret_cast<volatile int *>(&S->best_slot) = slot; }
+        __builtin_amdgcn_wave_barrier();
+        if (k < key) atomicMin(&S->best, k);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long b = *reinterpret_cast<volatile unsigned long long *>(&S->best);
+        if (k == b && b != key) *reinterpret_cast<volatile int *>(&S->best_slot) = sl;        // any lane holding the minimum (same face -> same slot, or a padding copy)
+        __builtin_amdgcn_wave_barrier();
+        if (b != key) { key = b; slot = *reinterpret_cast<volatile int *>(&S->best_slot); }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // ---- 1. greedy descent ---------------------------------------------------------------------------
     int cur = 0;
-    while (true) {
-        if (cur < 0) {
-            const int code = ~cur;
-            const int leaf = code >> 2, cnt = (code & 3) + 1;
-            const float *lr = reinterpret_cast<const float *>(m.leaves + leaf);
-            const unsigned long long before = key;
-            for (int t = 0; t < cnt; ++t) {
-                const float *q = lr + (t >> 1) * 48 + (t & 1);          // field f of triangle t: q[2 f]
-                TriC tc;
-                tc.a = mk3(q[0], q[2], q[4]); tc.b = mk3(q[6], q[8], q[10]); tc.ab = mk3(q[12], q[14], q[16]);
-                tc.ac = mk3(q[18], q[20], q[22]); tc.bc = mk3(q[24], q[26], q[28]);
-                tc.i00 = q[30]; tc.i11 = q[32]; tc.ibc = q[34]; tc.a00 = q[36]; tc.a01 = q[38]; tc.a11 = q[40]; tc.inn = q[42];
-                const float d2 = tri_dist2(p, tc);
-                const unsigned long long k = ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(q[44]);
-                if (k < key) { key = k; slot = leaf * kLeafMax + t; }
-            }
-            if (key != before) thr = prune_threshold(__int_as_float((int)(key >> 32)));
-            if (sp == 0) break;
-            cur = stack[(--sp) * kLaneBlock];
-        } else {
-            const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + cur);
-            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];             // lo.x(c0,c1) lo.y lo.z hi.x hi.y hi.z
-            const float2 ids = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(m.nodes + cur) + 12);
-            const float d0 = box_dist2(n0.x, n0.z, n1.x, n1.z, n2.x, n2.z, p);
-            const float d1 = box_dist2(n0.y, n0.w, n1.y, n1.w, n2.y, n2.w, p);
-            const int c0 = __float_as_int(ids.x), c1 = __float_as_int(ids.y);
-            const bool v0 = d0 <= thr, v1 = d1 <= thr;
-            if (v0 && v1) {
-                const bool first0 = d0 <= d1;
-                stack[(sp++) * kLaneBlock] = first0 ? c1 : c0;
-                cur = first0 ? c0 : c1;
-            } else if (v0) cur = c0;
-            else if (v1) cur = c1;
-            else {
-                if (sp == 0) break;
-                cur = stack[(--sp) * kLaneBlock];
-            }
-        }
+    while (cur >= 0) {
+        const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + cur);
+        const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
+        const float2 ids = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(m.nodes + cur) + 12);
+        const float d0 = box_dist2(n0.x, n0.z, n1.x, n1.z, n2.x, n2.z, p);
+        const float d1 = box_dist2(n0.y, n0.w, n1.y, n1.w, n2.y, n2.w, p);
+        cur = __builtin_amdgcn_readfirstlane(d0 <= d1 ? __float_as_int(ids.x) : __float_as_int(ids.y));
     }
+    {
+        const int code = ~cur, leaf = code >> 2, cnt = (code & 3) + 1;
+        int sl = 0;
+        const unsigned long long k = tri_key(leaf, lane & 3, cnt, sl);
+        wave_min(k, sl);
+    }
+    float thr = prune_threshold(__int_as_float((int)(key >> 32)));
+
+    // ---- 2. frontier -----------------------------------------------------------------------------------
+    int nf = 1, nl = 0;                           // uniform counters
+    if (lane == 0) S->frontier[0] = 0;
+    __builtin_amdgcn_wave_barrier();
+    while (nf > 0 || nl > 0) {
+        if (nl >= 16 || nf == 0) {
+            // leaf round: up to 16 leaves from the end of the list, one lane per triangle slot
+            const int take = min(nl, 16);
+            const int e = nl - take + (lane >> 2);
+            unsigned long long k = 0x7f8000007fffffffull;
+            int sl = 0;
+            if ((lane >> 2) < take) {
+                const int code = ~reinterpret_cast<volatile int *>(S->leaf_ref)[e];
+                if (reinterpret_cast<volatile float *>(S->leaf_d)[e] <= thr) k = tri_key(code >> 2, lane & 3, (code & 3) + 1, sl);
+            }
+            nl -= take;
+            const unsigned long long before = key;
+            wave_min(k, sl);
+            if (key != before) thr = prune_threshold(__int_as_float((int)(key >> 32)));
+            continue;
+        }
+        // inner round: pop up to 64 nodes (fewer if their children might not fit)
+        // popping `take` nodes frees `take` entries and pushes at most 2 * take: net growth <= take
+        const int take = min(min(nf, 64), min(kCoopFrontier - nf, (kCoopLeaves - nl) / 2));
+        const int e = nf - take + lane;
+        bool v0 = false, v1 = false;
+        int c0 = 0, c1 = 0;
+        float d0 = 0.f, d1 = 0.f;
+        if (lane < take) {
+            const int node = reinterpret_cast<volatile int *>(S->frontier)[e];
+            const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + node);
+            const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
+            const float2 ids = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(m.nodes + node) + 12);
+            d0 = box_dist2(n0.x, n0.z, n1.x, n1.z, n2.x, n2.z, p);
+            d1 = box_dist2(n0.y, n0.w, n1.y, n1.w, n2.y, n2.w, p);
+            c0 = __float_as_int(ids.x); c1 = __float_as_int(ids.y);
+            v0 = d0 <= thr; v1 = d1 <= thr;
+        }
+        nf -= take;
+        __builtin_amdgcn_wave_barrier();
+        const unsigned long long bi0 = __ballot(v0 && c0 >= 0), bi1 = __ballot(v1 && c1 >= 0);
+        const unsigned long long bl0 = __ballot(v0 && c0 < 0), bl1 = __ballot(v1 && c1 < 0);
+        if (v0 && c0 >= 0) S->frontier[nf + __popcll(bi0 & lt_mask)] = c0;
+        if (v1 && c1 >= 0) S->frontier[nf + __popcll(bi0) + __popcll(bi1 & lt_mask)] = c1;
+        if (v0 && c0 < 0) { const int o = nl + __popcll(bl0 & lt_mask); S->leaf_ref[o] = c0; S->leaf_d[o] = d0; }
+        if (v1 && c1 < 0) { const int o = nl + __popcll(bl0) + __popcll(bl1 & lt_mask); S->leaf_ref[o] = c1; S->leaf_d[o] = d1; }
+        nf += __popcll(bi0) + __popcll(bi1);
+        nl += __popcll(bl0) + __popcll(bl1);
+        __builtin_amdgcn_wave_barrier();
+    }
+    Nearest nr;
     nr.d2 = __int_as_float((int)(key >> 32)); nr.slot = slot; nr.face = (int)(key & 0xffffffffu);
     return nr;
 }
@@ -628,11 +699,12 @@ constexpr int kBlock = 256;
 template <bool BRUTE>
 __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__restrict__ pts, int64_t N,
                                                       float *sdf, float *nrm, float *cm, float *vis,
-                                                      int64_t *face, uint8_t *inside_out)
+                                                      int64_t *face, uint8_t *inside_out, const int32_t *__restrict__ perm)
 {
     __shared__ int lds[kBruteTile * 24];   // brute: TriPre tile; packet: 4 wave stacks
-    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     const bool live = i < N;
+    if (live && perm) i = perm[i];           // Morton order (sort_points.hip): a wave's 64 points are neighbours
     const int64_t ic = live ? i : (N - 1);
     const f3 p = mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
     Nearest nr;
@@ -649,26 +721,27 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     if (inside_out) inside_out[i] = ins ? 1 : 0;
 }
 
-// point mode, one lane per point (see nearest_lane)
-__global__ __launch_bounds__(kLaneBlock) void k_nearest_lane(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near)
+// point mode, one wavefront per point (see nearest_coop)
+__global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near)
 {
-    __shared__ int stack[kStackDepth * kLaneBlock];
-    const int64_t i = (int64_t)blockIdx.x * kLaneBlock + threadIdx.x;
+    __shared__ CoopLds S[kCoopWaves];
+    const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
-    const Nearest nr = nearest_lane(m, p, stack + threadIdx.x);
-    near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
+    const Nearest nr = nearest_coop(m, p, &S[threadIdx.x >> 6]);
+    if ((threadIdx.x & 63) == 0) near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
 }
 
-__global__ __launch_bounds__(kLaneBlock) void k_sdf_query_lane(MeshDev m, const float *__restrict__ pts, int64_t N,
-                                                               float *sdf, float *nrm, float *cm, float *vis,
-                                                               int64_t *face, uint8_t *inside_out)
+__global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, const float *__restrict__ pts, int64_t N,
+                                                                   float *sdf, float *nrm, float *cm, float *vis,
+                                                                   int64_t *face, uint8_t *inside_out)
 {
-    __shared__ int stack[kStackDepth * kLaneBlock];
-    const int64_t i = (int64_t)blockIdx.x * kLaneBlock + threadIdx.x;
+    __shared__ CoopLds S[kCoopWaves];
+    const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    const Nearest nr = nearest_lane(m, p, stack + threadIdx.x);
+    const Nearest nr = nearest_coop(m, p, &S[threadIdx.x >> 6]);
+    if ((threadIdx.x & 63) != 0) return;
     const bool ins = inside_bins(m, p);
     const SdfOut o = sdf_attrs(m, p, nr, ins);
     sdf[i] = o.sdf;
@@ -993,15 +1066,25 @@ extern "C" int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, in
     const int64_t nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb < (1ll << 31), "icon_sdf_query: N too large for one launch");
     hipStream_t st = (hipStream_t)stream;
-    if (search == ICON_SEARCH_BRUTE)
+    if (search == ICON_SEARCH_BRUTE) {
         hipLaunchKernelGGL(k_sdf_query<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
-                           d_cmap, d_vis, d_face, d_inside);
-    else if (N < kPacketMinPoints)      // sparse / unordered points: one lane per point (see nearest_lane)
-        hipLaunchKernelGGL(k_sdf_query_lane, dim3((unsigned)((N + kLaneBlock - 1) / kLaneBlock)), dim3(kLaneBlock), 0, st, mesh->dev, d_points, N,
+                           d_cmap, d_vis, d_face, d_inside, nullptr);
+    } else if (N < kPacketMinPoints) {    // sparse / unordered points: one wavefront per point (see nearest_coop)
+        hipLaunchKernelGGL(k_sdf_query_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), 0, st, mesh->dev, d_points, N,
                            d_sdf, d_norm, d_cmap, d_vis, d_face, d_inside);
-    else
-        hipLaunchKernelGGL(k_sdf_query<false>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
-                           d_cmap, d_vis, d_face, d_inside);
+    } else {                              // large batches: packets over the Morton order (scratch freed after a stream sync)
+        icon_work tmp;
+        static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        const int32_t *perm = nullptr;
+        int rc = morton_order(&tmp, d_points, ident, N, st, &perm);
+        if (!rc) {
+            hipLaunchKernelGGL(k_sdf_query<false>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
+                               d_cmap, d_vis, d_face, d_inside, perm);
+            if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ICON_ERR_HIP, "icon_sdf_query: launch failed");
+        }
+        (void)hipFree(tmp.d_sort_keys); (void)hipFree(tmp.d_sort_idx); (void)hipFree(tmp.d_sort_tmp);
+        return rc;
+    }
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
@@ -1181,8 +1264,9 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
         // point mode: sparse batches walk the tree one lane per point; a batch dense enough for a wave's 64
         // Morton neighbours to be close together (>= ~2M points in the cube) goes through the packet kernel
         const int32_t *perm = nullptr;
-        if (!LATTICE && N < kPacketMinPoints) {
-            hipLaunchKernelGGL(k_nearest_lane, dim3((unsigned)((N + kLaneBlock - 1) / kLaneBlock)), dim3(kLaneBlock), 0, st, md, cal, d_points, N, near);
+        static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
+        if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
+            hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), 0, st, md, cal, d_points, N, near);
         } else {
             if (!LATTICE) {
                 const int rc = morton_order(work, d_points, cal.m, N, st, &perm);

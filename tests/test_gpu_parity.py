@@ -78,6 +78,42 @@ def test_sdf_query_vs_oracle(mesh, n, search):
     assert np.abs(g["cmap"] - o["cmap"]).max() <= 1e-6
 
 
+@pytest.mark.parametrize("n", [1, 63, 4097, 65535, 65536, 200000])
+def test_point_search_strategies_agree_with_brute_force(body, n):
+    """point mode picks its traversal by batch size (one wavefront per point below 65,536 points,
+    Morton-ordered packets above): both must reproduce the brute-force scan exactly, far field and
+    points outside the unit cube included"""
+    from icon_amd.engine import MeshHandle
+    rng = np.random.RandomState(n)
+    k = max(n // 2, 1)
+    pts = np.concatenate([synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], k, seed=n),
+                          rng.uniform(-1.3, 1.3, (n - k, 3)).astype(np.float32)])[:n]
+    rng.shuffle(pts)
+    h = MeshHandle(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    a = h.sdf_query(T(pts), search="bvh")
+    b = h.sdf_query(T(pts), search="brute")
+    for key in ("face", "inside", "vis", "sdf", "norm", "cmap"):
+        assert torch.equal(a[key], b[key]), key
+
+
+@pytest.mark.parametrize("n", [70000, 150000])
+def test_query_large_unordered_batches(body, n):
+    """HGPIFuNet.query on an unordered batch large enough for the packet path: equal to the same points
+    queried in two halves (cmap_mode='local' makes points independent) and to the oracle on a sample"""
+    eng = make_engine(body, cmap_mode="local")
+    rng = np.random.RandomState(n)
+    pts = rng.uniform(-1.0, 1.0, (n, 3)).astype(np.float32)
+    cal = torch.eye(4, device=dev())[None]
+    full = eng.query([T(body.features)], T(pts.T.copy())[None], cal)[0][0, 0]
+    h = n // 2
+    a = eng.query([T(body.features)], T(pts[:h].T.copy())[None], cal)[0][0, 0]
+    b = eng.query([T(body.features)], T(pts[h:].T.copy())[None], cal)[0][0, 0]
+    assert torch.equal(full, torch.cat([a, b]))
+    sel = rng.choice(n, 3000, replace=False)
+    ref, _ = oracle_query(body, pts[sel], cmap_local=True)
+    assert np.abs(full.cpu().numpy()[sel] - ref).max() <= OCC_TOL
+
+
 def test_sdf_bvh_equals_brute_large(body):
     """50k points incl. a dense far field: BVH pruning never changes the argmin / tie rule"""
     from icon_amd.engine import MeshHandle

@@ -5,7 +5,7 @@ from icon_amd.engine import MeshHandle
 a = synth.make_assets("body"); T=lambda x: torch.from_numpy(x).cuda()
 mesh = MeshHandle(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
 g = torch.Generator(device="cuda"); g.manual_seed(0)
-for n in (64, 1024, 8192, 36000, 200000):
+for n in (64, 1024, 8192, 36000, 200000, 1000000, 1999999, 2000001):
     pts = (torch.rand((n, 3), device="cuda", generator=g) * 2 - 1)
     mesh.sdf_query(pts); torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
