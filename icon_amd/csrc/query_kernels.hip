@@ -290,8 +290,9 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
 // BVH2 traversal, ONE WAVEFRONT PER POINT: the 64 lanes expand 64 tree nodes / test 64 triangles of the
 // SAME query point per round.  A point far from the surface has hundreds of leaves whose boxes are
 // closer than its nearest triangle; walked one after the other by a single lane that is a chain of
-// ~500 dependent loads (0.5 ms for a single wave), here it is ~10-20 rounds.  Per point this costs
-// about 3x the amortised work of the lattice packets, independent of how the points are ordered.
+// ~500 dependent loads (0.5 ms for a single wave), here it is ~10-20 rounds: 33 us for 64 points.
+// Throughput is ~9 ns per point (the lattice packets amortise to 0.25 ns), so this is the search for
+// small batches only - see kPacketMinPoints.
 //   1. greedy descent (near child first) to one leaf -> initial bound
 //   2. LIFO frontier of node references in LDS: a round pops up to 64 entries, every lane tests the
 //      two child boxes of its node against the current bound and pushes the survivors (inner nodes
