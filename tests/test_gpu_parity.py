@@ -96,6 +96,30 @@ def test_point_search_strategies_agree_with_brute_force(body, n):
         assert torch.equal(a[key], b[key]), key
 
 
+def test_point_search_worst_cases():
+    """frontier stress for the one-wavefront-per-point search: the centre of a sphere (every triangle is
+    as close as the nearest one, nothing can be pruned), points far outside, points on vertices"""
+    from icon_amd.engine import MeshHandle
+    ico = assets("ico")
+    v = ico.smpl_verts[0]
+    c = v.mean(0, keepdims=True).astype(np.float32)
+    pts = np.concatenate([c, c + 1e-4, np.array([[5, 5, 5], [-7, 0.1, 0.2], [0, 0, 30]], np.float32), v[:40]]).astype(np.float32)
+    h = MeshHandle(T(ico.smpl_verts), T(ico.smpl_faces), T(ico.smpl_cmap), T(ico.smpl_vis))
+    a = h.sdf_query(T(pts), search="bvh")
+    b = h.sdf_query(T(pts), search="brute")
+    for key in ("face", "inside", "vis", "sdf", "norm", "cmap"):
+        assert torch.equal(a[key], b[key]), key
+    # a finer sphere (20,480 faces, 5,120 leaves all inside the bound of its centre)
+    v5, f5 = synth.icosphere(5, radius=0.7, center=(0.0, 0.0, 0.0))
+    v5 = v5.astype(np.float32); f5 = f5.astype(np.int64)
+    vis5, cm5 = synth.make_vis_cmap(v5, f5)
+    h5 = MeshHandle(T(v5[None]), T(f5[None]), T(np.asarray(cm5, np.float32).reshape(1, -1, 3)), T(np.asarray(vis5, np.float32).reshape(1, -1, 1)))
+    p5 = np.array([[0, 0, 0], [1e-5, -2e-5, 3e-5], [0.69, 0, 0], [3, 3, 3]], np.float32)
+    a, b = h5.sdf_query(T(p5), search="bvh"), h5.sdf_query(T(p5), search="brute")
+    for key in ("face", "inside", "sdf"):
+        assert torch.equal(a[key], b[key]), key
+
+
 @pytest.mark.parametrize("n", [70000, 150000])
 def test_query_large_unordered_batches(body, n):
     """HGPIFuNet.query on an unordered batch large enough for the packet path: equal to the same points
