@@ -186,6 +186,23 @@ def main():
         except Exception:
             traffic = None
 
+    # informational: the reference's own coarse-to-fine schedule (Seg3dLossless._forward_faster, ~1 % of the
+    # lattice queried) on the same engine - not the metric, which is the dense grid
+    adaptive_ms = None
+    if world == 1 and res == 257:
+        from icon_amd.recon import AdaptiveReconEngine
+        ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                 resolutions=[33, 65, 129, res], align_corners=True).to(dev)
+        eng._work().profile(False)
+        for _ in range(2):
+            ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
+        torch.cuda.synchronize()
+        adaptive_ms = (time.perf_counter() - t1) / 5 * 1e3
+
     if rank == 0:
         out = {
             "metric": "query-points/sec at 256^3 grid", "value": value, "unit": "points/s",
@@ -197,6 +214,7 @@ def main():
                             f"V=6890/F=13776, planes [1,12,128,128], MLP 13-512-256-128-1, cmap_mode={args.cmap_mode}, mlp={args.precision}",
                 "parallelism": f"zslab{world}", "points_per_step": n_points, "prep_ms": prep_ms,
                 "stage_ms": {"features": stage[0], "cmap_patch": stage[1], "mlp": stage[2]},
+                "reference_schedule_ms_per_volume": adaptive_ms,
             },
             "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved,
                          "peak": PEAK_TFLOPS[args.precision],
