@@ -301,20 +301,34 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
 //      lane per triangle, the wave minimum of the (d^2, face) keys goes through one LDS atomic.
 // Same S2 distance, same key, same pruning bound as the other traversals -> same results.
 // point mode: batches below this size go one wavefront per point, larger ones through Morton-ordered packets
-// (measured crossover on MI355X, tools/time_query_points.py: 60k points 0.56 vs 0.67 ms, 200k 1.69 vs 0.70 ms)
-constexpr int64_t kPacketMinPoints = 65536;
-constexpr int kCoopWaves = 2;                  // wavefronts (= points) per workgroup (2 x 18 KB of LDS)
-constexpr int kCoopFrontier = 4096;            // >= 64 * (kStackDepth + 2): LIFO bound for 64-wide expansion
+// (measured crossover on MI355X, tools/time_query_points.py: 60k points 0.42 vs 0.67 ms, 200k ~1.4 vs 0.70 ms)
+constexpr int64_t kPacketMinPoints = 98304;
+constexpr int kCoopWaves = 4;                  // wavefronts (= points) per workgroup
 constexpr int kCoopLeaves = 256;               // leaf list (ref, box distance)
+// per-wave LDS: [frontier: cap ints][leaf refs][leaf box distances][best key][best slot].  cap >= 64 * (tree
+// depth + 2) is the LIFO bound of a 64-wide expansion (a round pops the 64 deepest entries and pushes at
+// most 128 one level deeper); the SMPL tree (depth ~20) needs 6 KiB per wave, so ~5 waves per SIMD fit.
 struct CoopLds {
-    int frontier[kCoopFrontier];
-    int leaf_ref[kCoopLeaves];
-    float leaf_d[kCoopLeaves];
-    unsigned long long best;
-    int best_slot;
+    int *frontier; int cap;
+    int *leaf_ref; float *leaf_d;
+    unsigned long long *best; int *best_slot;
 };
+__host__ __device__ inline int coop_cap(int depth) { return 64 * (depth + 3); }
+__host__ __device__ inline size_t coop_wave_bytes(int cap) { return (size_t)cap * 4 + kCoopLeaves * 8 + 16; }
+__device__ __forceinline__ CoopLds coop_lds(char *smem, int wave, int cap)
+{
+    char *b = smem + (size_t)wave * coop_wave_bytes(cap);
+    CoopLds S;
+    S.best = reinterpret_cast<unsigned long long *>(b);
+    S.best_slot = reinterpret_cast<int *>(b + 8);
+    S.leaf_ref = reinterpret_cast<int *>(b + 16);
+    S.leaf_d = reinterpret_cast<float *>(b + 16 + kCoopLeaves * 4);
+    S.frontier = reinterpret_cast<int *>(b + 16 + kCoopLeaves * 8);
+    S.cap = cap;
+    return S;
+}
 
-__device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds *S)
+__device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, const CoopLds &S)
 {
     const int lane = threadIdx.x & 63;
     const unsigned long long lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -334,14 +348,14 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds 
     };
     // wave minimum of (key, slot) -> uniform
     auto wave_min = [&](unsigned long long k, int sl) {
-        if (lane == 0) { *reinterpret_cast<volatile unsigned long long *>(&S->best) = key; *reinterpret_cast<volatile int *>(&S->best_slot) = slot; }
+        if (lane == 0) { *reinterpret_cast<volatile unsigned long long *>(S.best) = key; *reinterpret_cast<volatile int *>(S.best_slot) = slot; }
         __builtin_amdgcn_wave_barrier();
-        if (k < key) atomicMin(&S->best, k);
+        if (k < key) atomicMin(S.best, k);
         __builtin_amdgcn_wave_barrier();
-        const unsigned long long b = *reinterpret_cast<volatile unsigned long long *>(&S->best);
-        if (k == b && b != key) *reinterpret_cast<volatile int *>(&S->best_slot) = sl;        // any lane holding the minimum (same face -> same slot, or a padding copy)
+        const unsigned long long b = *reinterpret_cast<volatile unsigned long long *>(S.best);
+        if (k == b && b != key) *reinterpret_cast<volatile int *>(S.best_slot) = sl;        // any lane holding the minimum (same face -> same slot, or a padding copy)
         __builtin_amdgcn_wave_barrier();
-        if (b != key) { key = b; slot = *reinterpret_cast<volatile int *>(&S->best_slot); }
+        if (b != key) { key = b; slot = *reinterpret_cast<volatile int *>(S.best_slot); }
         __builtin_amdgcn_wave_barrier();
     };
 
@@ -365,7 +379,7 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds 
 
     // ---- 2. frontier -----------------------------------------------------------------------------------
     int nf = 1, nl = 0;                           // uniform counters
-    if (lane == 0) S->frontier[0] = 0;
+    if (lane == 0) S.frontier[0] = 0;
     __builtin_amdgcn_wave_barrier();
     while (nf > 0 || nl > 0) {
         if (nl >= 16 || nf == 0) {
@@ -375,8 +389,8 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds 
             unsigned long long k = 0x7f8000007fffffffull;
             int sl = 0;
             if ((lane >> 2) < take) {
-                const int code = ~reinterpret_cast<volatile int *>(S->leaf_ref)[e];
-                if (reinterpret_cast<volatile float *>(S->leaf_d)[e] <= thr) k = tri_key(code >> 2, lane & 3, (code & 3) + 1, sl);
+                const int code = ~reinterpret_cast<volatile int *>(S.leaf_ref)[e];
+                if (reinterpret_cast<volatile float *>(S.leaf_d)[e] <= thr) k = tri_key(code >> 2, lane & 3, (code & 3) + 1, sl);
             }
             nl -= take;
             const unsigned long long before = key;
@@ -386,13 +400,13 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds 
         }
         // inner round: pop up to 64 nodes (fewer if their children might not fit)
         // popping `take` nodes frees `take` entries and pushes at most 2 * take: net growth <= take
-        const int take = min(min(nf, 64), min(kCoopFrontier - nf, (kCoopLeaves - nl) / 2));
+        const int take = min(min(nf, 64), min(S.cap - nf, (kCoopLeaves - nl) / 2));
         const int e = nf - take + lane;
         bool v0 = false, v1 = false;
         int c0 = 0, c1 = 0;
         float d0 = 0.f, d1 = 0.f;
         if (lane < take) {
-            const int node = reinterpret_cast<volatile int *>(S->frontier)[e];
+            const int node = reinterpret_cast<volatile int *>(S.frontier)[e];
             const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + node);
             const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
             const float2 ids = *reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(m.nodes + node) + 12);
@@ -405,10 +419,10 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, CoopLds 
         __builtin_amdgcn_wave_barrier();
         const unsigned long long bi0 = __ballot(v0 && c0 >= 0), bi1 = __ballot(v1 && c1 >= 0);
         const unsigned long long bl0 = __ballot(v0 && c0 < 0), bl1 = __ballot(v1 && c1 < 0);
-        if (v0 && c0 >= 0) S->frontier[nf + __popcll(bi0 & lt_mask)] = c0;
-        if (v1 && c1 >= 0) S->frontier[nf + __popcll(bi0) + __popcll(bi1 & lt_mask)] = c1;
-        if (v0 && c0 < 0) { const int o = nl + __popcll(bl0 & lt_mask); S->leaf_ref[o] = c0; S->leaf_d[o] = d0; }
-        if (v1 && c1 < 0) { const int o = nl + __popcll(bl0) + __popcll(bl1 & lt_mask); S->leaf_ref[o] = c1; S->leaf_d[o] = d1; }
+        if (v0 && c0 >= 0) S.frontier[nf + __popcll(bi0 & lt_mask)] = c0;
+        if (v1 && c1 >= 0) S.frontier[nf + __popcll(bi0) + __popcll(bi1 & lt_mask)] = c1;
+        if (v0 && c0 < 0) { const int o = nl + __popcll(bl0 & lt_mask); S.leaf_ref[o] = c0; S.leaf_d[o] = d0; }
+        if (v1 && c1 < 0) { const int o = nl + __popcll(bl0) + __popcll(bl1 & lt_mask); S.leaf_ref[o] = c1; S.leaf_d[o] = d1; }
         nf += __popcll(bi0) + __popcll(bi1);
         nl += __popcll(bl0) + __popcll(bl1);
         __builtin_amdgcn_wave_barrier();
@@ -723,25 +737,26 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
 }
 
 // point mode, one wavefront per point (see nearest_coop)
-__global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near)
+__global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near,
+                                                                 int cap)
 {
-    __shared__ CoopLds S[kCoopWaves];
+    extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = project(cal, mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
-    const Nearest nr = nearest_coop(m, p, &S[threadIdx.x >> 6]);
+    const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
     if ((threadIdx.x & 63) == 0) near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
 }
 
 __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, const float *__restrict__ pts, int64_t N,
                                                                    float *sdf, float *nrm, float *cm, float *vis,
-                                                                   int64_t *face, uint8_t *inside_out)
+                                                                   int64_t *face, uint8_t *inside_out, int cap)
 {
-    __shared__ CoopLds S[kCoopWaves];
+    extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
-    const Nearest nr = nearest_coop(m, p, &S[threadIdx.x >> 6]);
+    const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
     if ((threadIdx.x & 63) != 0) return;
     const bool ins = inside_bins(m, p);
     const SdfOut o = sdf_attrs(m, p, nr, ins);
@@ -1071,8 +1086,9 @@ extern "C" int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, in
         hipLaunchKernelGGL(k_sdf_query<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
                            d_cmap, d_vis, d_face, d_inside, nullptr);
     } else if (N < kPacketMinPoints) {    // sparse / unordered points: one wavefront per point (see nearest_coop)
-        hipLaunchKernelGGL(k_sdf_query_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), 0, st, mesh->dev, d_points, N,
-                           d_sdf, d_norm, d_cmap, d_vis, d_face, d_inside);
+        const int cap = coop_cap((int)mesh->stats[1]);
+        hipLaunchKernelGGL(k_sdf_query_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), kCoopWaves * coop_wave_bytes(cap), st,
+                           mesh->dev, d_points, N, d_sdf, d_norm, d_cmap, d_vis, d_face, d_inside, cap);
     } else {                              // large batches: packets over the Morton order (scratch freed after a stream sync)
         icon_work tmp;
         static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -1267,7 +1283,8 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
         const int32_t *perm = nullptr;
         static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
         if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
-            hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), 0, st, md, cal, d_points, N, near);
+            { const int cap = coop_cap((int)mesh->stats[1]);
+              hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), kCoopWaves * coop_wave_bytes(cap), st, md, cal, d_points, N, near, cap); }
         } else {
             if (!LATTICE) {
                 const int rc = morton_order(work, d_points, cal.m, N, st, &perm);

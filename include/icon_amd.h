@@ -88,7 +88,7 @@ int icon_mesh_stats(const icon_mesh_t *mesh, int64_t out[6]);
  *   check_sign (kaolin leaf) :393.
  * d_points [N,3]; outputs d_sdf [N], d_norm [N,3], d_cmap [N,3], d_vis [N] (0/1 as float),
  * optional d_face [N] int64 (nearest face index) and d_inside [N] uint8.  Unclipped, as
- * cal_sdf_batch returns them.  The points may come in any order: batches below 65,536 points are
+ * cal_sdf_batch returns them.  The points may come in any order: batches below 98,304 points are
  * searched one wavefront per point, larger ones as 64-point packets over a Morton ordering built on
  * the device (that path synchronises the stream once to free its scratch).
  * ------------------------------------------------------------------------------------------- */

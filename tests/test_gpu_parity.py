@@ -78,9 +78,9 @@ def test_sdf_query_vs_oracle(mesh, n, search):
     assert np.abs(g["cmap"] - o["cmap"]).max() <= 1e-6
 
 
-@pytest.mark.parametrize("n", [1, 63, 4097, 65535, 65536, 200000])
+@pytest.mark.parametrize("n", [1, 63, 4097, 98303, 98304, 200000])
 def test_point_search_strategies_agree_with_brute_force(body, n):
-    """point mode picks its traversal by batch size (one wavefront per point below 65,536 points,
+    """point mode picks its traversal by batch size (one wavefront per point below 98,304 points,
     Morton-ordered packets above): both must reproduce the brute-force scan exactly, far field and
     points outside the unit cube included"""
     from icon_amd.engine import MeshHandle
@@ -120,7 +120,7 @@ def test_point_search_worst_cases():
         assert torch.equal(a[key], b[key]), key
 
 
-@pytest.mark.parametrize("n", [70000, 150000])
+@pytest.mark.parametrize("n", [70000, 150000])      # below / above the switch to Morton-ordered packets
 def test_query_large_unordered_batches(body, n):
     """HGPIFuNet.query on an unordered batch large enough for the packet path: equal to the same points
     queried in two halves (cmap_mode='local' makes points independent) and to the oracle on a sample"""
