@@ -100,6 +100,8 @@ def main():
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--precision", default="mx6", choices=["f32", "f16x3", "mx6"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--with-adaptive", action="store_true",
+                    help="also time the reference's coarse-to-fine schedule (extra small launches: keep it off when profiling)")
     args = ap.parse_args()
 
     import numpy as np
@@ -189,7 +191,7 @@ def main():
     # informational: the reference's own coarse-to-fine schedule (Seg3dLossless._forward_faster, ~1 % of the
     # lattice queried) on the same engine - not the metric, which is the dense grid
     adaptive_ms = None
-    if world == 1 and res == 257:
+    if args.with_adaptive and world == 1 and res == 257:
         from icon_amd.recon import AdaptiveReconEngine
         ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                                  resolutions=[33, 65, 129, res], align_corners=True).to(dev)
