@@ -102,9 +102,15 @@ class DenseReconEngine(nn.Module):
     def _lattice_fast_path(self, proj_matrix) -> bool:
         r = self.resolutions[-1]
         ok = bool(self.align_corners) and proj_matrix is None and int(r[0]) == int(r[1]) == int(r[2])
-        ok = ok and torch.equal(self.b_min.cpu().flatten(), torch.tensor([-1.0, 1.0, -1.0]))
-        ok = ok and torch.equal(self.b_max.cpu().flatten(), torch.tensor([1.0, -1.0, 1.0]))
-        return ok
+        if not ok:
+            return False
+        # the bounding-box buffers live on the device: compare them once per (tensor, version), not per call
+        key = (self.b_min.data_ptr(), self.b_min._version, self.b_max.data_ptr(), self.b_max._version)
+        if getattr(self, "_bbox_key", None) != key:
+            self._bbox_ok = (torch.equal(self.b_min.cpu().flatten(), torch.tensor([-1.0, 1.0, -1.0]))
+                             and torch.equal(self.b_max.cpu().flatten(), torch.tensor([1.0, -1.0, 1.0])))
+            self._bbox_key = key
+        return self._bbox_ok
 
     def _backend_for(self, netG):
         if self.backend is not None:
