@@ -111,8 +111,10 @@ struct FeatDev {
     int32_t Cv, Dv, Hv, Wv, vpad;
 };
 
-// affine calibration (rot | trans), row-major [3][4]
-struct Calib { float m[12]; };
+// affine calibration (rot | trans), row-major [3][4]; when `d` is set the 12 floats are read from
+// device memory by the kernel itself (wave-uniform scalar loads), so a caller holding the calibration
+// on the device never has to copy it to the host (no stream synchronisation in query())
+struct Calib { float m[12]; const float *d; };
 
 // lattice descriptor: point i -> (x, y, z) index; world = idx/(R-1) * (bmax-bmin) + bmin
 struct Lattice {
@@ -163,7 +165,7 @@ void parallel_for(int n, const std::function<void(int)> &fn);
 struct McDevState;
 void mc_destroy(McDevState *s);
 // sort_points.hip: perm[k] = index of the k-th point in Morton order of the projected positions (device array owned by w)
-int morton_order(icon_work *w, const float *d_points, const float *calib12, int64_t N, hipStream_t st, const int32_t **perm);
+int morton_order(icon_work *w, const float *d_points, const float *calib12, const float *d_calib12, int64_t N, hipStream_t st, const int32_t **perm);
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);

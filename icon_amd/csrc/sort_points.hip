@@ -24,13 +24,15 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v)      // 10 bits -> ever
     return v;
 }
 
-struct Calib12 { float m[12]; };
+struct Calib12 { float m[12]; const float *d; };
 
 __global__ void k_morton_keys(const float *__restrict__ pts, Calib12 c, int64_t N, uint32_t *__restrict__ keys, int32_t *__restrict__ idx)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= N) return;
     const float x = pts[3 * i], y = pts[3 * i + 1], z = pts[3 * i + 2];
+    if (c.d)
+        for (int k = 0; k < 12; ++k) c.m[k] = c.d[k];
     float q[3];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
@@ -41,7 +43,7 @@ __global__ void k_morton_keys(const float *__restrict__ pts, Calib12 c, int64_t 
     idx[i] = (int32_t)i;
 }
 
-int morton_order(icon_work *w, const float *d_points, const float *calib12, int64_t N, hipStream_t st, const int32_t **perm)
+int morton_order(icon_work *w, const float *d_points, const float *calib12, const float *d_calib12, int64_t N, hipStream_t st, const int32_t **perm)
 {
     ICON_ARG(N > 0 && N < (1ll << 31), "morton_order: bad point count");
     size_t tmp = 0;
@@ -61,6 +63,7 @@ int morton_order(icon_work *w, const float *d_points, const float *calib12, int6
     }
     Calib12 c;
     memcpy(c.m, calib12, sizeof(c.m));
+    c.d = d_calib12;
     uint32_t *k0 = w->d_sort_keys, *k1 = w->d_sort_keys + w->cap_sort;
     int32_t *i0 = w->d_sort_idx, *i1 = w->d_sort_idx + w->cap_sort;
     hipLaunchKernelGGL(k_morton_keys, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, d_points, c, N, k0, i0);

@@ -283,6 +283,40 @@ def make_mlp_state_dict(seed: int = SEED, dims=MLP_DIMS, res_layers=RES_LAYERS,
     return sd
 
 
+def make_mlp_state_dict_init_net(seed: int = SEED, dims=MLP_DIMS, res_layers=RES_LAYERS, init_gain: float = 0.02) -> dict:
+    """state_dict as the reference's constructor leaves it: ``init_net(self)`` (lib/net/HGPIFuNet.py:165)
+    -> ``init_weights(net, 'xavier', 0.02)`` (lib/net/net_util.py:73-126): Conv1d weights
+    xavier_normal with gain 0.02, zero biases; BatchNorm1d keeps torch's defaults (weight 1, bias 0,
+    running_mean 0, running_var 1 - only 'BatchNorm2d' is matched by the initialiser)."""
+    rng = np.random.RandomState(seed + 7)
+    sd = {}
+    for l, (co, ci) in enumerate(mlp_layer_shapes(dims, res_layers)):
+        std = init_gain * np.sqrt(2.0 / (ci + co))
+        sd[f"filters.{l}.weight"] = rng.normal(0, std, size=(co, ci, 1)).astype(np.float32)
+        sd[f"filters.{l}.bias"] = np.zeros((co,), np.float32)
+        if l != len(dims) - 2:
+            sd[f"norms.{l}.weight"] = np.ones((co,), np.float32)
+            sd[f"norms.{l}.bias"] = np.zeros((co,), np.float32)
+            sd[f"norms.{l}.running_mean"] = np.zeros((co,), np.float32)
+            sd[f"norms.{l}.running_var"] = np.ones((co,), np.float32)
+    return sd
+
+
+def representative_rows(n: int, c0: int = 13, seed: int = SEED) -> np.ndarray:
+    """[n, c0] float32 MLP inputs with the statistics of the query path (lib/net/HGPIFuNet.py:298-311):
+    image features ~ N(0,1); sdf +-1 for ~90 % (clipped outliers) else inside the clip band; cmap the
+    outlier signs or [0,1]; norm a unit vector."""
+    rng = np.random.RandomState(seed + 31)
+    x = rng.normal(0, 1, (n, c0)).astype(np.float32)
+    if c0 == 13:
+        out = rng.rand(n) < 0.9
+        x[:, 6] = np.where(out, np.sign(rng.normal(size=n)), rng.uniform(-0.05, 0.05, n))
+        x[:, 7:10] = np.where(out[:, None], np.sign(rng.normal(size=(n, 3))), rng.rand(n, 3))
+        v = rng.normal(size=(n, 3))
+        x[:, 10:13] = v / np.maximum(np.linalg.norm(v, axis=1, keepdims=True), 1e-6)
+    return x.astype(np.float32)
+
+
 def mlp_forward_f64(sd: dict, x: np.ndarray, dims=MLP_DIMS, res_layers=RES_LAYERS) -> np.ndarray:
     """float64 evaluation of lib/net/MLP.py:49-72 (Conv1d k=1, BatchNorm1d eval with eps 1e-5,
     LeakyReLU 0.01, input re-concatenated before res layers, no last_op in test mode).

@@ -43,11 +43,14 @@ enum { ICON_PRIOR_ICON = 0, ICON_PRIOR_PAMIR = 1, ICON_PRIOR_PIFU = 2 };
  * outlier (3j+k) mod K.  LOCAL is the per-point rule (cmap := own sign). */
 enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
 
-/* MLP arithmetic.  F32: v_mfma_f32_32x32x2_f32, bit-for-bit an f32 fma chain.  F16X3: every
- * product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 with f32 accumulation
- * (22-bit operands; ~1e-6 of the f32 result, 5x the rate).  MX6: a_hi*b_hi on the f16 MFMA and
- * the two 2^-11 cross terms on the block-scaled fp6 MFMA v_mfma_scale_f32_32x32x64_f8f6f4
- * (half the matrix-pipe time of F16X3; <= ~3e-5 from the float64 MLP on the occupancy). */
+/* MLP arithmetic.  F32: v_mfma_f32_32x32x2_f32, bit-for-bit an f32 fma chain.  F16X3 (the DEFAULT
+ * of the host layer): every product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16
+ * with f32 accumulation (22-bit operands; ~1e-6 of the f32 result, 5x the rate) - f32-class.
+ * MX6 (explicit opt-in, NOT f32-equivalent): a_hi*b_hi on the f16 MFMA and the two 2^-11 cross terms
+ * on the block-scaled fp6 MFMA v_mfma_scale_f32_32x32x64_f8f6f4, i.e. ~15 significant bits per
+ * product; its occupancy error scales with the hidden activations and the last layer's gain
+ * (3e-4 on an unattenuated checkpoint), so the host layer calibrates it per checkpoint against
+ * F16X3 and falls back unless the deviation is <= 2.5e-5. */
 enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1, ICON_PRECISION_MX6 = 2 };
 
 /* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
@@ -157,6 +160,14 @@ int icon_query_points(const icon_mesh_t *mesh, const icon_feat_t *feat, const ic
                       int prior_type, float sdf_clip, int cmap_mode, const float *h_calib,
                       const float *d_points, int64_t N, float *d_occ,
                       int search, int precision, icon_work_t *work, void *stream);
+
+/* The same with the calibration left on the device: d_calib = 12 floats, calibs[0,:3,:4] row-major
+ * (HGPIFuNet.query receives `calibs` as a device tensor, lib/common/train_util.py:340-343); the
+ * kernels read it themselves, so query() never synchronises the stream to copy it to the host. */
+int icon_query_points_dcalib(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
+                             int prior_type, float sdf_clip, int cmap_mode, const float *d_calib,
+                             const float *d_points, int64_t N, float *d_occ,
+                             int search, int precision, icon_work_t *work, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dense lattice evaluation: one rank's Z-slab of reconEngine (lib/common/seg3d_lossless.py).

@@ -306,6 +306,19 @@ static void bary_heidrich(v3 p, v3 v0, v3 v1, v3 v2, float w[3])
     w[0] = (1.0f - b1) - b2; w[1] = b1; w[2] = b2;
 }
 
+/* icon_accel.c: the same two leaves through a BVH / ray bins, bit-identical results */
+typedef struct orc_accel orc_accel;
+orc_accel *orc_accel_build(const float *verts, int64_t V, const int64_t *faces, int64_t F);
+void orc_accel_free(orc_accel *A);
+void orc_accel_nearest(const orc_accel *A, const float *pts, int64_t N, float *out_d2, int64_t *out_idx);
+void orc_accel_check_sign(const orc_accel *A, const float *pts, int64_t N, uint8_t *inside);
+
+/* 1 (default): cal_sdf / query_icon answer the two O(N*F) leaves through icon_accel.c;
+ * 0: through the linear scans above (the definition).  tests/test_oracle_leaves.py holds both equal. */
+static int g_accel = 1;
+void orc_set_accel(int on) { g_accel = on ? 1 : 0; }
+int orc_get_accel(void) { return g_accel; }
+
 void orc_cal_sdf(const float *verts, int64_t V, const int64_t *faces, int64_t F,
                  const float *cmaps, const float *vis, const float *pts, int64_t N,
                  float *out_sdf, float *out_norm, float *out_cmap, float *out_vis,
@@ -316,8 +329,15 @@ void orc_cal_sdf(const float *verts, int64_t V, const int64_t *faces, int64_t F,
     int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (size_t)N);
     uint8_t *ins = (uint8_t *)malloc((size_t)N);
     orc_vertex_normals(verts, V, faces, F, vn);
-    orc_nearest_brute(verts, faces, F, pts, N, d2, idx);
-    orc_check_sign(verts, faces, F, pts, N, ins);
+    if (g_accel) {
+        orc_accel *A = orc_accel_build(verts, V, faces, F);
+        orc_accel_nearest(A, pts, N, d2, idx);
+        orc_accel_check_sign(A, pts, N, ins);
+        orc_accel_free(A);
+    } else {
+        orc_nearest_brute(verts, faces, F, pts, N, d2, idx);
+        orc_check_sign(verts, faces, F, pts, N, ins);
+    }
     const float sqrt3 = sqrtf(3.0f);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < N; ++i) {
@@ -556,6 +576,65 @@ void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t
     orc_mask_in_cube(xyz, N, out_occ);
     if (!out_x) free(X);
     free(xyz); free(sdf); free(nrm); free(cm); free(vs); free(olist); free(orank);
+}
+
+/* The same call, but the MLP (and the output) only for the points listed in `subset` (M indices into
+ * the call, ascending or not): the geometry half runs on ALL N points because the tiled outlier-cmap
+ * assignment makes every point depend on the outlier signs of the whole call.  This is what lets
+ * bench.py check a stratified sample of the 257^3 lattice against the checker in seconds.
+ * out_occ [M], out_x [M, C/2+7] (optional). */
+void orc_query_icon_subset(const float *verts, int64_t V, const int64_t *faces, int64_t F,
+                           const float *cmaps, const float *vis,
+                           const float *feat, int C, int H, int W,
+                           const orc_mlp *mlp, float sdf_clip, const float *calib,
+                           const float *pts, int64_t N, const int64_t *subset, int64_t M,
+                           float *out_occ, float *out_x, int accumulate_f64, int cmap_local)
+{
+    const int half = C / 2;
+    const int c0 = half + 7;
+    float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    orc_project(calib, pts, N, xyz);
+    float *sdf = (float *)malloc(sizeof(float) * (size_t)N);
+    float *nrm = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    float *cm = (float *)malloc(sizeof(float) * 3 * (size_t)N);
+    float *vs = (float *)malloc(sizeof(float) * (size_t)N);
+    orc_cal_sdf(verts, V, faces, F, cmaps, vis, xyz, N, sdf, nrm, cm, vs, NULL, NULL);
+    int8_t *olist = (int8_t *)malloc((size_t)(N > 0 ? N : 1));
+    int64_t *orank = (int64_t *)malloc(sizeof(int64_t) * (size_t)(N > 0 ? N : 1));
+    int64_t K = 0;
+    for (int64_t i = 0; i < N; ++i) {
+        orank[i] = -1;
+        if (fabsf(sdf[i]) >= sdf_clip) {
+            orank[i] = K;
+            olist[K++] = (int8_t)((sdf[i] > 0.0f) ? 1 : ((sdf[i] < 0.0f) ? -1 : 0));
+        }
+    }
+    float *X = out_x ? out_x : (float *)malloc(sizeof(float) * (size_t)c0 * (size_t)(M > 0 ? M : 1));
+    float *sxyz = (float *)malloc(sizeof(float) * 3 * (size_t)(M > 0 ? M : 1));
+#pragma omp parallel for schedule(static)
+    for (int64_t m = 0; m < M; ++m) {
+        const int64_t i = subset[m];
+        float s = sdf[i];
+        float c3[3] = { cm[3 * i], cm[3 * i + 1], cm[3 * i + 2] };
+        if (orank[i] >= 0) {
+            const int64_t j = orank[i];
+            s = (float)olist[j];
+            for (int k = 0; k < 3; ++k) c3[k] = cmap_local ? s : (float)olist[(3 * j + k) % K];
+        }
+        float fall[64];
+        orc_bilinear(feat, C, H, W, xyz[3 * i], xyz[3 * i + 1], fall);
+        const int off = (vs[i] != 0.0f) ? 0 : half;
+        float *x = X + (size_t)c0 * m;
+        for (int k = 0; k < half; ++k) x[k] = fall[off + k];
+        x[half] = s;
+        x[half + 1] = c3[0]; x[half + 2] = c3[1]; x[half + 3] = c3[2];
+        x[half + 4] = nrm[3 * i]; x[half + 5] = nrm[3 * i + 1]; x[half + 6] = nrm[3 * i + 2];
+        sxyz[3 * m] = xyz[3 * i]; sxyz[3 * m + 1] = xyz[3 * i + 1]; sxyz[3 * m + 2] = xyz[3 * i + 2];
+    }
+    orc_mlp_forward(mlp, X, M, c0, out_occ, accumulate_f64);
+    orc_mask_in_cube(sxyz, M, out_occ);
+    if (!out_x) free(X);
+    free(xyz); free(sdf); free(nrm); free(cm); free(vs); free(olist); free(orank); free(sxyz);
 }
 
 /* PaMIR branch (HGPIFuNet.py:348-354): point_feat = [index(im_feat, xy) (C), index(vol_feat, xyz) (Cv)]

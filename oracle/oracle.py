@@ -20,8 +20,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "icon_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("icon_oracle.c", "icon_accel.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -38,6 +38,8 @@ def lib():
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_point_tri_dist2.restype = C.c_float
         _lib.orc_ray_hit.restype = C.c_int
+        _lib.orc_get_accel.restype = C.c_int
+        _lib.orc_accel_build.restype = C.c_void_p
     return _lib
 
 
@@ -80,6 +82,40 @@ def nearest_brute(verts, faces, pts):
     lib().orc_nearest_brute(_p(verts), _p(faces), C.c_int64(len(faces)), _p(pts), C.c_int64(len(pts)),
                             _p(d2), _p(idx))
     return d2, idx
+
+
+def set_accel(on: bool) -> None:
+    """cal_sdf / query_icon through the BVH + ray bins of icon_accel.c (default) or the linear scans"""
+    lib().orc_set_accel(C.c_int(int(on)))
+
+
+class Accel:
+    """BVH + (y,z) ray bins over one mesh (icon_accel.c): the two O(N*F) leaves, bit-identical to the scans."""
+
+    def __init__(self, verts, faces):
+        self.verts, self.faces = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3)
+        self.h = C.c_void_p(lib().orc_accel_build(_p(self.verts), C.c_int64(len(self.verts)), _p(self.faces),
+                                                  C.c_int64(len(self.faces))))
+
+    def __del__(self):
+        try:
+            if self.h:
+                lib().orc_accel_free(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def nearest(self, pts):
+        pts = _f32(pts).reshape(-1, 3)
+        d2, idx = np.empty(len(pts), np.float32), np.empty(len(pts), np.int64)
+        lib().orc_accel_nearest(self.h, _p(pts), C.c_int64(len(pts)), _p(d2), _p(idx))
+        return d2, idx
+
+    def check_sign(self, pts):
+        pts = _f32(pts).reshape(-1, 3)
+        out = np.empty(len(pts), np.uint8)
+        lib().orc_accel_check_sign(self.h, _p(pts), C.c_int64(len(pts)), _p(out))
+        return out.astype(bool)
 
 
 def check_sign(verts, faces, pts):
@@ -178,6 +214,26 @@ def query_icon(verts, faces, cmap, vis, feat, mlp: Mlp, pts, sdf_clip=0.05, cali
                          _p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), C.byref(mlp.struct),
                          C.c_float(np.float32(sdf_clip)), _p(cal), _p(pts), C.c_int64(n), _p(occ), _p(X),
                          C.c_int(int(f64)), C.c_int(int(cmap_local)))
+    return occ, X
+
+
+def query_icon_subset(verts, faces, cmap, vis, feat, mlp: Mlp, pts, subset, sdf_clip=0.05, calib=None, f64=False,
+                      cmap_local=False):
+    """query_icon over the call ``pts`` but occupancy only for ``pts[subset]`` (the geometry half and the
+    outlier sign list still cover the whole call) -> (occ [M], X [M, C/2+7])"""
+    verts, faces = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3)
+    cmap, vis, pts = _f32(cmap).reshape(-1, 3), _f32(vis).reshape(-1), _f32(pts).reshape(-1, 3)
+    subset = _i64(subset).reshape(-1)
+    feat = _f32(feat)
+    feat = feat.reshape(feat.shape[-3:])
+    Cc, H, W = feat.shape
+    occ = np.empty(len(subset), np.float32)
+    X = np.empty((len(subset), Cc // 2 + 7), np.float32)
+    cal = _calib12(calib)
+    lib().orc_query_icon_subset(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(cmap), _p(vis),
+                                _p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), C.byref(mlp.struct),
+                                C.c_float(np.float32(sdf_clip)), _p(cal), _p(pts), C.c_int64(len(pts)), _p(subset),
+                                C.c_int64(len(subset)), _p(occ), _p(X), C.c_int(int(f64)), C.c_int(int(cmap_local)))
     return occ, X
 
 

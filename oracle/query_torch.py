@@ -46,17 +46,29 @@ def build_mlp(state_dict) -> TorchMLP:
 
 
 TIMES = {"leaves": 0.0}
+_ACCEL = {}
+
+
+def _accel(verts, faces):
+    """one BVH + ray-bin structure per mesh (oracle/icon_accel.c): the exact accelerated leaves SURVEY.md
+    section 8(d) asks the timed CPU path to use; bit-identical to the linear scans (tests/test_oracle_leaves.py)"""
+    k = (verts.ctypes.data, faces.ctypes.data, verts.shape, faces.shape)
+    if k not in _ACCEL:
+        _ACCEL.clear()
+        _ACCEL[k] = (orc.Accel(verts, faces), verts, faces)
+    return _ACCEL[k][0]
 
 
 def cal_sdf_batch(verts, faces, cmaps, vis, points):
     """mesh_util.py:357-396; tensors [1,V,3] [1,F,3] [1,V,3] [1,V,1] [1,N,3]"""
     import time
     t0 = time.perf_counter()
-    leaf_sign = orc.check_sign(verts[0].numpy(), faces[0].numpy(), points[0].numpy())
+    acc = _accel(verts[0].numpy(), faces[0].numpy())
+    leaf_sign = acc.check_sign(points[0].numpy())
     vn = torch.from_numpy(orc.vertex_normals(verts[0].numpy(), faces[0].numpy()))[None]
     fl = faces[0].long()
     tri, nrm, cm, vs = verts[0][fl], vn[0][fl], cmaps[0][fl], vis[0][fl]          # face_vertices
-    d2, idx = orc.nearest_brute(verts[0].numpy(), faces[0].numpy(), points[0].numpy())
+    d2, idx = acc.nearest(points[0].numpy())
     TIMES["leaves"] += time.perf_counter() - t0
     idx = torch.from_numpy(idx)
     ct, cn, cc, cv = tri[idx], nrm[idx], cm[idx], vs[idx]                          # gathers

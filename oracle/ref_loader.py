@@ -25,6 +25,7 @@ from types import SimpleNamespace
 REFERENCE_ROOT = os.environ.get("ICON_REFERENCE_ROOT", "/root/reference")
 
 _loaded = None
+ACCEL = [True]
 
 
 def available() -> bool:
@@ -61,20 +62,23 @@ def load():
     from oracle import oracle as orc
 
     # ---- leaves -------------------------------------------------------------------
+    # ACCEL[0]: answer the two O(N*F) leaves through oracle/icon_accel.c (BVH / ray bins; bit-identical
+    # to the linear scans, tests/test_oracle_leaves.py) - what bench.py's timed "reference" leg uses
     def point_to_mesh_distance(points, triangles):
         # kaolin signature: points [B,N,3], face_vertices [B,F,3,3] -> (dist2 [B,N], idx [B,N], type)
         assert points.shape[0] == 1
         tri = triangles[0].detach().cpu().numpy().astype(np.float32)
         verts = tri.reshape(-1, 3)
         faces = np.arange(len(verts), dtype=np.int64).reshape(-1, 3)
-        d2, idx = orc.nearest_brute(verts, faces, points[0].detach().cpu().numpy())
+        pts = points[0].detach().cpu().numpy()
+        d2, idx = orc.Accel(verts, faces).nearest(pts) if ACCEL[0] else orc.nearest_brute(verts, faces, pts)
         return (torch.from_numpy(d2)[None], torch.from_numpy(idx)[None],
                 torch.zeros(1, len(d2), dtype=torch.int32))
 
     def check_sign(verts, faces, points, hash_resolution=512):
         assert verts.shape[0] == 1 and faces.dim() == 2
-        ins = orc.check_sign(verts[0].detach().cpu().numpy(), faces.detach().cpu().numpy(),
-                             points[0].detach().cpu().numpy())
+        v, f, pts = verts[0].detach().cpu().numpy(), faces.detach().cpu().numpy(), points[0].detach().cpu().numpy()
+        ins = orc.Accel(v, f).check_sign(pts) if ACCEL[0] else orc.check_sign(v, f, pts)
         return torch.from_numpy(ins)[None]
 
     class Meshes:

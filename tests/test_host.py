@@ -149,3 +149,43 @@ def test_synthetic_assets_are_deterministic():
     import hashlib
     h = hashlib.sha1(a.features.tobytes() + a.state_dict["filters.1.weight"].tobytes()).hexdigest()
     assert h == open(os.path.join(ROOT, "tests", "golden", "synth.sha1")).read().strip()
+
+
+def test_unsupported_regressors_are_refused():
+    """lib/net/MLP.py builds GroupNorm / InstanceNorm / weight_norm variants and a Sigmoid last_op
+    (cfg.test_mode False): folding only equals eval-mode BatchNorm1d without last_op, everything else
+    must raise instead of silently mis-evaluating."""
+    import torch.nn as nn
+    from icon_amd.engine import check_regressor
+    from icon_amd._lib import IconAmdError
+    from oracle.query_torch import TorchMLP
+
+    ok = TorchMLP().eval()
+    ok.norm, ok.last_op = "batch", None
+    check_regressor(ok)
+    check_regressor({k: v for k, v in ok.state_dict().items()})
+    for attr, val in (("norm", "group"), ("norm", "instance"), ("norm", "weight"), ("last_op", nn.Sigmoid())):
+        m = TorchMLP().eval()
+        m.norm, m.last_op = "batch", None
+        setattr(m, attr, val)
+        with pytest.raises(IconAmdError):
+            check_regressor(m)
+    m = TorchMLP()
+    m.norm, m.last_op = "batch", None
+    m.train()
+    with pytest.raises(IconAmdError):
+        check_regressor(m)
+    gn = {"filters.0.weight": torch.zeros(4, 3, 1), "norms.0.weight": torch.ones(4), "norms.0.bias": torch.zeros(4)}
+    with pytest.raises(IconAmdError):
+        check_regressor(gn)
+
+
+def test_handle_cache_keys_hold_their_tensors():
+    """a cached handle is only valid while the tensors its key was made from are alive (otherwise the
+    caching allocator can give the next image's features the same address): the engine keeps strong refs"""
+    from icon_amd.engine import IconQueryEngine
+    src = open(os.path.join(ROOT, "icon_amd", "engine.py")).read()
+    for name in ("_mesh_src", "_feat_src", "_mlp_src", "_vol_src"):
+        assert re.search(rf"self\.{name}\s*=|self\._\w+_key, self\.{name} =", src), name
+    eng = IconQueryEngine()
+    assert eng._feat_src is None and eng.precision == "f16x3"

@@ -132,3 +132,49 @@ def test_body_mesh_sign_matches_star_shape():
     sure = np.abs(rad / lim - 1) > 0.08
     assert np.array_equal(ins[sure], (rad < lim)[sure])
     assert ins.sum() > 5
+
+
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+def test_accelerated_leaves_equal_the_linear_scans(mesh):
+    """oracle/icon_accel.c (BVH nearest + binned ray parity) against the definitions in icon_oracle.c: squared
+    distance bit for bit, the same face index (lowest on float32 ties), the same inside flag - on
+    near-surface / far / boundary points, lattice points, mesh vertices and edge midpoints (exact ties,
+    rays through vertices and edges)."""
+    a = synth.make_assets(mesh)
+    v, f = a.smpl_verts[0], a.smpl_faces[0]
+    pts = np.concatenate([synth.stratified_points(v, f, 3000), synth.lattice_points(17), v[:400],
+                          ((v[f[:400, 0]] + v[f[:400, 1]]) / 2).astype(np.float32)])
+    d2b, ib = orc.nearest_brute(v, f, pts)
+    sb = orc.check_sign(v, f, pts)
+    acc = orc.Accel(v, f)
+    d2a, ia = acc.nearest(pts)
+    sa = acc.check_sign(pts)
+    assert np.array_equal(d2a.view(np.int32), d2b.view(np.int32))
+    assert np.array_equal(ia, ib)
+    assert np.array_equal(sa, sb)
+
+
+def test_cal_sdf_accel_switch_is_invisible():
+    a = synth.make_assets("body")
+    v, f = a.smpl_verts[0], a.smpl_faces[0]
+    pts = synth.stratified_points(v, f, 1500, seed=3)
+    try:
+        orc.set_accel(False)
+        slow = orc.cal_sdf(v, f, a.smpl_cmap[0], a.smpl_vis[0], pts)
+    finally:
+        orc.set_accel(True)
+    fast = orc.cal_sdf(v, f, a.smpl_cmap[0], a.smpl_vis[0], pts)
+    for k in slow:
+        assert np.array_equal(slow[k], fast[k]), k
+
+
+def test_query_icon_subset_equals_full_call():
+    """the subset form (bench.py's live parity sample) returns exactly the rows of the full call"""
+    a = synth.make_assets("body")
+    pts = synth.lattice_points(17)
+    mlp = orc.Mlp(a.state_dict)
+    occ, X = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, mlp, pts)
+    sub = np.random.RandomState(0).choice(len(pts), 700, replace=False)
+    occ_s, X_s = orc.query_icon_subset(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, mlp,
+                                       pts, sub)
+    assert np.array_equal(X_s, X[sub]) and np.array_equal(occ_s, occ[sub])
