@@ -41,7 +41,7 @@ ALGO_BYTES_PER_POINT = 4              # one fp32 occupancy wri
 PEAK_TFLOPS = {"f32": 157.3,          # v_mfma_f32_32x32x2_f32
                "f16x3": 2500.0,       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
                "mx6": 2500.0}         # same f16 peak; 4 f16 + 2 fp6 MFMAs per K=64 (1.5 issue slots per K=16)
-KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_mlp_f16x3", "mx6": "k_mlp_mx6"}
+KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_fused_f16x3", "mx6": "k_mlp_mx6"}   # f16x3: features + MLP in one kernel
 DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (22-bit operands, f32 accumulate)",
          "mx6": "f32 via f16 MFMA + block-scaled fp6 cross terms (NOT f32-equivalent; calibrated opt-in)"}
 
@@ -241,7 +241,7 @@ def main():
     assert occ is not None and occ.shape == (res, res, res)
 
     n_points = res ** 3
-    z0, z1, _ = slab_bounds(res, world, rank) if world > 1 else (0, res, res)
+    z0, z1 = recon.last_stats["slabs"][rank] if world > 1 else (0, res)      # the cut the engine actually used
     my_points = (z1 - z0) * res * res
     value = n_points * args.steps / elapsed
     mlp_s = stage[2] * 1e-3

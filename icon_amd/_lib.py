@@ -30,8 +30,8 @@ SYMBOLS = [
     "icon_work_create", "icon_work_destroy", "icon_work_profile", "icon_work_stage_ms",
     "icon_query_points", "icon_query_points_dcalib",
     "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish", "icon_grid_slab_finish_gathered",
-    "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_debug_traversal_stats",
-    "icon_visibility",
+    "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_debug_traversal_stats", "icon_debug_set_unfused",
+    "icon_visibility", "icon_mesh_components",
 ]
 
 _lib = None

@@ -88,6 +88,10 @@ constexpr int kCodeSlot = 15;      // row slot holding the per-point code word
 constexpr uint32_t kCodeOutlier = 1u;          // |sdf| >= sdf_clip
 constexpr uint32_t kCodeSignShift = 1;         // 2 bits: sign(sdf) + 1  (0,1,2)
 constexpr uint32_t kCodeInCube = 8u;           // all(-1 < xyz < 1)
+constexpr uint32_t kCodeInside = 16u;          // check_sign: the point is inside the body (k_sign only)
+
+constexpr int kScanBlock = 256;    // points per block of the outlier count / scan / compact passes == one tile of the fused kernel
+constexpr int kMaxWorld = 64;      // ranks whose sign messages one gathered buffer may hold
 
 struct MeshDev {
     const BvhNode *nodes;
@@ -119,6 +123,25 @@ struct Calib { float m[12]; const float *d; };
 // lattice descriptor: point i -> (x, y, z) index; world = idx/(R-1) * (bmax-bmin) + bmin
 struct Lattice {
     int32_t res, z0, z1;
+};
+
+// Lattice tiling of the geometry kernels (see geom_device.h: lattice_point)
+struct LatticeMap {
+    int res, z0, nz;           // evaluated planes [z0, z0+nz)
+    int tx, ty, tz;            // tile counts
+    int remap;                 // 1: contiguous run of tiles per XCD, 0: tiles interleaved over XCDs
+};
+
+// where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)
+enum { kSignNone = 0, kSignSelf = 1, kSignGlobal = 2, kSignSeg = 3 };
+struct FusedSigns {
+    int mode;
+    const int8_t *list;           // SELF / GLOBAL: signs in point order
+    const int64_t *k_dev;         // SELF: device scalar K
+    int64_t k_host, rank_offset;  // GLOBAL
+    const int8_t *gathered;       // SEG: all_gather output, message r = [int64 count][int8 signs]
+    int64_t stride;
+    int world, rank;
 };
 
 }  // namespace icon
@@ -175,13 +198,20 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
 uint16_t f32_to_f16_rtn(float f);
 float f16_to_f32(uint16_t h);
 float pick_scale(const std::vector<float> &W);     // power of two that brings max|W| to ~8192
+// fused_f16x3.hip
+int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const float *d_points, int64_t N, float sdf_clip,
+                const icon_work *work, bool lattice, hipStream_t st);
+int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_mlp *mlp, int prior, const Calib &cal,
+                       int res, int z0, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
+                       const icon_work *work, const FusedSigns &fs, float *d_occ, bool lattice, hipStream_t st);
 // mlp_mx6.hip
 int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
 int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
 }  // namespace icon
 
 struct icon_work {
-    float *d_x = nullptr;                 // [cap_points][16] MLP input rows
+    float *d_x = nullptr;                 // [cap_x][16] MLP input rows (materialising paths only: f32 / mx6 / brute force)
+    int64_t cap_x = 0;
     void *d_near = nullptr;               // [cap_points] (slot, d^2 bits) from k_nearest
     uint8_t *d_code8 = nullptr;           // [cap_points] byte copy of each row's code word
     int64_t cap_points = 0;
@@ -191,6 +221,7 @@ struct icon_work {
     int8_t *d_signs = nullptr;            // compacted outlier signs of the call
     int64_t cap_signs = 0;
     int64_t *d_total = nullptr;           // device scalar: number of outliers
+    int64_t *d_seg = nullptr;             // [kMaxWorld + 1] prefix of the per-rank counts of a gathered exchange
     int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
     int32_t *d_row_slots = nullptr;       // [rows][kRowCap]
     int64_t cap_rows = 0;
@@ -203,6 +234,16 @@ struct icon_work {
     // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
     int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
     bool slab_ready = false, slab_needs_patch = false;
+    // what phase 1 of a query recorded for phase 2 (the handles must outlive the pair of calls)
+    const icon_mesh *q_mesh = nullptr;
+    const icon_feat *q_feat = nullptr;
+    int q_prior = 0, q_cmap_mode = 0, q_search = 0;
+    float q_sdf_clip = 0.f;
+    icon::Calib q_cal{};
+    icon::LatticeMap q_L{};
+    const float *q_points = nullptr;
+    int64_t q_N = 0;
+    bool q_lattice = false, q_rows_ready = false;
     icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
     bool prof = false;

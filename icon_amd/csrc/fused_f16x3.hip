@@ -1,0 +1,378 @@
+// fused_f16x3.hip - HGPIFuNet.query with NOTHING but the occupancy written to HBM per point:
+// the 13-channel MLP input of a point is assembled in LDS by the same persistent workgroup that then
+// carries it through the 3x-f16 MFMA chain (mlp_f16x3_device.h).  Default path (precision f16x3).
+//
+//   before (round 1)                                   HBM per point
+//     k_nearest            -> (slot, d^2)                  8 B  w
+//     k_features           -> X row [16] f32 + code      8 r + 65 w
+//     count / scan / compact over the codes                2 r + <=1 w
+//     k_outlier_patch_self -> X rows rewritten         1 + 64 r + 64 w     (reference cmap mode)
+//     k_mlp_f16x3          <- X rows                      64 r + 4 w      => ~280 B/pt, 4.8 GB per 257^3
+//   now
+//     k_nearest            -> (slot, d^2)                  8 B  w
+//     k_sign               -> 1-byte code (outlier, sign, inside, in_cube)   8 r + 1 w
+//     count / scan / compact over the codes                2 r + <=1 w
+//     k_fused_f16x3        <- (slot, d^2), code, sign list; -> occupancy     8 + 1 + ~3 r + 4 w
+//                                                                         => ~36 B/pt, 0.6 GB per 257^3
+// (the algorithmic traffic is the 4-byte occupancy; what is left on top is the
+// nearest-triangle result handed from the VALU-bound traversal kernel to the MFMA-bound one.)
+//
+// Reference being replaced: lib/net/HGPIFuNet.py:268-367 (query), lib/dataset/mesh_util.py:357-396,
+// lib/net/geometry.py:21-61, lib/net/MLP.py:49-72.  The geometry arithmetic is the shared, bit-exact code
+// of geom_device.h (this file is compiled with -ffp-contract=off like query_kernels.hip); the MLP
+// arithmetic is the shared code of mlp_f16x3_device.h, so the results are IDENTICAL to the unfused
+// f16x3 path (tests/test_gpu_parity.py::test_fused_equals_unfused).
+//
+// Workgroup = 512 threads = 8 waves, ONE per CU (LDS: 80 KiB weight double buffer + 32 KiB resident W0 +
+// side arrays + 16 KiB point tile), persistent: it walks tiles of 256 consecutive points of the call's
+// linear order, so the outlier rank of a point = the tile's offset from the scan + a ballot prefix, and the
+// reference's tiled cmap rule cmap[j][k] = s[(3j+k) mod K] (HGPIFuNet.py:303-305) is three byte loads.
+// W0 / biases are staged once per workgroup; chunk 0 of the next tile is DMA'd during the last layer-2 chunk.
+#pragma clang fp contract(off)
+
+#include "geom_device.h"
+#include "mlp_f16x3_device.h"
+
+namespace icon {
+
+constexpr int kTilePts = kF16Pts;                     // 256 points per tile
+constexpr int kXsOff = kSideOff + 4352;               // point tile [256][16] f32 behind the side arrays
+constexpr int kMiscOff = kXsOff + kTilePts * kXRow * 4;
+constexpr int kFusedLds = kMiscOff + 16;                  // + the four wave sums of the outlier ballot
+
+struct SignSrc {
+    int mode;
+    const int8_t *list;          // SELF / GLOBAL: the outlier signs of the call in point order
+    const int64_t *k_dev;        // SELF: device scalar K
+    int64_t k_host, rank_offset; // GLOBAL: K and the number of outliers in lower slabs
+    const int8_t *gathered;      // SEG: all_gather output, message r = [int64 count][int8 signs]
+    int64_t stride;
+    int world, rank;
+    const int64_t *seg;          // SEG: [world + 1] exclusive prefix of the counts (k_seg_offsets)
+};
+
+struct FusedGeom {
+    MeshDev m;
+    FeatDev f;
+    Calib cal;
+    int res, z0;                 // lattice mode
+    const float *pts;            // point mode
+    int64_t N;
+    float sdf_clip;
+    int cmap_local;
+    const int2 *near;            // icon prior: (slot, bits of d^2) from k_nearest / k_nearest_coop
+    const uint8_t *code8;        // icon prior: k_sign
+    const int64_t *tile_offsets; // exclusive scan of the outlier counts per 256-point tile
+    SignSrc sg;
+};
+
+// ---------------------------------------------------------------------------------------------
+// k_sign: outlier flag, sign, inside flag and in_cube flag of every point (icon prior), 1 byte
+// ---------------------------------------------------------------------------------------------
+template <bool LATTICE>
+__global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
+                                              float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
+                                              const int2 *__restrict__ near, uint8_t *__restrict__ code8)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    f3 p; bool ins;
+    if (LATTICE) {
+        const int64_t row = i / res;
+        const int ix = (int)(i - row * res), iy = (int)(row % res), iz = (int)(row / res);
+        p = lattice_world(res, ix, iy, iz + z0);
+        ins = inside_row(m, p, row_count, row_slots, row);
+    } else {
+        p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        ins = inside_bins(m, p);
+    }
+    const float dist = sqrtf(__int_as_float(near[i].y)) / sqrtf(3.0f);     // mesh_util.py:391
+    const float s = ins ? dist : -dist;                                   // :393-394
+    uint32_t code = in_cube_bit(p) | (ins ? kCodeInside : 0u);
+    if (fabsf(s) >= sdf_clip) {                                            // HGPIFuNet.py:298
+        const int sg = (s > 0.0f) ? 1 : ((s < 0.0f) ? -1 : 0);
+        code |= kCodeOutlier | ((uint32_t)(sg + 1) << kCodeSignShift);
+    }
+    code8[i] = (uint8_t)code;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused kernel
+// ---------------------------------------------------------------------------------------------
+// SEG mode: `off` = exclusive prefix of the per-rank counts (world + 1 entries, global memory written by
+// k_seg_offsets, read here through wave-uniform scalar loads): segment of mm = number of boundaries <= mm
+__device__ __forceinline__ float sign_at(const SignSrc &sg, int64_t mm)
+{
+    if (sg.mode == kSignSeg) {
+        int r = 0;
+        int64_t base = 0;
+        for (int q = 1; q < sg.world; ++q) {
+            const int64_t o = sg.seg[q];
+            const bool ge = mm >= o;
+            r += ge ? 1 : 0;
+            base = ge ? o : base;
+        }
+        return (float)sg.gathered[(int64_t)r * sg.stride + 8 + (mm - base)];
+    }
+    return (float)sg.list[mm];
+}
+
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int PRIOR, bool LATTICE>
+__global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float *__restrict__ out, MlpF16Dev w)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float *Xs = reinterpret_cast<float *>(smem + kXsOff);
+    int *wsum = reinterpret_cast<int *>(smem + kMiscOff);
+
+    // ---- once per workgroup: resident layer-0 operands, side arrays, sign-list geometry ------------------
+    issue_units(w.image, smem + kW0Off, kW0Bytes / 1024, wave0, lane0);
+    float *side = reinterpret_cast<float *>(smem + kSideOff);
+    for (int i = threadIdx.x; i < kSideFloats; i += kF16Block) side[i] = w.side[i];
+    const float *sb0 = side, *sb1 = side + 512, *sb2 = side + 768, *sw3 = side + 896;
+    int64_t K = 0, rank0 = 0;
+    if (PRIOR == ICON_PRIOR_ICON && !G.cmap_local) {
+        if (G.sg.mode == kSignSelf) K = *G.sg.k_dev;
+        else if (G.sg.mode == kSignGlobal) { K = G.sg.k_host; rank0 = G.sg.rank_offset; }
+        else if (G.sg.mode == kSignSeg) { K = G.sg.seg[G.sg.world]; rank0 = G.sg.seg[G.sg.rank]; }
+    }
+    // wave-uniform 64-bit values that live across the whole MLP body: keep them in SGPRs, not in the
+    // 250-register vector budget of the MFMA chain
+    K = uniform64(K); rank0 = uniform64(rank0);
+
+    const int64_t ntiles = (G.N + kTilePts - 1) / kTilePts;
+    int64_t tile = blockIdx.x;
+    if (tile < ntiles) issue_chunk(w.image, smem, 0, wave0, lane0);
+
+    for (; tile < ntiles; tile += gridDim.x) {
+        // Everything derived from the thread index is re-derived per tile from an opaque copy: hoisted out of
+        // the loop, those ~20 lane-dependent addresses would have to stay live across the 250-register MFMA
+        // body, i.e. be spilled to scratch (measured: 1.5 GB of scratch writes per 257^3 launch).
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int j = lane & 31, h = lane >> 5;
+        // ---- feature phase: waves 0-3, one point per thread -> Xs[t][16] ---------------------------------
+        const int t = tid;
+        const bool worker = t < kTilePts;                       // wave-uniform
+        int64_t i = tile * kTilePts + (worker ? t : 0);
+        const bool live = i < G.N;
+        if (!live) i = G.N - 1;
+        uint32_t code = 0;
+        int2 nn = make_int2(0, 0);
+        bool outl = false;
+        if (PRIOR == ICON_PRIOR_ICON) {
+            if (worker) {
+                code = G.code8[i];
+                nn = G.near[i];
+                outl = live && (code & kCodeOutlier);
+            }
+            const unsigned long long b = __ballot(outl);
+            if (worker && lane == 0) wsum[wave] = __popcll(b);
+            __syncthreads();
+            if (worker) {
+                f3 p;
+                if (LATTICE) {
+                    const int64_t row = i / G.res;
+                    p = lattice_world(G.res, (int)(i - row * G.res), (int)(row % G.res), (int)(row / G.res) + G.z0);
+                } else {
+                    p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
+                }
+                Nearest nr; nr.slot = nn.x; nr.d2 = __int_as_float(nn.y); nr.face = 0;
+                const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
+                float s = o.sdf;
+                f3 cmv = o.cm;
+                if (code & kCodeOutlier) {                      // HGPIFuNet.py:298-305
+                    s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
+                    if (G.cmap_local) cmv = mk3(s, s, s);
+                    else if (K > 0) {
+                        int before = 0;
+                        for (int k = 0; k < wave; ++k) before += wsum[k];
+                        before += __popcll(b & ((1ull << lane) - 1ull));
+                        const int64_t jr = rank0 + G.tile_offsets[tile] + before;
+                        float c3[3];
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            int64_t mm = 3 * jr + k;            // jr < K  =>  mm < 3K
+                            if (mm >= K) mm -= K;
+                            if (mm >= K) mm -= K;
+                            c3[k] = sign_at(G.sg, mm);
+                        }
+                        cmv = mk3(c3[0], c3[1], c3[2]);
+                    }
+                }
+                // the row goes to LDS slot by slot (no 16-wide register tuple next to the MFMA accumulators);
+                // slots >= c0 are never read as data (masked by index in the MLP part), slot 15 = in_cube flag
+                float *xrow = Xs + t * kXRow;
+                gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
+                const int hh = G.f.csel;
+                xrow[hh] = s;
+                xrow[hh + 1] = cmv.x; xrow[hh + 2] = cmv.y; xrow[hh + 3] = cmv.z;
+                xrow[hh + 4] = o.nrm.x; xrow[hh + 5] = o.nrm.y; xrow[hh + 6] = o.nrm.z;
+                xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
+            }
+        } else {
+            if (worker) {
+                f3 p;
+                if (LATTICE) {
+                    const int64_t row = i / G.res;
+                    p = lattice_world(G.res, (int)(i - row * G.res), (int)(row % G.res), (int)(row / G.res) + G.z0);
+                } else {
+                    p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
+                }
+                float *xrow = Xs + t * kXRow;
+                gather_planes_dyn(G.f, 0, p.x, p.y, xrow);
+                const int hh = G.f.csel;
+                if (PRIOR == ICON_PRIOR_PAMIR) {
+                    float v[8];
+                    if (G.f.vpad == 8) gather_volume<2>(G.f, p.x, p.y, p.z, v); else gather_volume<1>(G.f, p.x, p.y, p.z, v);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k < G.f.Cv) xrow[hh + k] = v[k];
+                } else {
+                    xrow[hh] = p.z;
+                }
+                xrow[kCodeSlot] = __int_as_float((int)in_cube_bit(p));
+            }
+        }
+        __syncthreads();          // tile visible; chunk 0 (and, the first time, W0 + side arrays) landed
+
+        // ---- MLP: one wave = 32 points, lane (j,h) holds input slots 8h..8h+7 of point j ------------------
+        const int pt = wave * 32 + j;
+        float xr[8];
+        {
+            const float4 *q = reinterpret_cast<const float4 *>(Xs + pt * kXRow + 8 * h);
+            const float4 a = q[0], b4 = q[1];
+            xr[0] = a.x; xr[1] = a.y; xr[2] = a.z; xr[3] = a.w; xr[4] = b4.x; xr[5] = b4.y; xr[6] = b4.z; xr[7] = b4.w;
+        }
+        const float maskf = (__float_as_int(Xs[pt * kXRow + kCodeSlot]) & (int)kCodeInCube) ? 1.0f : 0.0f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) xr[s] = (s + 8 * h < w.c0) ? xr[s] : 0.0f;
+        half8 xhi, xlo;
+        split8(xr, xhi, xlo);
+
+        f32x16 acc1[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) acc1[m] = ld16(sb1 + (m * 2 + h) * 16);
+        half8 bh[2], bl[2];
+        activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
+        for (int c = 0; c < 16; ++c) {
+            l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
+                      w.inv0, h, lane, wave, bh, bl);
+            __syncthreads();
+        }
+        f32x16 acc2[4];
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
+        activate_split(acc1[0], w.inv1, bh, bl);
+        l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        const bool more = tile + gridDim.x < ntiles;            // chunk 0 of the next tile rides on the last chunk
+        l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, more ? 0 : -1);
+
+        // ---- layer 3 on the VALU (f32) ---------------------------------------------------------------------
+        const float *w3 = sw3 + h * 72;
+        float part = 0.0f;
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) {
+            const f32x16 wv = ld16(w3 + m2 * 16);
+#pragma unroll
+            for (int tt = 0; tt < 16; ++tt) {
+                const float x = acc2[m2][tt] * w.inv2;
+                part = fmaf(wv[tt], fmaxf(x, 0.01f * x), part);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
+        const float other = __shfl_xor(part, 32);
+        const float y = (part + other) + w.b3;
+        const int64_t oi = tile * kTilePts + pt;
+        if (h == 0 && oi < G.N) out[oi] = maskf * y;
+    }
+}
+
+// exclusive prefix of the per-rank outlier counts found in the headers of the gathered messages
+__global__ void k_seg_offsets(const int8_t *__restrict__ gathered, int64_t stride, int world, int64_t *__restrict__ seg)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int64_t a = 0;
+    for (int r = 0; r < world; ++r) { seg[r] = a; a += *reinterpret_cast<const int64_t *>(gathered + (int64_t)r * stride); }
+    seg[world] = a;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const float *d_points, int64_t N, float sdf_clip,
+                const icon_work *work, bool lattice, hipStream_t st)
+{
+    const int64_t nb = (N + 255) / 256;
+    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    const int2 *near = reinterpret_cast<const int2 *>(work->d_near);
+    if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
+                                    work->d_row_count, work->d_row_slots, near, work->d_code8);
+    else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, near, work->d_code8);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_mlp *mlp, int prior, const Calib &cal,
+                       int res, int z0, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
+                       const icon_work *work, const FusedSigns &fs, float *d_occ, bool lattice, hipStream_t st)
+{
+    if (N <= 0) return ICON_OK;
+    FusedGeom G{};
+    if (mesh) G.m = mesh->dev;
+    G.f = feat->dev; G.cal = cal; G.res = res; G.z0 = z0; G.pts = d_points; G.N = N; G.sdf_clip = sdf_clip; G.cmap_local = cmap_local;
+    G.near = reinterpret_cast<const int2 *>(work->d_near); G.code8 = work->d_code8; G.tile_offsets = work->d_block_offsets;
+    G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
+    G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;
+    if (fs.mode == kSignSeg) {
+        if (!work->d_seg) return fail(ICON_ERR_STATE, "fused: segment offsets buffer missing");
+        hipLaunchKernelGGL(k_seg_offsets, dim3(1), dim3(64), 0, st, fs.gathered, fs.stride, fs.world, work->d_seg);
+        G.sg.seg = work->d_seg;
+    }
+    MlpF16Dev w;
+    w.image = mlp->d_f16;
+    w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
+    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
+
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        ICON_HIP(hipGetDevice(&dev));
+        ICON_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if (n_cu <= 0) n_cu = 256;
+    }
+    const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
+#define ICON_FUSED(P, L)                                                                                                   \
+    do {                                                                                                                   \
+        static bool attr = false;                                                                                          \
+        if (!attr) {                                                                                                       \
+            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L>),                                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));                          \
+            attr = true;                                                                                                   \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((k_fused_f16x3<P, L>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);                \
+    } while (0)
+    if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true); else ICON_FUSED(ICON_PRIOR_ICON, false); }
+    else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true); else ICON_FUSED(ICON_PRIOR_PAMIR, false); }
+    else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true); else ICON_FUSED(ICON_PRIOR_PIFU, false); }
+#undef ICON_FUSED
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+}  // namespace icon

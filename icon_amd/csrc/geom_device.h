@@ -639,11 +639,6 @@ __device__ __forceinline__ void gather_planes_dyn(const FeatDev &f, int sel, flo
 // round-robin), which balances the strongly position-dependent traversal cost.  The optional
 // contiguous-band-per-XCD remap (ICON_AMD_XCD_REMAP=1) keeps each L2 on one band of the body but
 // was measured 1.6x slower: the mesh fits every L2 anyway and the bands are unequal work.
-struct LatticeMap {
-    int res, z0, nz;           // evaluated planes [z0, z0+nz)
-    int tx, ty, tz;            // tile counts
-    int remap;                 // 1: contiguous run of tiles per XCD, 0: tiles interleaved over XCDs
-};
 
 __device__ __forceinline__ int xcd_remap(int b, int nb)
 {

@@ -238,7 +238,6 @@ __global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap 
 // outlier sign list (reference cmap mode): count -> scan -> compact -> patch, all in the linear
 // point order of the call.
 // ---------------------------------------------------------------------------------------------
-constexpr int kScanBlock = 1024;
 
 __device__ __forceinline__ uint32_t row_code(const float *X, int64_t i)
 {
@@ -332,7 +331,6 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict_
 // gathered + r * stride = [int64 count_r][int8 signs_r ...] (multi-GPU path, recon.py).  K, this
 // rank's offset and the segment of every index are derived on the device from the headers, so the
 // host never has to read the counts (no synchronisation between the exchange and the MLP launch).
-constexpr int kMaxWorld = 64;
 __global__ __launch_bounds__(kScanBlock) void k_outlier_patch_seg(float *__restrict__ X, const uint8_t *__restrict__ code8, int64_t N, int cmap_slot,
                                                                   const int64_t *block_offsets, const int8_t *__restrict__ gathered,
                                                                   int64_t stride, int world, int rank)
@@ -477,7 +475,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
@@ -503,129 +501,6 @@ extern "C" int icon_work_stage_ms(icon_work_t *w, float out_ms[3])
     for (int k = 0; k < 3; ++k) ICON_HIP(hipEventElapsedTime(&out_ms[k], w->ev[k], w->ev[k + 1]));
     return ICON_OK;
 }
-
-namespace {
-
-inline void mark(icon_work *w, int k, hipStream_t st)
-{
-    if (w->prof) { (void)hipEventRecord(w->ev[k], st); if (k == 3) w->ev_valid = true; }
-}
-
-int ensure_work(icon_work *w, int64_t n_points)
-{
-    if (n_points > w->cap_points) {
-        (void)hipFree(w->d_x); w->d_x = nullptr; w->cap_points = 0;
-        ICON_HIP(hipMalloc((void **)&w->d_x, (size_t)n_points * kXRow * sizeof(float)));
-        (void)hipFree(w->d_near); w->d_near = nullptr;
-        ICON_HIP(hipMalloc((void **)&w->d_near, (size_t)n_points * 8));
-        (void)hipFree(w->d_code8); w->d_code8 = nullptr;
-        ICON_HIP(hipMalloc((void **)&w->d_code8, (size_t)n_points));
-        w->cap_points = n_points;
-    }
-    const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
-    if (nblk > w->cap_blocks) {
-        (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-        w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->cap_blocks = 0;
-        ICON_HIP(hipMalloc((void **)&w->d_block_counts, (size_t)nblk * sizeof(int32_t)));
-        ICON_HIP(hipMalloc((void **)&w->d_block_offsets, (size_t)nblk * sizeof(int64_t)));
-        w->cap_blocks = nblk;
-    }
-    if (n_points > w->cap_signs) {
-        (void)hipFree(w->d_signs); w->d_signs = nullptr; w->cap_signs = 0;
-        ICON_HIP(hipMalloc((void **)&w->d_signs, (size_t)n_points));
-        w->cap_signs = n_points;
-    }
-    if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
-    return ICON_OK;
-}
-
-int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int *c0)
-{
-    ICON_ARG(feat != nullptr, "feature handle is null");
-    const FeatDev &f = feat->dev;
-    if (prior == ICON_PRIOR_ICON) {
-        ICON_ARG(mesh != nullptr, "icon prior needs a mesh handle");
-        ICON_ARG(f.n_select == 2, "icon prior needs feature planes created with n_select = 2");
-        *c0 = f.csel + 7;
-    } else if (prior == ICON_PRIOR_PAMIR) {
-        ICON_ARG(f.n_select == 1 && f.vol != nullptr, "pamir prior needs n_select = 1 and a volume");
-        *c0 = f.csel + f.Cv;
-    } else if (prior == ICON_PRIOR_PIFU) {
-        ICON_ARG(f.n_select == 1, "pifu prior needs n_select = 1");
-        *c0 = f.csel + 1;
-    } else {
-        return fail(ICON_ERR_ARG, "unknown prior_type");
-    }
-    if (*c0 > kCodeSlot) return fail(ICON_ERR_UNSUPPORTED, "more than 15 MLP input channels");
-    return ICON_OK;
-}
-
-template <bool LATTICE>
-int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sdf_clip, int cmap_mode,
-                    const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, int search,
-                    icon_work *work, hipStream_t st)
-{
-    float *d_x = work->d_x;
-    int32_t *row_count = nullptr, *row_slots = nullptr;
-    if (LATTICE && prior == ICON_PRIOR_ICON && search != ICON_SEARCH_BRUTE) {
-        const int64_t rows = (int64_t)L.nz * L.res;
-        if (rows > work->cap_rows) {
-            (void)hipFree(work->d_row_count); (void)hipFree(work->d_row_slots);
-            work->d_row_count = nullptr; work->d_row_slots = nullptr; work->cap_rows = 0;
-            ICON_HIP(hipMalloc((void **)&work->d_row_count, (size_t)rows * sizeof(int32_t)));
-            ICON_HIP(hipMalloc((void **)&work->d_row_slots, (size_t)rows * kRowCap * sizeof(int32_t)));
-            work->cap_rows = rows;
-        }
-        row_count = work->d_row_count; row_slots = work->d_row_slots;
-        hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
-                           row_count, row_slots);
-    }
-    int64_t nb;
-    if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
-    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    const dim3 grid((unsigned)nb), block(kBlock);
-    const MeshDev md = mesh ? mesh->dev : MeshDev{};
-    const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
-    const bool brute = (search == ICON_SEARCH_BRUTE);
-    int2 *near = nullptr;
-    if (prior == ICON_PRIOR_ICON && !brute) {
-        near = reinterpret_cast<int2 *>(work->d_near);
-        // point mode: sparse batches walk the tree one lane per point; a batch dense enough for a wave's 64
-        // Morton neighbours to be close together (>= ~2M points in the cube) goes through the packet kernel
-        const int32_t *perm = nullptr;
-        static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
-        if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
-            { const int cap = coop_cap((int)mesh->stats[1]);
-              hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), kCoopWaves * coop_wave_bytes(cap), st, md, cal, d_points, N, near, cap); }
-        } else {
-            if (!LATTICE) {
-                const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
-                if (rc) return rc;
-            }
-            hipLaunchKernelGGL((k_nearest<LATTICE>), grid, block, 0, st, md, cal, L, d_points, N, near, perm);
-        }
-    }
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, row_count, row_slots, near, d_x, work->d_code8)
-    if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
-    else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
-    else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
-#undef ICON_LAUNCH
-    ICON_HIP(hipGetLastError());
-    return ICON_OK;
-}
-
-// count + scan + compact over rows [0, N): fills w->d_block_offsets, w->d_total, and `signs`
-int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
-{
-    const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_block_offsets, w->d_total);
-    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
-    ICON_HIP(hipGetLastError());
-    return ICON_OK;
-}
-
-}  // namespace
 
 namespace icon {
 // device-side K: same as k_outlier_patch but K and the list come from this call's own scan
@@ -653,7 +528,142 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_patch_self(float *__rest
 }  // namespace icon
 
 namespace {
-int patch_only(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
+
+inline void mark(icon_work *w, int k, hipStream_t st)
+{
+    if (w->prof) { (void)hipEventRecord(w->ev[k], st); if (k == 3) w->ev_valid = true; }
+}
+
+// scratch for n_points: (slot, d^2) + 1-byte codes + scan arrays + sign list; the 64-byte input rows only
+// for the paths that still materialise them (need_x: precisions f32 / mx6 and the brute-force search)
+int ensure_work(icon_work *w, int64_t n_points, bool need_x)
+{
+    if (n_points > w->cap_points) {
+        (void)hipFree(w->d_near); w->d_near = nullptr; w->cap_points = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_near, (size_t)n_points * 8));
+        (void)hipFree(w->d_code8); w->d_code8 = nullptr;
+        ICON_HIP(hipMalloc((void **)&w->d_code8, (size_t)n_points));
+        w->cap_points = n_points;
+    }
+    if (need_x && n_points > w->cap_x) {
+        (void)hipFree(w->d_x); w->d_x = nullptr; w->cap_x = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_x, (size_t)n_points * kXRow * sizeof(float)));
+        w->cap_x = n_points;
+    }
+    const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
+    if (nblk > w->cap_blocks) {
+        (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
+        w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->cap_blocks = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_block_counts, (size_t)nblk * sizeof(int32_t)));
+        ICON_HIP(hipMalloc((void **)&w->d_block_offsets, (size_t)nblk * sizeof(int64_t)));
+        w->cap_blocks = nblk;
+    }
+    if (n_points > w->cap_signs) {
+        (void)hipFree(w->d_signs); w->d_signs = nullptr; w->cap_signs = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_signs, (size_t)n_points));
+        w->cap_signs = n_points;
+    }
+    if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
+    if (!w->d_seg) ICON_HIP(hipMalloc((void **)&w->d_seg, (kMaxWorld + 1) * sizeof(int64_t)));
+    return ICON_OK;
+}
+
+int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int *c0)
+{
+    ICON_ARG(feat != nullptr, "feature handle is null");
+    const FeatDev &f = feat->dev;
+    if (prior == ICON_PRIOR_ICON) {
+        ICON_ARG(mesh != nullptr, "icon prior needs a mesh handle");
+        ICON_ARG(f.n_select == 2, "icon prior needs feature planes created with n_select = 2");
+        *c0 = f.csel + 7;
+    } else if (prior == ICON_PRIOR_PAMIR) {
+        ICON_ARG(f.n_select == 1 && f.vol != nullptr, "pamir prior needs n_select = 1 and a volume");
+        *c0 = f.csel + f.Cv;
+    } else if (prior == ICON_PRIOR_PIFU) {
+        ICON_ARG(f.n_select == 1, "pifu prior needs n_select = 1");
+        *c0 = f.csel + 1;
+    } else {
+        return fail(ICON_ERR_ARG, "unknown prior_type");
+    }
+    if (*c0 > kCodeSlot) return fail(ICON_ERR_UNSUPPORTED, "more than 15 MLP input channels");
+    return ICON_OK;
+}
+
+// geometry pre-pass of the icon prior (BVH search): per-row crossing lists (lattice), nearest triangle -> near
+template <bool LATTICE>
+int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N,
+                   icon_work *work, hipStream_t st)
+{
+    if (LATTICE) {
+        const int64_t rows = (int64_t)L.nz * L.res;
+        if (rows > work->cap_rows) {
+            (void)hipFree(work->d_row_count); (void)hipFree(work->d_row_slots);
+            work->d_row_count = nullptr; work->d_row_slots = nullptr; work->cap_rows = 0;
+            ICON_HIP(hipMalloc((void **)&work->d_row_count, (size_t)rows * sizeof(int32_t)));
+            ICON_HIP(hipMalloc((void **)&work->d_row_slots, (size_t)rows * kRowCap * sizeof(int32_t)));
+            work->cap_rows = rows;
+        }
+        hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
+                           work->d_row_count, work->d_row_slots);
+    }
+    int64_t nb;
+    if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
+    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    int2 *near = reinterpret_cast<int2 *>(work->d_near);
+    // point mode: sparse batches walk the tree one wavefront per point; a batch dense enough for a wave's 64
+    // Morton neighbours to be close together goes through the packet kernel
+    const int32_t *perm = nullptr;
+    static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
+    if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
+        const int cap = coop_cap((int)mesh->stats[1]);
+        hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
+                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near, cap);
+    } else {
+        if (!LATTICE) {
+            const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm);
+    }
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+// X rows + codes (the materialising path): k_features, reading `near` unless the search is brute force
+template <bool LATTICE>
+int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sdf_clip, int cmap_mode,
+                    const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, int search,
+                    icon_work *work, hipStream_t st)
+{
+    int64_t nb;
+    if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
+    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    const dim3 grid((unsigned)nb), block(kBlock);
+    const MeshDev md = mesh ? mesh->dev : MeshDev{};
+    const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
+    const bool brute = (search == ICON_SEARCH_BRUTE);
+    const int2 *near = reinterpret_cast<const int2 *>(work->d_near);
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, near, work->d_x, work->d_code8)
+    if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
+    else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
+    else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
+#undef ICON_LAUNCH
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+// count + scan + compact over the codes of points [0, N): fills w->d_block_offsets, w->d_total, and `signs`
+int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
+{
+    const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
+    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_block_offsets, w->d_total);
+    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+int patch_self(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
 {
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(icon::k_outlier_patch_self, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_x, w->d_code8, N, cmap_slot,
@@ -661,7 +671,105 @@ int patch_only(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
+
+// The f16x3 precision (the default) with the BVH search runs FUSED: no input rows in HBM (fused_f16x3.hip).
+// ICON_AMD_UNFUSED=1 forces the materialising path (tests compare the two bit for bit).
+int g_unfused = -1;      // -1: read ICON_AMD_UNFUSED once; 0 / 1: set by icon_debug_set_unfused
+inline bool want_fused(int precision, int search)
+{
+    if (g_unfused < 0) g_unfused = (getenv("ICON_AMD_UNFUSED") && atoi(getenv("ICON_AMD_UNFUSED")) != 0) ? 1 : 0;
+    return !g_unfused && precision == ICON_PRECISION_F16X3 && search != ICON_SEARCH_BRUTE;
+}
+
+// Phase 1 of every query: what can be done before the outlier sign list of the whole call is known.
+//   icon prior, BVH: nearest search + k_sign (+ the call's own sign list in reference cmap mode); no rows yet
+//   icon prior, brute force: k_features (rows + codes) + sign list
+//   pamir / pifu: nothing
+// Records in `work` everything phase 2 needs (the handles must stay alive until then).
+template <bool LATTICE>
+int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sdf_clip, int cmap_mode, const Calib &cal,
+           const LatticeMap &L, const float *d_points, int64_t N, int search, int8_t *d_signs_out, icon_work *work, hipStream_t st)
+{
+    int rc;
+    work->q_mesh = mesh; work->q_feat = feat; work->q_prior = prior; work->q_sdf_clip = sdf_clip; work->q_cmap_mode = cmap_mode;
+    work->q_cal = cal; work->q_L = L; work->q_points = d_points; work->q_N = N; work->q_search = search; work->q_lattice = LATTICE;
+    work->q_rows_ready = false;
+    work->slab_needs_patch = (prior == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
+    work->slab_cmap_slot = feat->dev.csel + 1;
+    if (prior != ICON_PRIOR_ICON) return ICON_OK;
+    if (search == ICON_SEARCH_BRUTE) {
+        if ((rc = ensure_work(work, N, true))) return rc;
+        if ((rc = launch_features<LATTICE>(mesh, feat, prior, sdf_clip, cmap_mode, cal, L, d_points, N, search, work, st))) return rc;
+        work->q_rows_ready = true;
+    } else {
+        if ((rc = launch_nearest<LATTICE>(mesh, cal, L, d_points, N, work, st))) return rc;
+        if ((rc = launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st))) return rc;
+    }
+    if (work->slab_needs_patch) {
+        int8_t *signs = d_signs_out ? d_signs_out : work->d_signs;
+        if ((rc = outlier_list(work, N, signs, st))) return rc;
+    }
+    return ICON_OK;
+}
+
+// Phase 2: the MLP input of every point and the MLP itself, given where the call's outlier signs are.
+int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precision, icon_work *work, hipStream_t st)
+{
+    int rc;
+    const int prior = work->q_prior;
+    const int64_t N = work->q_N;
+    const bool fused = want_fused(precision, work->q_search);
+    const int local = (work->q_cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
+    if (fused) {
+        mark(work, 2, st);
+        rc = launch_fused_f16x3(work->q_mesh, work->q_feat, mlp, prior, work->q_cal, work->q_L.res, work->q_L.z0, work->q_points, N,
+                                work->q_sdf_clip, local, work, fs, d_occ, work->q_lattice, st);
+        mark(work, 3, st);
+        return rc;
+    }
+    if (!work->q_rows_ready) {
+        if ((rc = ensure_work(work, N, true))) return rc;
+        rc = work->q_lattice ? launch_features<true>(work->q_mesh, work->q_feat, prior, work->q_sdf_clip, work->q_cmap_mode, work->q_cal, work->q_L,
+                                                     work->q_points, N, work->q_search, work, st)
+                             : launch_features<false>(work->q_mesh, work->q_feat, prior, work->q_sdf_clip, work->q_cmap_mode, work->q_cal, work->q_L,
+                                                      work->q_points, N, work->q_search, work, st);
+        if (rc) return rc;
+    }
+    if (work->slab_needs_patch) {
+        const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+        if (fs.mode == kSignSelf) {
+            if ((rc = patch_self(work, N, work->slab_cmap_slot, st))) return rc;
+        } else if (fs.mode == kSignGlobal) {
+            if (fs.k_host > 0)
+                hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
+                                   work->d_block_offsets, fs.list, fs.k_host, fs.rank_offset);
+        } else if (fs.mode == kSignSeg) {
+            hipLaunchKernelGGL(k_outlier_patch_seg, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
+                               work->d_block_offsets, fs.gathered, fs.stride, fs.world, fs.rank);
+        }
+        ICON_HIP(hipGetLastError());
+    }
+    mark(work, 2, st);
+    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    mark(work, 3, st);
+    return rc;
+}
+
+FusedSigns self_signs(const icon_work *work)
+{
+    FusedSigns fs{};
+    fs.mode = work->slab_needs_patch ? kSignSelf : kSignNone;
+    fs.list = work->d_signs; fs.k_dev = work->d_total;
+    return fs;
+}
+
 }  // namespace
+
+extern "C" int icon_debug_set_unfused(int on)
+{
+    g_unfused = on ? 1 : 0;
+    return ICON_OK;
+}
 
 static int query_points_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
                              int prior_type, float sdf_clip, int cmap_mode, const float *h_calib, const float *d_calib,
@@ -676,22 +784,17 @@ static int query_points_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, c
     ICON_ARG(c0 == mlp->c0, "icon_query_points: MLP input width does not match the feature layout");
     if (N == 0) return ICON_OK;
     hipStream_t st = (hipStream_t)stream;
-    if ((rc = ensure_work(work, N))) return rc;
+    if ((rc = ensure_work(work, N, false))) return rc;
     Calib cal;
     static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
     memcpy(cal.m, h_calib ? h_calib : ident, sizeof(cal.m));
     cal.d = d_calib;
     LatticeMap L{};
+    work->slab_ready = false;
     mark(work, 0, st);
-    if ((rc = launch_features<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, work, st))) return rc;
-    const bool patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
-    if (patch && (rc = outlier_list(work, N, work->d_signs, st))) return rc;
+    if ((rc = phase1<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, nullptr, work, st))) return rc;
     mark(work, 1, st);
-    if (patch && (rc = patch_only(work, N, feat->dev.csel + 1, st))) return rc;
-    mark(work, 2, st);
-    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
-    mark(work, 3, st);
-    return rc;
+    return phase2(mlp, self_signs(work), d_occ, precision, work, st);
 }
 
 extern "C" int icon_query_points(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp,
@@ -737,21 +840,15 @@ extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_
     if ((rc = lattice_map(res, z0, z1, &L))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = (int64_t)L.nz * res * res;
-    if ((rc = ensure_work(work, N))) return rc;
+    if ((rc = ensure_work(work, N, false))) return rc;
     Calib cal{};
     work->slab_ready = false;
     mark(work, 0, st);
-    if ((rc = launch_features<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, work, st))) return rc;
-    work->slab_needs_patch = (prior_type == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
-    work->slab_cmap_slot = feat->dev.csel + 1;
+    if ((rc = phase1<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, d_signs_local, work, st))) return rc;
     work->slab_c0 = c0;
-    if (work->slab_needs_patch) {
-        int8_t *signs = d_signs_local ? d_signs_local : work->d_signs;
-        if ((rc = outlier_list(work, N, signs, st))) return rc;
-        if (d_count_local)
-            ICON_HIP(hipMemcpyAsync(d_count_local, work->d_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
-    } else if (d_count_local) {
-        ICON_HIP(hipMemsetAsync(d_count_local, 0, sizeof(int64_t), st));
+    if (d_count_local) {
+        if (work->slab_needs_patch) ICON_HIP(hipMemcpyAsync(d_count_local, work->d_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+        else ICON_HIP(hipMemsetAsync(d_count_local, 0, sizeof(int64_t), st));
     }
     mark(work, 1, st);
     work->slab_res = res; work->slab_z0 = z0; work->slab_z1 = z1; work->slab_ready = true;
@@ -766,20 +863,13 @@ extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int
     if (!work->slab_ready || work->slab_res != res || work->slab_z0 != z0 || work->slab_z1 != z1)
         return fail(ICON_ERR_STATE, "icon_grid_slab_finish: no matching icon_grid_slab_features call on this workspace");
     ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_slab_finish: MLP input width does not match the feature layout");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t N = (int64_t)(z1 - z0) * res * res;
-    if (work->slab_needs_patch && k_total > 0) {
-        ICON_ARG(d_signs_global != nullptr, "icon_grid_slab_finish: sign list is null");
-        const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(k_outlier_patch, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
-                           work->d_block_offsets, d_signs_global, k_total, rank_offset);
-        ICON_HIP(hipGetLastError());
+    FusedSigns fs{};
+    if (work->slab_needs_patch) {
+        ICON_ARG(k_total == 0 || d_signs_global != nullptr, "icon_grid_slab_finish: sign list is null");
+        fs.mode = kSignGlobal; fs.list = d_signs_global; fs.k_host = k_total; fs.rank_offset = rank_offset;
     }
-    mark(work, 2, st);
     work->slab_ready = false;
-    const int rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
-    mark(work, 3, st);
-    return rc;
+    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream);
 }
 
 extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1,
@@ -792,20 +882,13 @@ extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, in
     if (!work->slab_ready || work->slab_res != res || work->slab_z0 != z0 || work->slab_z1 != z1)
         return fail(ICON_ERR_STATE, "icon_grid_slab_finish_gathered: no matching icon_grid_slab_features call on this workspace");
     ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_slab_finish_gathered: MLP input width does not match the feature layout");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t N = (int64_t)(z1 - z0) * res * res;
+    FusedSigns fs{};
     if (work->slab_needs_patch) {
         ICON_ARG(d_gathered != nullptr, "icon_grid_slab_finish_gathered: gathered messages are null");
-        const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-        hipLaunchKernelGGL(k_outlier_patch_seg, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, work->d_x, work->d_code8, N, work->slab_cmap_slot,
-                           work->d_block_offsets, d_gathered, stride, world, rank);
-        ICON_HIP(hipGetLastError());
+        fs.mode = kSignSeg; fs.gathered = d_gathered; fs.stride = stride; fs.world = world; fs.rank = rank;
     }
-    mark(work, 2, st);
     work->slab_ready = false;
-    const int rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
-    mark(work, 3, st);
-    return rc;
+    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream);
 }
 
 extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3])
@@ -836,13 +919,7 @@ extern "C" int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *f
     int rc = icon_grid_slab_features(mesh, feat, prior_type, sdf_clip, cmap_mode, res, z0, z1, nullptr, nullptr, search, work, stream);
     if (rc) return rc;
     ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_eval_slab: MLP input width does not match the feature layout");
-    hipStream_t st = (hipStream_t)stream;
-    const int64_t N = (int64_t)(z1 - z0) * res * res;
     // the slab's own sign list is the whole list (single call == whole lattice or caller's choice)
-    if (work->slab_needs_patch && (rc = patch_only(work, N, work->slab_cmap_slot, st))) return rc;
-    mark(work, 2, st);
     work->slab_ready = false;
-    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
-    mark(work, 3, st);
-    return rc;
+    return phase2(mlp, self_signs(work), d_occ, precision, work, (hipStream_t)stream);
 }

@@ -356,6 +356,18 @@ class IconQueryEngine:
             self._mesh_key, self._mesh_src = k, ts      # strong refs: see _key
         return self._mesh
 
+    def mesh_z_range(self):
+        """(z_min, z_max) of the bound SMPL vertices in world coordinates (one D2H read per mesh, cached):
+        the cost model of the Z-slab cut (recon.plane_weights).  None for priors without a body mesh."""
+        if self.prior_type != "icon":
+            return None
+        self._mesh_handle()
+        if getattr(self, "_zr_key", None) != self._mesh_key:
+            z = self._mesh_src[0].detach().reshape(-1, 3)[:, 2].float()
+            self._zr = (float(z.min()), float(z.max()))
+            self._zr_key = self._mesh_key
+        return self._zr
+
     def _feat_handle(self, im_feat: torch.Tensor) -> FeatHandle:
         vol = self._pamir_volume() if self.prior_type == "pamir" else None
         k = _key(im_feat) + (_key(vol) if vol is not None else ())

@@ -28,11 +28,43 @@ from . import _lib
 from ._lib import IconAmdError, check
 
 
-def slab_bounds(res: int, world_size: int, rank: int):
-    """Planes [z0, z1) of rank ``rank``: equal slabs of ceil(res / world) planes, last ones short/empty."""
-    per = -(-res // world_size)
-    z0 = min(rank * per, res)
-    return z0, min(z0 + per, res), per
+def slab_partition(res: int, world_size: int, weights=None):
+    """Contiguous Z-slabs [(z0, z1)] * world_size of near-equal COST.  ``weights`` [res] is the relative cost of
+    every plane (default: uniform -> slab sizes differ by at most one plane: 257 / 8 = 33 + 7 x 32, instead of
+    the 7 x 33 + 26 of a ceil-division split whose short tail idles).  Deterministic in its inputs, so every
+    rank derives the same cut from the same (replicated) mesh."""
+    w = np.ones(res, np.float64) if weights is None else np.asarray(weights, np.float64).reshape(res)
+    if not (w > 0).all():
+        raise IconAmdError("slab_partition: plane weights must be positive")
+    cum = np.concatenate([[0.0], np.cumsum(w)])
+    total = cum[-1]
+    cuts = [0]
+    for r in range(1, world_size):
+        target = total * r / world_size
+        z = int(np.searchsorted(cum, target, side="left"))
+        if z > 0 and abs(cum[z - 1] - target) <= abs(cum[z] - target):   # nearest plane boundary to the ideal cut
+            z -= 1
+        cuts.append(min(max(z, cuts[-1]), res))
+    cuts.append(res)
+    return [(cuts[r], cuts[r + 1]) for r in range(world_size)]
+
+
+def slab_bounds(res: int, world_size: int, rank: int, weights=None):
+    """Planes [z0, z1) of rank ``rank`` and the largest slab size of the partition (the padded length every
+    rank contributes to the all_gather)."""
+    parts = slab_partition(res, world_size, weights)
+    z0, z1 = parts[rank]
+    return z0, z1, max(b - a for a, b in parts)
+
+
+def plane_weights(res: int, z_lo: float, z_hi: float, far_cost: float = 1.1) -> np.ndarray:
+    """Relative cost of the lattice planes for a body whose vertices span [z_lo, z_hi] in world z: planes farther
+    than the clip band from the body are pure far-field, where the exact nearest-triangle search visits more
+    candidates (measured on MI355X: the outer slabs of an 8-way split ran ~10 % longer than the middle ones;
+    the MLP cost per point is uniform)."""
+    z = -1.0 + 2.0 * np.arange(res) / (res - 1)
+    near = (z >= z_lo - 0.1) & (z <= z_hi + 0.1)
+    return np.where(near, 1.0, far_cost)
 
 
 def lattice_coords(res, b_min, b_max, align_corners: bool, device) -> torch.Tensor:
@@ -58,6 +90,7 @@ class DenseReconEngine(nn.Module):
     engine        an ``IconQueryEngine`` (otherwise one is attached to ``netG`` on first call)
     process_group torch.distributed group to shard over (default: WORLD if initialised)
     shard         False -> every rank evaluates the whole lattice (replicas, no collectives)
+    balance_slabs cost-weighted Z-slab cut (far-field planes count 1.1; see plane_weights); False -> equal plane counts
     backend       object providing eval_slab / slab_features / slab_finish (tests inject a CPU
                   checker here; the default is the HIP engine)
     """
@@ -65,7 +98,7 @@ class DenseReconEngine(nn.Module):
     def __init__(self, query_func=None, b_min=((-1.0, 1.0, -1.0),), b_max=((1.0, -1.0, 1.0),), resolutions=(257,),
                  channels=1, balance_value=0.5, align_corners=False, visualize=False, debug=False,
                  use_cuda_impl=False, faster=False, use_shadow=False, engine=None, process_group=None,
-                 shard=True, backend=None, **kwargs):
+                 shard=True, backend=None, balance_slabs=True, **kwargs):
         super().__init__()
         self.query_func = query_func
         self.register_buffer("b_min", torch.tensor(b_min).float().unsqueeze(1))   # [1,1,3]
@@ -89,6 +122,7 @@ class DenseReconEngine(nn.Module):
         self.backend = backend
         self.process_group = process_group
         self.shard = shard
+        self.balance_slabs = balance_slabs
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------
@@ -155,26 +189,44 @@ class DenseReconEngine(nn.Module):
         dist.all_gather_into_tensor(out, t.contiguous(), group=group)
         return out
 
+    def _plane_weights(self, be, res):
+        """cost model of the Z-slab cut (see plane_weights); None -> uniform"""
+        if not self.balance_slabs:
+            return None
+        zr = getattr(be, "mesh_z_range", None)
+        zr = zr() if callable(zr) else None
+        return None if zr is None else plane_weights(res, zr[0], zr[1])
+
+    def _shard_buffers(self, key, per, res, stride, dev):
+        """slab / message buffers of the sharded path, allocated once per (resolution, world, device)"""
+        if getattr(self, "_shard_key", None) != key:
+            self._shard_slab = torch.zeros((per, res, res), dtype=torch.float32, device=dev)
+            self._shard_msg = torch.zeros(stride, dtype=torch.int8, device=dev)
+            self._shard_key = key
+        return self._shard_slab, self._shard_msg
+
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
-        z0, z1, per = slab_bounds(res, world, rank)
+        parts = slab_partition(res, world, self._plane_weights(be, res))
+        z0, z1 = parts[rank]
+        per = max(b - a for a, b in parts)
         dev = im_feat.device
-        slab = torch.zeros((per, res, res), dtype=torch.float32, device=dev)
+        stride = 8 + (per * res * res + 7) // 8 * 8
+        slab, msg = self._shard_buffers((res, world, rank, str(dev), per), per, res, stride, dev)
         need_exchange = getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
         if need_exchange and hasattr(be, "slab_finish_gathered"):
             # ONE collective, no host synchronisation: every rank contributes a fixed-size message
             # [int64 count][int8 signs, padded to the largest slab]; phase 1 writes straight into it and
             # phase 2 consumes the gathered buffer as it is (K, rank offset and segment lookup happen
-            # in the patch kernel), so the exchange and the MLP launch are enqueued back to back.
-            stride = 8 + (per * res * res + 7) // 8 * 8
-            msg = torch.zeros(stride, dtype=torch.int8, device=dev)
+            # on the device), so the exchange and the MLP launch are enqueued back to back.
             n = (z1 - z0) * res * res
+            msg[:8].zero_()
             if z1 > z0:
                 be.slab_features(im_feat, res, z0, z1, signs=msg[8:8 + n], count=msg[:8].view(torch.int64))
             gathered = self._all_gather_cat(dist, msg, world, g)
             if z1 > z0:
                 be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0])
-            self.last_stats = dict(exchanged_bytes=stride * world, collectives=2)   # sign messages + the volume
+            self.last_stats = dict(exchanged_bytes=stride * world, collectives=2, slabs=parts)   # sign messages + the volume
         elif need_exchange:
             if z1 > z0:
                 signs, count = be.slab_features(im_feat, res, z0, z1)
@@ -193,10 +245,14 @@ class DenseReconEngine(nn.Module):
             if z1 > z0:
                 be.slab_finish(res, z0, z1, signs_global, sum(counts), sum(counts[:rank]),
                                out=slab[: z1 - z0], device=dev)
-            self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world)
+            self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world, slabs=parts)
         elif z1 > z0:
             be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
-        return self._all_gather_cat(dist, slab, world, g)[:res]
+        allv = self._all_gather_cat(dist, slab, world, g)
+        if all(b - a == per for a, b in parts):
+            return allv[:res]
+        allv = allv.view(world, per, res, res)                    # unequal slabs: drop each rank's padding planes
+        return torch.cat([allv[r, : b - a] for r, (a, b) in enumerate(parts)], 0)
 
     def _forward_generic(self, **kwargs):
         """Any b_min/b_max/align_corners/proj_matrix: materialise the lattice coordinates exactly as
@@ -234,6 +290,90 @@ class DenseReconEngine(nn.Module):
             return verts.cpu(), faces.cpu()          # the reference returns CPU tensors (:601-602)
         occ = occupancys.detach().to("cpu", torch.float32).contiguous()
         return export_mesh_numpy(occ.numpy(), float(self.balance_value))
+
+
+    # ------------------------------------------------------------------------------------------
+    # normal-map preview of a volume (lib/common/seg3d_lossless.py:498-581; used by apps/ICON.py:706)
+    def find_vertices(self, sdf, direction="front"):
+        """First voxel above 0.5 along the viewing direction for every (x, y) column, the sub-voxel depth
+        of the 0.5 crossing and a finite-difference normal (seg3d_lossless.py:498-558).
+        -> X [N], Y [N] (long), Z [N] (float), norm [N,3]"""
+        resolution = sdf.size(2)
+        if direction == "left":
+            sdf = sdf.permute(2, 1, 0)
+        elif direction == "back":
+            sdf = sdf.flip(0)
+        elif direction == "right":
+            sdf = sdf.flip(2).permute(2, 1, 0)
+        elif direction != "front":
+            raise IconAmdError(f"unknown direction {direction!r}")
+        vol = sdf.flip(0).permute(2, 1, 0)                        # [x, y, depth]
+        inside = vol > 0.5
+        hit = inside.any(dim=2)
+        first = inside.to(torch.uint8).argmax(dim=2)             # first voxel above the level (the reference's shadow mask keeps only it)
+        xy = hit.nonzero(as_tuple=False)
+        X, Y = xy[:, 0], xy[:, 1]
+        Zi = first[X, Y]
+        zc, yc, xc = (Zi - 2).clamp(0, resolution), (Y - 2).clamp(0, resolution), (X - 2).clamp(0, resolution)
+        v1, v2, v3, v4 = vol[X, Y, Zi], vol[X, Y, zc], vol[X, yc, Zi], vol[xc, Y, Zi]
+        Z = (zc.float() * (0.5 - v1) / (v2 - v1) + Zi.float() * (v2 - 0.5) / (v2 - v1)).clamp(0, resolution)
+        norm = torch.stack([v4 - v1, v3 - v1, v2 - v1], dim=1)
+        norm = norm / torch.norm(norm, p=2, dim=1, keepdim=True)
+        return X.long(), Y.long(), Z, norm
+
+    def render_normal(self, resolution, X, Y, Z, norm):
+        image = torch.ones((1, 3, resolution, resolution), dtype=torch.float32, device=norm.device)
+        image[0, :, Y, X] = ((norm + 1) / 2.0).clamp(0, 1).t()
+        return image
+
+    def display(self, sdf):
+        """[res, 4*res, 3] uint8: front | left | right | back normal renderings (seg3d_lossless.py:566-581)"""
+        res = int(self.resolutions[-1, -1])
+        views = [self.render_normal(res, *self.find_vertices(sdf, d)) for d in ("front", "left", "right", "back")]
+        image = torch.cat(views, dim=3)
+        return np.uint8(image.detach().cpu().numpy()[0].transpose(1, 2, 0) * 255.0)
+
+
+def mesh_components(faces: torch.Tensor, n_verts: int) -> torch.Tensor:
+    """[V] int32 component label of every vertex (the smallest vertex index of its component), computed on
+    the device by icon_mesh_components (union-find over the faces)."""
+    from .engine import _stream
+    if not faces.is_cuda:
+        raise IconAmdError("mesh_components needs device tensors (there is no CPU path)")
+    f = faces.detach().to(torch.int64).reshape(-1, 3).contiguous()
+    labels = torch.empty(int(n_verts), dtype=torch.int32, device=f.device)
+    check(_lib.lib().icon_mesh_components(_lib.ptr(f), C.c_int64(f.shape[0]), C.c_int64(int(n_verts)), _lib.ptr(labels), _stream()),
+          "icon_mesh_components")
+    return labels
+
+
+def clean_mesh(verts: torch.Tensor, faces: torch.Tensor):
+    """Drop-in for ``lib.dataset.mesh_util.clean_mesh`` (mesh_util.py:778-791): keep the connected component
+    with the most vertices (ties: the one containing the lowest-index face, the order trimesh's split
+    enumerates them in); vertices and faces keep their relative order, as trimesh's submesh does.
+    Returns (verts float32, faces int32) on the device of ``verts`` - the reference returns
+    ``.float()`` / ``.int()`` tensors on ``verts.device``.  Inputs on the host (export_mesh returns CPU
+    tensors, seg3d_lossless.py:601-602) are moved to the current HIP device for the labelling."""
+    if not torch.cuda.is_available():
+        raise IconAmdError("clean_mesh needs the HIP device (there is no CPU fallback)")
+    out_dev = verts.device
+    dev = verts.device if verts.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    v = verts.detach().to(dev)
+    f = faces.detach().to(dev, torch.int64).reshape(-1, 3)
+    if f.shape[0] == 0 or v.shape[0] == 0:
+        return v.float().to(out_dev), f.int().to(out_dev)
+    labels = mesh_components(f, v.shape[0]).long()
+    used = torch.zeros(v.shape[0], dtype=torch.bool, device=dev)
+    used[f.reshape(-1)] = True                                   # trimesh drops unreferenced vertices
+    counts = torch.bincount(labels[used], minlength=v.shape[0])
+    best_count = counts.max()
+    face_label = labels[f[:, 0]]
+    tied = counts[face_label] == best_count                      # faces of the largest component(s)
+    best = face_label[tied.nonzero()[0, 0]]                      # ... the one met first in face order
+    keep_v = (labels == best) & used
+    keep_f = face_label == best
+    remap = torch.cumsum(keep_v.to(torch.int64), 0) - 1
+    return v[keep_v].float().to(out_dev), remap[f[keep_f]].int().to(out_dev)
 
 
 _mc_work = None

@@ -139,8 +139,9 @@ int icon_work_destroy(icon_work_t *work);
 /* Stage timing with HIP events recorded on the caller's stream (bench.py's live roofline leg).
  * After enabling, every icon_query_points / icon_grid_* call brackets its stages with events;
  * icon_work_stage_ms synchronises on the last one and returns milliseconds of the most recent
- * call: out_ms[0] = features (SDF + gather + outlier count/scan/compact),
- *       out_ms[1] = outlier cmap patch, out_ms[2] = MLP kernel alone. */
+ * call: out_ms[0] = geometry pre-pass (nearest search, sign / outlier codes, count/scan/compact),
+ *       out_ms[1] = row materialisation + outlier cmap patch (0 on the fused path),
+ *       out_ms[2] = the MLP kernel alone (fused path: k_fused_f16x3, which also assembles the rows). */
 int icon_work_profile(icon_work_t *work, int enable);
 int icon_work_stage_ms(icon_work_t *work, float out_ms[3]);
 
@@ -210,6 +211,12 @@ int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z
                                    const int8_t *d_gathered, int64_t stride, int world, int rank,
                                    float *d_occ, int precision, icon_work_t *work, void *stream);
 
+/* Diagnostics: with precision F16X3 and the BVH search the query runs FUSED - the MLP input rows are
+ * assembled in LDS by the MLP kernel itself and never reach HBM (icon_amd/csrc/fused_f16x3.hip).  on != 0
+ * forces the materialising path (rows written by a feature kernel, patched, read back by the MLP kernel) that
+ * the other precisions use; both give bit-identical results (tests/test_gpu_parity.py).  Process-wide. */
+int icon_debug_set_unfused(int on);
+
 /* Diagnostics (synchronises): BVH work of the lattice traversal over planes [z0,z1):
  * out[0] = wavefronts (4x4x4 point blocks), out[1] = BVH nodes visited, out[2] = triangles tested,
  * both summed over wavefronts (every visit serves all 64 lanes of the wavefront). */
@@ -233,6 +240,13 @@ int icon_export_mesh(const float *h_occ, int res, float level,
 int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, void *stream,
                   int64_t *n_verts, int64_t *n_faces);
 int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream);
+
+/* ---- connected components of a triangle mesh --------------------------------------------------------
+ * the engine of clean_mesh (lib/dataset/mesh_util.py:778-791: trimesh split, keep the component with the
+ * most vertices; called on the marching-cubes output at apps/ICON.py:755-756).
+ * d_faces [F,3] int64, d_labels [V] int32 out: the smallest vertex index of the vertex's component.
+ * Synchronises the stream (reports out-of-range face indices). */
+int icon_mesh_components(const int64_t *d_faces, int64_t F, int64_t V, int32_t *d_labels, void *stream);
 
 /* ---- SMPL vertex visibility ----------------------------------------------------------------------
  * replaces get_visibility (lib/dataset/mesh_util.py:280-316: pytorch3d rasterisation at 2^12 squared,

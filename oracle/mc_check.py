@@ -1,0 +1,138 @@
+"""Independent checker of the marching-cubes output - TEST INFRASTRUCTURE ONLY.
+
+The reference extracts the mesh with third-party code that is absent here (kaolin
+``voxelgrids_to_trianglemeshes`` for grids <= 256^3, PyMCubes above: lib/common/seg3d_lossless.py:583-604),
+so there is no reference output to compare triangle lists with: PARITY UNPINNED for the triangulation.
+What every correct marching cubes shares, whatever its case table, is checked here in plain numpy, written
+without looking at the product's tables:
+
+* the VERTEX SET: one vertex on every lattice edge whose end points lie on different sides of the level
+  (``a > level`` xor ``b > level``), at the linear interpolation ``i + (level - a) / (b - a)``;
+* every triangle joins three crossings of ONE cube;
+* the surface is a closed, consistently oriented 2-manifold (every directed edge has exactly one
+  opposite partner) wherever it does not touch the border of the grid, with the inside (occ > level)
+  on the side the reference's conventions put it (positive signed volume after export_mesh's
+  ``faces[:, [0, 2, 1]]`` flip means outward normals);
+* Euler characteristic 2 per closed genus-0 component (reported, asserted by the caller where the
+  topology is known).
+
+export_mesh conventions (seg3d_lossless.py:585-602): marching cubes on ``occ[1:, 1:, 1:]``, vertices as
+(x, y, z) in voxel units of the cropped grid.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def edge_crossings(occ: np.ndarray, level: float = 0.5) -> np.ndarray:
+    """[N,3] float64 (x, y, z) positions of all level crossings on the lattice edges of ``occ[1:,1:,1:]``
+    (z slowest in the array, as the reference's volume)."""
+    v = np.asarray(occ, np.float32)[1:, 1:, 1:]
+    ins = v > np.float32(level)
+    out = []
+    for axis in (0, 1, 2):                         # array axes: 0 = z, 1 = y, 2 = x
+        a = np.moveaxis(v, axis, 0)
+        ia = np.moveaxis(ins, axis, 0)
+        cross = ia[:-1] != ia[1:]
+        idx = np.argwhere(cross)                   # (k along axis, other two in array order)
+        va = a[:-1][cross].astype(np.float64)
+        vb = a[1:][cross].astype(np.float64)
+        t = (np.float64(level) - va) / (vb - va)
+        coords = idx.astype(np.float64)
+        coords[:, 0] += t
+        # back to array order (z, y, x)
+        order = [0, 1, 2]
+        order.remove(axis)
+        zyx = np.empty_like(coords)
+        zyx[:, axis] = coords[:, 0]
+        zyx[:, order[0]] = coords[:, 1]
+        zyx[:, order[1]] = coords[:, 2]
+        out.append(zyx[:, ::-1])                   # -> (x, y, z)
+    return np.concatenate(out, 0)
+
+
+def same_point_set(a: np.ndarray, b: np.ndarray, tol: float = 1e-4) -> bool:
+    """both [N,3]; equal as sets up to ``tol`` (one-to-one nearest-neighbour matching both ways)"""
+    from scipy.spatial import cKDTree
+    if len(a) != len(b):
+        return False
+    if len(a) == 0:
+        return True
+    da, ia = cKDTree(b).query(a)
+    db, _ = cKDTree(a).query(b)
+    return bool(da.max() <= tol and db.max() <= tol and len(np.unique(ia)) == len(a))
+
+
+def topology(verts: np.ndarray, faces: np.ndarray, grid: int) -> dict:
+    """``grid`` = points per axis of the cropped volume (vertices lie in [0, grid-1])."""
+    v = np.asarray(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    res = {"n_verts": len(v), "n_faces": len(f)}
+    if len(f) == 0:
+        res.update(closed=True, oriented=True, euler=0, components=0, signed_volume=0.0, one_cube=True, used_all=len(v) == 0)
+        return res
+    # every triangle inside one cube
+    lo = np.floor(v[f].min(1) + 1e-9)
+    hi = v[f].max(1)
+    res["one_cube"] = bool((hi <= lo + 1.0 + 1e-6).all())
+    res["used_all"] = bool(len(np.unique(f)) == len(v))
+    # directed edges
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    key = e[:, 0] * (len(v) + 1) + e[:, 1]
+    rkey = e[:, 1] * (len(v) + 1) + e[:, 0]
+    uk, cnt = np.unique(key, return_counts=True)
+    res["oriented"] = bool((cnt == 1).all())                      # no directed edge twice
+    has_partner = np.isin(key, rkey)
+    on_border = lambda p: ((p <= 1e-9) | (p >= grid - 1 - 1e-9)).any(-1)
+    open_edges = e[~has_partner]
+    # an unmatched edge is legitimate only on the border of the grid
+    res["closed"] = bool(len(open_edges) == 0 or (on_border(v[open_edges[:, 0]]) & on_border(v[open_edges[:, 1]])).all())
+    res["watertight"] = bool(len(open_edges) == 0)
+    und = np.unique(np.sort(e, 1), axis=0)
+    res["euler"] = int(len(v) - len(und) + len(f))
+    # components (union-find over vertices)
+    parent = np.arange(len(v))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b in und:
+        ra, rb = find(a), find(b)
+        if ra != rb:
+            parent[max(ra, rb)] = min(ra, rb)
+    roots = np.array([find(i) for i in np.unique(f)])
+    res["components"] = int(len(np.unique(roots)))
+    t = v[f]
+    res["signed_volume"] = float(np.einsum("ij,ij->i", t[:, 0], np.cross(t[:, 1], t[:, 2])).sum() / 6.0)
+    return res
+
+
+def largest_component(verts: np.ndarray, faces: np.ndarray):
+    """numpy restatement of lib/dataset/mesh_util.py:778-791 (trimesh split -> most vertices): the component
+    with the most referenced vertices (ties: the one containing the lowest-index face); vertices and faces
+    keep their relative order.  -> (verts, faces int32)"""
+    v = np.asarray(verts)
+    f = np.asarray(faces, np.int64)
+    parent = np.arange(len(v))
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+    for a, b, c in f:
+        for p, q in ((a, b), (a, c)):
+            rp, rq = find(p), find(q)
+            if rp != rq:
+                parent[max(rp, rq)] = min(rp, rq)
+    lab = np.array([find(i) for i in range(len(v))])
+    used = np.zeros(len(v), bool)
+    used[f.reshape(-1)] = True
+    counts = np.bincount(lab[used], minlength=len(v))
+    fl = lab[f[:, 0]]
+    best = fl[np.nonzero(counts[fl] == counts.max())[0][0]]
+    keep_v = (lab == best) & used
+    remap = np.cumsum(keep_v) - 1
+    return v[keep_v].astype(np.float32), remap[f[fl == best]].astype(np.int32)

@@ -73,8 +73,26 @@ def test_slab_bounds(res, world):
         assert 0 <= z0 <= z1 <= res and z1 - z0 <= per
         cover += list(range(z0, z1))
     assert cover == list(range(res))
+    sizes = [slab_bounds(res, world, r)[1] - slab_bounds(res, world, r)[0] for r in range(world)]
+    assert max(sizes) - min(sizes) <= 1                     # uniform cost: no short tail slab (257 / 8 = 33 + 7 x 32)
     if (res, world) == (257, 8):
-        assert [slab_bounds(res, world, r)[1] - slab_bounds(res, world, r)[0] for r in range(8)] == [33] * 7 + [26]
+        assert sorted(sizes) == [32] * 7 + [33]
+
+
+def test_cost_weighted_slab_partition():
+    """far-field planes cost more per point (nearest-triangle search) than the planes through the body: the
+    weighted cut gives the outer ranks fewer planes, every rank about the same cost"""
+    from icon_amd.recon import plane_weights, slab_partition
+    res, world = 257, 8
+    w = plane_weights(res, -0.25, 0.25)
+    parts = slab_partition(res, world, w)
+    assert parts[0][0] == 0 and parts[-1][1] == res and all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+    cost = [w[a:b].sum() for a, b in parts]
+    assert max(cost) / min(cost) < 1.08
+    sizes = [b - a for a, b in parts]
+    assert sizes[0] <= sizes[world // 2] and sizes[-1] <= sizes[world // 2]
+    assert slab_partition(9, 16) == slab_partition(9, 16)   # deterministic; more ranks than planes -> empty slabs allowed
+    assert sum(b - a for a, b in slab_partition(9, 16)) == 9
 
 
 def test_lattice_mapping_matches_reference_formula():

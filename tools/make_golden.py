@@ -113,5 +113,23 @@ def main():
     os.system(f"ls -la {OUT}")
 
 
+def section_g_display():
+    """(g) Seg3dLossless.display (lib/common/seg3d_lossless.py:566-581) of a synthetic 33^3 volume, reference run verbatim"""
+    import torch
+    from oracle import ref_loader
+    ref = ref_loader.load()
+    res = 33
+    rng = np.random.RandomState(0)
+    z, y, x = np.meshgrid(*[np.linspace(-1, 1, res)] * 3, indexing="ij")
+    vol = (0.5 + 0.8 * (0.6 - np.sqrt((x * 0.9) ** 2 + (y * 0.6) ** 2 + (z * 1.3) ** 2)) + 0.02 * rng.normal(size=(res, res, res))).astype(np.float32)
+    r = ref.Seg3dLossless(query_func=None, b_min=[[-1, 1, -1]], b_max=[[1, -1, 1]], resolutions=[17, res], align_corners=True,
+                          balance_value=0.5, device="cpu", visualize=False, debug=False, use_cuda_impl=False, faster=True)
+    np.savez_compressed(os.path.join(OUT, "display_33.npz"), vol=vol, image=r.display(torch.from_numpy(vol)))
+
+
 if __name__ == "__main__":
-    main()
+    if "--display" in sys.argv:      # only (g)
+        section_g_display()
+    else:
+        main()
+        section_g_display()
