@@ -31,7 +31,7 @@ SYMBOLS = [
     "icon_query_points", "icon_query_points_dcalib",
     "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish", "icon_grid_slab_finish_gathered",
     "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_debug_traversal_stats", "icon_debug_set_unfused",
-    "icon_visibility", "icon_mesh_components",
+    "icon_visibility", "icon_mesh_components", "icon_semantic_voxelize",
 ]
 
 _lib = None

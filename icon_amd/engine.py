@@ -377,18 +377,25 @@ class IconQueryEngine:
         return self._feat
 
     def _pamir_volume(self) -> torch.Tensor:
+        """VolumeEncoder output [1,Cv,D,H,W] of the current image (lib/net/HGPIFuNet.py:314-325).  The
+        reference voxelises and encodes on EVERY query() call; both only depend on the image, so they run once
+        per set of voxel tensors: the semantic volume on the HIP voxeliser (semantic_voxelization - no
+        voxelize_cuda wheel needed), the 3-D convolutions of ``netG.ve`` on PyTorch-ROCm."""
         if self._vol is not None:
             return self._vol
         netG = self.netG
-        if netG is None or not hasattr(netG, "voxelization"):
+        if netG is None or not hasattr(netG, "voxelization") or not hasattr(netG, "ve"):
             raise IconAmdError("pamir prior: call set_volume_features(vol_feat) (VolumeEncoder output)")
         d = netG.smpl_feat_dict
         k = _key(d["voxel_verts"], d["voxel_faces"])
-        if k != self._vol_key:   # reference recomputes this on every query(); it only depends on the image
-            vv = d["voxel_verts"][:, :-d["pad_v_num"][0], :]
-            vf = d["voxel_faces"][:, :-d["pad_f_num"][0], :]
-            netG.voxelization.update_param(batch_size=vf.shape[0], smpl_tetra=vf[0].detach().cpu().numpy())
-            self._vol_cached = netG.ve(netG.voxelization(vv), intermediate_output=False)[-1]
+        if k != self._vol_key:
+            vv = d["voxel_verts"][:, :-int(d["pad_v_num"][0]), :]
+            vf = d["voxel_faces"][:, :-int(d["pad_f_num"][0]), :]
+            vox = netG.voxelization
+            vol = semantic_voxelization(vv, vf, vox.smpl_vertex_code, res=int(getattr(vox, "volume_res", 128)),
+                                        sigma=float(getattr(vox, "sigma", 0.05)))
+            with torch.no_grad():
+                self._vol_cached = netG.ve(vol, intermediate_output=False)[-1]
             self._vol_key, self._vol_src = k, (d["voxel_verts"], d["voxel_faces"])
         return self._vol_cached
 
@@ -530,6 +537,30 @@ def query_func(opt, netG, features, points, proj_matrix=None):
     if type(preds) is list:
         preds = preds[0]
     return preds
+
+
+def semantic_voxelization(voxel_verts: torch.Tensor, voxel_tets: torch.Tensor, vertex_code, res: int = 128,
+                          sigma: float = 0.05) -> torch.Tensor:
+    """Drop-in for ``Voxelization.forward`` (lib/net/voxelize.py:119-137 -> voxelize_cuda, an external CUDA
+    wheel): ``voxel_verts [1,V,3]`` (tetrahedralised SMPL in the [-0.5,0.5] cube, surface vertices first;
+    lib/dataset/TestDataset.py:150-192 with the padding stripped as lib/net/HGPIFuNet.py:316-319 does),
+    ``voxel_tets [1,T,4]`` vertex indices, ``vertex_code [Vs,3]`` the semantic code of the surface vertices
+    (``Voxelization.smpl_vertex_code``) -> ``[1,3,res,res,res]`` (b,c,d,h,w), what ``vol.permute(0,4,1,2,3)`` returns.
+    PARITY UNPINNED: see include/icon_amd.h (icon_semantic_voxelize)."""
+    if not voxel_verts.is_cuda:
+        raise IconAmdError("semantic_voxelization needs device tensors (there is no CPU path)")
+    dev = voxel_verts.device
+    v = voxel_verts.detach().to(torch.float32).reshape(-1, 3).contiguous()
+    t = voxel_tets.detach().to(dev, torch.int64).reshape(-1, 4).contiguous()
+    code = torch.as_tensor(np.asarray(vertex_code, dtype=np.float32) if not isinstance(vertex_code, torch.Tensor) else vertex_code)
+    code = code.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    if code.shape[0] > v.shape[0]:
+        raise IconAmdError("semantic_voxelization: more vertex codes than vertices")
+    out = torch.empty((res, res, res, 3), dtype=torch.float32, device=dev)
+    check(_lib.lib().icon_semantic_voxelize(ptr(v), C.c_int64(v.shape[0]), C.c_int64(code.shape[0]), ptr(code), ptr(t),
+                                            C.c_int64(t.shape[0]), C.c_int(res), C.c_float(sigma), ptr(out), _stream()),
+          "icon_semantic_voxelize")
+    return out.permute(3, 0, 1, 2).unsqueeze(0)
 
 
 def get_visibility(xy: torch.Tensor, z: torch.Tensor, faces: torch.Tensor, image_size: int = 2 ** 12) -> torch.Tensor:

@@ -370,6 +370,23 @@ def make_assets(mesh: str = "body", seed: int = SEED, prior_type: str = "icon") 
     return a
 
 
+def make_tetra_body(verts: np.ndarray, faces: np.ndarray, cmap: np.ndarray):
+    """Stand-in for the tetrahedralised SMPL of the PaMIR prior (lib/dataset/TestDataset.py:150-192,
+    lib/dataset/body_model.py:233-395 - the real tetrahedra need credential-gated data): the surface vertices
+    followed by ONE interior vertex, every surface triangle joined to it (the synthetic body is star-shaped
+    around its centre), scaled by 0.5 with z flipped exactly as compute_voxel_verts does (:172-179).
+    -> voxel_verts [V+1,3] f32, voxel_tets [F,4] i64, vertex_code [V,3] f32 (the semantic code of the surface
+    vertices, here the cmap)."""
+    v = verts.reshape(-1, 3).astype(np.float64)
+    centre = 0.5 * (v.min(0) + v.max(0))
+    centre[1] = np.median(v[:, 1]) + 0.05
+    vv = np.concatenate([v, centre[None]], 0) * 0.5
+    vv[:, 2] *= -1.0
+    f = faces.reshape(-1, 3).astype(np.int64)
+    tets = np.concatenate([f, np.full((len(f), 1), len(v), np.int64)], 1)
+    return vv.astype(np.float32), tets, cmap.reshape(-1, 3).astype(np.float32)
+
+
 def stratified_points(verts: np.ndarray, faces: np.ndarray, n: int, seed: int = SEED) -> np.ndarray:
     """Query points [n,3] f32 mixing the regimes of SURVEY.md §7(1d): near-surface (face,
     edge and vertex Voronoi regions), inside/outside the clip band, far field and the cube

@@ -241,6 +241,18 @@ int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, v
                   int64_t *n_verts, int64_t *n_faces);
 int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream);
 
+/* ---- PaMIR semantic voxelisation ---------------------------------------------------------------------
+ * replaces voxelize_cuda.forward_semantic_voxelization (external CUDA wheel, requirements.txt:34; call site
+ * lib/net/voxelize.py:57-59, arguments of Voxelization.forward :119-137; volume_res 128, sigma 0.05 at
+ * lib/net/HGPIFuNet.py:109-118).  PARITY UNPINNED (source and test vectors absent): semantics as defined in
+ * oracle/icon_accel.c - voxel centre p = ((x,y,z)+0.5)/res - 0.5, inside = p in some tetrahedron,
+ * out = inside * sum_v w_v code_v / (1e-3 + sum_v w_v), w_v = exp(-|p-v|^2 / (2 sigma^2)) over the surface vertices.
+ * d_verts [V,3] f32 (the first V_surf are the SMPL surface vertices, the rest the added interior ones,
+ * lib/dataset/TestDataset.py:160-163), d_code [V_surf,3] f32, d_tets [T,4] int64 vertex indices,
+ * d_out [res,res,res,3] f32 in (z,y,x,c) order - the layout lib/net/voxelize.py:22 documents.  Synchronises. */
+int icon_semantic_voxelize(const float *d_verts, int64_t V, int64_t V_surf, const float *d_code,
+                           const int64_t *d_tets, int64_t T, int res, float sigma, float *d_out, void *stream);
+
 /* ---- connected components of a triangle mesh --------------------------------------------------------
  * the engine of clean_mesh (lib/dataset/mesh_util.py:778-791: trimesh split, keep the component with the
  * most vertices; called on the marching-cubes output at apps/ICON.py:755-756).

@@ -249,3 +249,86 @@ void orc_accel_check_sign(const orc_accel *A, const float *pts, int64_t N, uint8
         inside[i] = (uint8_t)(cnt & 1);
     }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * PaMIR semantic voxelisation - restatement of voxelize_cuda.forward_semantic_voxelization
+ * (YuliangXiu/neural_voxelization_layer, unpinned in requirements.txt:34; NOT under /root/reference),
+ * call site lib/net/voxelize.py:57-59, arguments built by Voxelization.forward (:119-137), parameters
+ * volume_res = 128, sigma = 0.05 (lib/net/HGPIFuNet.py:109-118).
+ *
+ * PARITY UNPINNED: the CUDA source is absent and the reference holds no test vector for it.  The
+ * semantics are therefore DEFINED here, from the call site's contract and the published description of the
+ * layer (PaMIR, "semantic volume": tetrahedralised SMPL -> occupancy; every inside voxel gets the
+ * Gaussian-weighted average of the semantic codes of the SURFACE vertices, weight_sum starts at 1e-3 as
+ * lib/net/voxelize.py:49-51 allocates it; outside voxels stay 0 as :44-48 initialises them):
+ *   voxel (z,y,x) has centre p = ((x,y,z) + 0.5) / R - 0.5        (the volume spans [-0.5, 0.5]^3: the caller
+ *                                                                 scales the body by 0.5, TestDataset.py:172-179)
+ *   occ  = 1 iff p lies in (or on the boundary of) at least one tetrahedron
+ *   sem  = occ * sum_v w_v code_v / (1e-3 + sum_v w_v),  w_v = exp(-|p - v|^2 / (2 sigma^2)),  v over the surface vertices
+ * Output layout [z][y][x][3] (the reference's "(batch_size, z_dims, y_dims, x_dims, channel_num)").
+ *
+ * Inside test (float32, no contraction; the HIP kernel evaluates the same expressions): for the faces
+ * (b,c,d), (a,d,c), (a,b,d), (a,c,b) of the tetrahedron, s_k = dot(cross(e1, e2), p - origin); p is inside iff
+ * all four s_k have the sign of the tetrahedron's own orientation or are zero (degenerate: volume 0 -> never).
+ * ------------------------------------------------------------------------------------------- */
+static inline float det3(const float *o, const float *u, const float *v, const float *p)
+{
+    const float ux = u[0] - o[0], uy = u[1] - o[1], uz = u[2] - o[2];
+    const float vx = v[0] - o[0], vy = v[1] - o[1], vz = v[2] - o[2];
+    const float px = p[0] - o[0], py = p[1] - o[1], pz = p[2] - o[2];
+    const float cx = fmaf(uy, vz, -(uz * vy)), cy = fmaf(uz, vx, -(ux * vz)), cz = fmaf(ux, vy, -(uy * vx));
+    return fmaf(cz, pz, fmaf(cy, py, cx * px));
+}
+
+void orc_semantic_voxelize(const float *verts, int64_t V, int64_t V_surf, const float *code,
+                           const int64_t *tets, int64_t T, int res, float sigma, float *out /* [res][res][res][3] */,
+                           uint8_t *occ_out /* optional [res][res][res] */)
+{
+    const int64_t n = (int64_t)res * res * res;
+    uint8_t *occ = (uint8_t *)calloc((size_t)n, 1);
+    const float inv = 1.0f / (float)res;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t ia = tets[4 * t], ib = tets[4 * t + 1], ic = tets[4 * t + 2], id = tets[4 * t + 3];
+        if (ia < 0 || ib < 0 || ic < 0 || id < 0 || ia >= V || ib >= V || ic >= V || id >= V) continue;
+        const float *a = verts + 3 * ia, *b = verts + 3 * ib, *c = verts + 3 * ic, *d = verts + 3 * id;
+        const float vol = det3(a, b, c, d);
+        if (vol == 0.0f) continue;
+        int lo[3], hi[3];
+        for (int k = 0; k < 3; ++k) {
+            const float mn = minf(minf(a[k], b[k]), minf(c[k], d[k])), mx = maxf(maxf(a[k], b[k]), maxf(c[k], d[k]));
+            lo[k] = (int)floorf((mn + 0.5f) * (float)res - 0.5f);
+            hi[k] = (int)ceilf((mx + 0.5f) * (float)res - 0.5f);
+            if (lo[k] < 0) lo[k] = 0;
+            if (hi[k] > res - 1) hi[k] = res - 1;
+        }
+        for (int z = lo[2]; z <= hi[2]; ++z)
+            for (int y = lo[1]; y <= hi[1]; ++y)
+                for (int x = lo[0]; x <= hi[0]; ++x) {
+                    const float p[3] = { ((float)x + 0.5f) * inv - 0.5f, ((float)y + 0.5f) * inv - 0.5f, ((float)z + 0.5f) * inv - 0.5f };
+                    const float s0 = det3(b, c, d, p), s1 = det3(a, d, c, p), s2 = det3(a, b, d, p), s3 = det3(a, c, b, p);
+                    /* orientation of (b,c,d | a) is -vol: inside <=> every s_k has the sign of -vol (or is zero) */
+                    const int in = (vol > 0.0f) ? (s0 <= 0.0f && s1 <= 0.0f && s2 <= 0.0f && s3 <= 0.0f)
+                                                : (s0 >= 0.0f && s1 >= 0.0f && s2 >= 0.0f && s3 >= 0.0f);
+                    if (in) occ[((int64_t)z * res + y) * res + x] = 1;
+                }
+    }
+    const float k2 = 1.0f / (2.0f * sigma * sigma);
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t i = 0; i < n; ++i) {
+        float *o = out + 3 * i;
+        o[0] = o[1] = o[2] = 0.0f;
+        if (!occ[i]) continue;
+        const int x = (int)(i % res), y = (int)((i / res) % res), z = (int)(i / ((int64_t)res * res));
+        const float px = ((float)x + 0.5f) * inv - 0.5f, py = ((float)y + 0.5f) * inv - 0.5f, pz = ((float)z + 0.5f) * inv - 0.5f;
+        double ws = 1e-3, s0 = 0.0, s1 = 0.0, s2 = 0.0;          /* float64 accumulation: the checker's reference value */
+        for (int64_t v = 0; v < V_surf; ++v) {
+            const float dx = px - verts[3 * v], dy = py - verts[3 * v + 1], dz = pz - verts[3 * v + 2];
+            const float d2 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            const double wgt = exp(-(double)d2 * (double)k2);
+            ws += wgt; s0 += wgt * code[3 * v]; s1 += wgt * code[3 * v + 1]; s2 += wgt * code[3 * v + 2];
+        }
+        o[0] = (float)(s0 / ws); o[1] = (float)(s1 / ws); o[2] = (float)(s2 / ws);
+    }
+    if (occ_out) memcpy(occ_out, occ, (size_t)n);
+    free(occ);
+}

@@ -237,6 +237,18 @@ def query_icon_subset(verts, faces, cmap, vis, feat, mlp: Mlp, pts, subset, sdf_
     return occ, X
 
 
+def semantic_voxelize(verts, n_surface, code, tets, res=128, sigma=0.05, return_occ=False):
+    """PaMIR semantic volume (restated voxelize_cuda.forward_semantic_voxelization, PARITY UNPINNED - see
+    icon_accel.c): verts [V,3] (surface vertices first), code [n_surface,3], tets [T,4] -> [res,res,res,3] (z,y,x,c)"""
+    verts, code, tets = _f32(verts).reshape(-1, 3), _f32(code).reshape(-1, 3), _i64(tets).reshape(-1, 4)
+    assert len(code) == n_surface <= len(verts)
+    out = np.empty((res, res, res, 3), np.float32)
+    occ = np.empty((res, res, res), np.uint8)
+    lib().orc_semantic_voxelize(_p(verts), C.c_int64(len(verts)), C.c_int64(n_surface), _p(code), _p(tets),
+                                C.c_int64(len(tets)), C.c_int(res), C.c_float(np.float32(sigma)), _p(out), _p(occ))
+    return (out, occ.astype(bool)) if return_occ else out
+
+
 def query_vol(feat, vol, mlp: Mlp, pts, calib=None, f64=False):
     """PaMIR (vol [Cv,D,H,W]) or PIFu (vol None) branch -> (occ [N], X [N, c0])"""
     feat = _f32(feat)
