@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libicon_amd.so")
+LIB_PATH = os.environ.get("ICON_AMD_LIB") or os.path.join(_HERE, "libicon_amd.so")   # ICON_AMD_LIB: experiment builds (tools/exp_fused.sh)
 CSRC = os.path.join(_HERE, "csrc")
 
 # include/icon_amd.h enums

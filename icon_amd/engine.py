@@ -435,14 +435,13 @@ class IconQueryEngine:
             raise IconAmdError("points are on the CPU; icon_amd has no CPU path")
         n = int(points.shape[2])
         if transforms is not None:
-            # orthogonal() with an image transform (lib/net/geometry.py:57-60): do it in torch, then
-            # hand already-projected points to the kernel with an identity calibration
-            rot, trans = calibs[:, :3, :3], calibs[:, :3, 3:4]
-            pts = torch.baddbmm(trans, rot, points)
-            pts[:, :2, :] = torch.baddbmm(transforms[:2, 2:3], transforms[:2, :2], pts[:, :2, :])
-            calib12 = None
-            pts = pts[0].t().contiguous()
-        elif calibs.is_cuda:
+            # lib/net/geometry.py:57-60 indexes `transforms[:2, :2]` / `transforms[:2, 2:3]` and feeds the slices to
+            # torch.baddbmm: for the documented [B,2,3] layout the shift slice is empty and for a [2,3] matrix the
+            # operands are 2-D - the reference raises for every shape, and no caller in the tree passes the
+            # argument (tests/test_oracle_vs_reference.py pins that).  There is no behaviour to reproduce.
+            raise IconAmdError("query(transforms=...) is not supported: the reference's own orthogonal() raises for any "
+                               "`transforms` (lib/net/geometry.py:57-60) and none of its callers passes one")
+        if calibs.is_cuda:
             # stays on the device: the kernels read the 12 floats themselves (no D2H copy / stream sync per query)
             calib12 = calibs[0, :3, :4].detach().to(torch.float32).contiguous()
             pts = points[0].t().to(torch.float32).contiguous()

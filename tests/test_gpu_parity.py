@@ -691,6 +691,28 @@ def test_adaptive_recon_matches_reference_volume(body):
     assert agree > 0.995
 
 
+def test_adaptive_recon_257_matches_reference_schedule(body):
+    """apps/ICON.py:62-90 at mcube_res=256: Seg3dLossless [33,65,129,257], faster=True, run verbatim on the synthetic
+    subject by tools/make_golden.py (h).  Same number of queried points at every level, and the same volume on the
+    stored subsets (stride-4 sub-lattice, three mid planes, 60,000 random voxels)."""
+    from icon_amd.engine import query_func
+    from icon_amd.recon import AdaptiveReconEngine
+    from types import SimpleNamespace
+    g = golden("seg3d_body_adaptive_257.npz")
+    eng = make_engine(body)
+    ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                             resolutions=[int(r) for r in g["resolutions"]], align_corners=True).to(dev())
+    vol = ad(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert vol.shape == (257, 257, 257)
+    assert ad.last_stats["queries"] == [int(q) for q in g["queries"]]
+    v = vol.cpu().numpy()
+    assert np.abs(v[::4, ::4, ::4] - g["sub4"]).max() <= OCC_TOL
+    assert np.abs(v[128] - g["plane_z"]).max() <= OCC_TOL and np.abs(v[:, 128] - g["plane_y"]).max() <= OCC_TOL
+    assert np.abs(v[:, :, 128] - g["plane_x"]).max() <= OCC_TOL
+    assert np.abs(v.reshape(-1)[g["idx"]] - g["samples"]).max() <= OCC_TOL
+    assert abs(int((v > 0.5).sum()) - int(g["inside"])) <= 8         # voxels within 1e-4 of the level may flip
+
+
 def test_lattice_513_properties(body):
     """cfg 5 size (513^3 = 135,005,697 points, 8.6 GB of MLP input rows): 64-bit indexing, and
     the even sub-lattice IS the 257^3 lattice (identical float coordinates), so in the per-point

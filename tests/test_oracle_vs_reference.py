@@ -1,6 +1,8 @@
 """CPU, build container only: the oracle against the reference's own Python imported verbatim
 from /root/reference (skipped on machines without the reference tree, e.g. the GPU box - the
 committed fixtures in tests/golden/ carry the same information there)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -84,3 +86,17 @@ def test_chamfer_dense_vs_adaptive_cpu(ref):
     (vd, fd), (va, fa) = mesh(dense), mesh(adaptive)
     c, _ = chamfer(vd, fd, va, fa, n=8000)
     assert c <= 3.2, c          # half a voxel: the voxel size at 33^3 is 6.25 on this x100 scale
+
+
+def test_reference_transforms_branch_is_dead_code(ref):
+    """lib/net/geometry.py:57-60: orthogonal(points, calibs, transforms) raises for the documented [B,2,3]
+    layout and for a bare [2,3] matrix alike, so HGPIFuNet.query(transforms=...) has no behaviour to mirror;
+    IconQueryEngine.query raises a clear error for it (icon_amd/engine.py)."""
+    pts = torch.randn(1, 3, 8)
+    calib = torch.eye(4)[None]
+    for tr in (torch.tensor([[1.0, 0.0, 0.1], [0.0, 1.0, -0.1]]), torch.tensor([[[1.0, 0.0, 0.1], [0.0, 1.0, -0.1]]])):
+        with pytest.raises(Exception):
+            ref.orthogonal(pts, calib, tr)
+    from common import ROOT
+    src = open(os.path.join(ROOT, "icon_amd", "engine.py")).read()
+    assert "transforms is not None" in src and "is not supported" in src

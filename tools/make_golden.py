@@ -127,9 +127,38 @@ def section_g_display():
     np.savez_compressed(os.path.join(OUT, "display_33.npz"), vol=vol, image=r.display(torch.from_numpy(vol)))
 
 
+def section_h_adaptive_257():
+    """(h) the schedule apps/ICON.py:62-90 builds for mcube_res=256 - Seg3dLossless, resolutions [33,65,129,257],
+    faster=True - run verbatim on the synthetic subject.  The 257^3 volume (68 MB) is stored as subsets: the
+    stride-4 sub-lattice, three orthogonal mid planes and 60,000 seeded random voxels; plus the number of
+    points the reference queried at every level."""
+    ref = ref_loader.load()
+    a = synth.make_assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    counts = []
+    orig = ref.query_func
+
+    def counting_query_func(opt, netG, features, points, proj_matrix=None):
+        counts.append(int(points.shape[1]))
+        return orig(opt, netG, features, points, proj_matrix)
+    res = [33, 65, 129, 257]
+    with torch.no_grad():
+        eng = ref.Seg3dLossless(query_func=counting_query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                resolutions=res, align_corners=True, balance_value=0.5, faster=True)
+        vol = eng(opt=cfg, netG=netG, features=[T(a.features)], proj_matrix=None).numpy().astype(np.float32)
+    rng = np.random.RandomState(257)
+    idx = rng.randint(0, 257 ** 3, 60000).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "seg3d_body_adaptive_257.npz"), resolutions=np.array(res), queries=np.array(counts),
+                        sub4=vol[::4, ::4, ::4], plane_z=vol[128], plane_y=vol[:, 128], plane_x=vol[:, :, 128],
+                        idx=idx, samples=vol.reshape(-1)[idx], inside=np.int64((vol > 0.5).sum()))
+    print("adaptive 257: queries per level", counts, "inside voxels", int((vol > 0.5).sum()))
+
+
 if __name__ == "__main__":
-    if "--display" in sys.argv:      # only (g)
-        section_g_display()
-    else:
+    only = [s for s in ("--display", "--adaptive257") if s in sys.argv]
+    if not only:
         main()
+    if not only or "--display" in only:
         section_g_display()
+    if not only or "--adaptive257" in only:
+        section_h_adaptive_257()
