@@ -36,16 +36,10 @@
 namespace icon {
 
 constexpr int kTilePts = kF16Pts;                     // 256 points per tile
-// LDS map: VER 1 = [2 x 40 KiB buffers][W0 32 KiB][side][point tile 16 KiB][wave sums];
-//          VER 2 = [3 x 32 KiB buffers][W0 32 KiB + layer-2 raw-input operands 8 KiB][side][point tile][wave sums]
-template <int VER> struct FusedLds {
-    static constexpr int w0 = VER == 2 ? kRes2Off : kW0Off;
-    static constexpr int side = VER == 2 ? kSide2Off : kSideOff;
-    static constexpr int xs = side + 4352;             // point tile [256][16] f32 behind the side arrays
-    static constexpr int misc = xs + kTilePts * kXRow * 4;
-    static constexpr int total = misc + 16;            // + the four wave sums of the outlier ballot
-};
-static_assert(FusedLds<2>::total <= 160 * 1024, "fused v2 LDS layout exceeds the 160 KiB of a CU");
+// LDS map: [2 x 40 KiB weight buffers][W0 32 KiB][side arrays][point tile 16 KiB][wave sums]
+constexpr int kXsOff = kSideOff + 4352;               // point tile [256][16] f32 behind the side arrays
+constexpr int kMiscOff = kXsOff + kTilePts * kXRow * 4;
+constexpr int kFusedLds = kMiscOff + 16;              // + the four wave sums of the outlier ballot
 
 struct SignSrc {
     int mode;
@@ -131,19 +125,17 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-template <int PRIOR, bool LATTICE, int VER>
+template <int PRIOR, bool LATTICE>
 __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float *__restrict__ out, MlpF16Dev w)
 {
-    constexpr int kXsOff = FusedLds<VER>::xs, kMiscOff = FusedLds<VER>::misc, kW0 = FusedLds<VER>::w0, kSideO = FusedLds<VER>::side;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *Xs = reinterpret_cast<float *>(smem + kXsOff);
     int *wsum = reinterpret_cast<int *>(smem + kMiscOff);
 
     // ---- once per workgroup: resident layer-0 operands, side arrays, sign-list geometry ------------------
-    issue_units(w.image, smem + kW0, kW0Bytes / 1024, wave0, lane0);
-    if (VER == 2) issue_units(w.image + (size_t)(chunk_offset(19) + 32) * 1024, smem + kL2XOff, 8, wave0, lane0);
-    float *side = reinterpret_cast<float *>(smem + kSideO);
+    issue_units(w.image, smem + kW0Off, kW0Bytes / 1024, wave0, lane0);
+    float *side = reinterpret_cast<float *>(smem + kSideOff);
     for (int i = threadIdx.x; i < kSideFloats; i += kF16Block) side[i] = w.side[i];
     const float *sb0 = side, *sb1 = side + 512, *sb2 = side + 768, *sw3 = side + 896;
     int64_t K = 0, rank0 = 0;
@@ -158,11 +150,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
 
     const int64_t ntiles = (G.N + kTilePts - 1) / kTilePts;
     int64_t tile = blockIdx.x;
-    if (tile < ntiles) {
-        if (VER == 2) { issue_chunk_v2(w.image, smem, 0, wave0, lane0); issue_chunk_v2(w.image, smem + kBuf2Bytes, 1, wave0, lane0); }
-        else issue_chunk(w.image, smem, 0, wave0, lane0);
-    }
-    int rot = 0;                    // VER 2: buffer of the current chunk (the three buffers rotate chunk by chunk)
+    if (tile < ntiles) issue_chunk(w.image, smem, 0, wave0, lane0);
 
     for (; tile < ntiles; tile += gridDim.x) {
         // Everything derived from the thread index is re-derived per tile from an opaque copy: hoisted out of
@@ -274,54 +262,24 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc1[m] = ld16(sb1 + (m * 2 + h) * 16);
         half8 bh[2], bl[2];
-        activate_split(l0_tile(smem + kW0, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
+        activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
         f32x16 acc2[4];
         const bool more = tile + gridDim.x < ntiles;            // the first chunks of the next tile ride on the last ones
-        if (VER == 2) {
-#define ICON_BUF(k) (smem + ((rot + (k)) % 3) * kBuf2Bytes)
-            half8 a[2][4];
-            load_group(ICON_BUF(0), 0, lane, a[0]);
-            for (int c = 0; c < 15; ++c) {
-                l01_chunk_v2<false>(ICON_BUF(0), ICON_BUF(1), ICON_BUF(2), c + 2, smem + kW0, sb0, w.image, c, acc1, xhi, xlo,
-                                    w.inv0, w.inv1, h, lane, wave, bh, bl, a);
-                __syncthreads();
-                rot = (rot + 1) % 3;
-            }
-            l01_chunk_v2<true>(ICON_BUF(0), ICON_BUF(1), ICON_BUF(2), 17, smem + kW0, sb0, w.image, 15, acc1, xhi, xlo,
-                               w.inv0, w.inv1, h, lane, wave, bh, bl, a);
+        for (int c = 0; c < 16; ++c) {
+            l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
+                      w.inv0, h, lane, wave, bh, bl);
             __syncthreads();
-            rot = (rot + 1) % 3;
-#pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
-            l2_chunk_v2<0>(ICON_BUF(0), ICON_BUF(1), ICON_BUF(2), 18, smem + kL2XOff, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, a);
-            __syncthreads();
-            rot = (rot + 1) % 3;
-            l2_chunk_v2<1>(ICON_BUF(0), ICON_BUF(1), ICON_BUF(2), 19, smem + kL2XOff, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, a);
-            __syncthreads();
-            rot = (rot + 1) % 3;
-            l2_chunk_v2<2>(ICON_BUF(0), ICON_BUF(1), ICON_BUF(2), more ? 0 : -1, smem + kL2XOff, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, a);
-            __syncthreads();
-            rot = (rot + 1) % 3;
-            l2_chunk_v2<3>(ICON_BUF(0), nullptr, ICON_BUF(2), more ? 1 : -1, smem + kL2XOff, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, a);
-            rot = (rot + 1) % 3;
-#undef ICON_BUF
-        } else {
-            for (int c = 0; c < 16; ++c) {
-                l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0, sb0, w.image, c, acc1, xhi, xlo,
-                          w.inv0, h, lane, wave, bh, bl);
-                __syncthreads();
-            }
-#pragma unroll
-            for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
-            activate_split(acc1[0], w.inv1, bh, bl);
-            l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-            __syncthreads();
-            l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-            __syncthreads();
-            l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-            __syncthreads();
-            l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, more ? 0 : -1);
         }
+#pragma unroll
+        for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
+        activate_split(acc1[0], w.inv1, bh, bl);
+        l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        __syncthreads();
+        l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, more ? 0 : -1);
 
         // ---- layer 3 on the VALU (f32) ---------------------------------------------------------------------
         const float *w3 = sw3 + h * 72;
@@ -400,24 +358,19 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     }
     const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
-#define ICON_FUSED(P, L, V)                                                                                                \
+#define ICON_FUSED(P, L)                                                                                                   \
     do {                                                                                                                   \
         static bool attr = false;                                                                                          \
         if (!attr) {                                                                                                       \
-            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L, V>),                             \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, FusedLds<V>::total));                 \
+            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L>),                                \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));                          \
             attr = true;                                                                                                   \
         }                                                                                                                  \
-        hipLaunchKernelGGL((k_fused_f16x3<P, L, V>), dim3(grid), dim3(kF16Block), FusedLds<V>::total, st, G, d_occ, w);    \
+        hipLaunchKernelGGL((k_fused_f16x3<P, L>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);                \
     } while (0)
-    // ICON_AMD_FUSED_VER=1 selects the double-buffered round-2a body (A/B measurements; icon prior on the lattice only)
-    static const int ver = getenv("ICON_AMD_FUSED_VER") ? atoi(getenv("ICON_AMD_FUSED_VER")) : 2;
-    if (prior == ICON_PRIOR_ICON) {
-        if (lattice) { if (ver == 1) ICON_FUSED(ICON_PRIOR_ICON, true, 1); else ICON_FUSED(ICON_PRIOR_ICON, true, 2); }
-        else ICON_FUSED(ICON_PRIOR_ICON, false, 2);
-    }
-    else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true, 2); else ICON_FUSED(ICON_PRIOR_PAMIR, false, 2); }
-    else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true, 2); else ICON_FUSED(ICON_PRIOR_PIFU, false, 2); }
+    if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true); else ICON_FUSED(ICON_PRIOR_ICON, false); }
+    else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true); else ICON_FUSED(ICON_PRIOR_PAMIR, false); }
+    else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true); else ICON_FUSED(ICON_PRIOR_PIFU, false); }
 #undef ICON_FUSED
     ICON_HIP(hipGetLastError());
     return ICON_OK;

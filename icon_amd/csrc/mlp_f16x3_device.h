@@ -45,14 +45,27 @@ __device__ __forceinline__ f32x16 ld16(const float *p)
     return v;
 }
 
-// x -> (hi, lo) with hi = f16_rtz(x), lo = f16_rtz(x - hi); 8 values -> one MFMA operand each
+// lo halves of a pair: f16(v - hi), the subtraction exact in f32 (hi is a truncation of v), ONE rounding
+// (nearest-even) into f16 - v_fma_mixlo/hi_f16 computes fma(f16 hi, -1.0, f32 v) straight into the low / high
+// half of the packed result: 2 issue slots where `v - (float)hi` + cvt_pkrtz takes 5 (2 x v_cvt_f32_f16,
+// 2 x v_sub_f32, v_cvt_pkrtz).  The activation VALU work is dynamic power the matrix pipe cannot use: the
+// kernel is power-bound (tools/mlp_power_probe.py), so every removed VALU instruction is time.
+__device__ __forceinline__ fp16x2 residual_pair(fp16x2 hh, float v0, float v1)
+{
+    const int hb = __builtin_bit_cast(int, hh);
+    int lb;
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb) : "v"(hb), "v"(v0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb) : "v"(hb), "v"(v1));
+    return __builtin_bit_cast(fp16x2, lb);
+}
+
+// x -> (hi, lo) with hi = f16_rtz(x), lo = f16_rne(x - hi); 8 values -> one MFMA operand each
 __device__ __forceinline__ void split8(const float *v, half8 &hi, half8 &lo)
 {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const fp16x2 h = __builtin_amdgcn_cvt_pkrtz(v[2 * q], v[2 * q + 1]);
-        const float r0 = v[2 * q] - (float)h[0], r1 = v[2 * q + 1] - (float)h[1];
-        const fp16x2 l = __builtin_amdgcn_cvt_pkrtz(r0, r1);
+        const fp16x2 l = residual_pair(h, v[2 * q], v[2 * q + 1]);
         hi[2 * q] = (_Float16)h[0]; hi[2 * q + 1] = (_Float16)h[1];
         lo[2 * q] = (_Float16)l[0]; lo[2 * q + 1] = (_Float16)l[1];
     }
@@ -99,15 +112,10 @@ __device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k,
 // stays in flight for the whole multiplication of chunk k and is only waited for at the barrier.
 
 // 3-term product group for 2 output tiles sharing one B operand pair
-#ifdef ICON_EXP_ONEMFMA    // timing experiment only: hi*hi term alone (1/3 of the MFMAs), wrong results
-#define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
-    ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]);
-#else
 #define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
     ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AL[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]);
-#endif
 
 // layer 0, hidden tile c (32 channels): 3 MFMAs from the resident W0 region
 __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const float *__restrict__ sb0, int c, half8 xhi, half8 xlo,
@@ -123,27 +131,11 @@ __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const flo
 // hi/lo halves -> pair (k&3) of the next B operand (u = k>>2)
 __device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, half8 (&nh)[2], half8 (&nl)[2])
 {
-#ifdef ICON_EXP_NOACT      // timing experiment only: no activation VALU work, wrong results
-    { const int u_ = k >> 2, q_ = k & 3; nh[u_][2 * q_] = nh[u_][2 * q_ + 1] = (_Float16)1.0f; nl[u_][2 * q_] = nl[u_][2 * q_ + 1] = (_Float16)0.5f; return; }
-#endif
-#ifdef ICON_EXP_FASTACT    // timing experiment: no scale multiply, residual through v_fma_mix (2 instead of 5 issue slots)
-    const float x0 = acc[2 * k], x1 = acc[2 * k + 1];
-    const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
-    fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-    fp16x2 ll;
-    {
-        const int hb_ = __builtin_bit_cast(int, hh);
-        int lb_;
-        asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(lb_) : "v"(hb_), "v"(v0));
-        asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lb_) : "v"(hb_), "v"(v1));
-        ll = __builtin_bit_cast(fp16x2, lb_);
-    }
-#else
+
     const float x0 = acc[2 * k] * inv, x1 = acc[2 * k + 1] * inv;
     const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
     fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
-    fp16x2 ll = __builtin_amdgcn_cvt_pkrtz(v0 - (float)hh[0], v1 - (float)hh[1]);
-#endif
+    fp16x2 ll = residual_pair(hh, v0, v1);
     // the (empty) volatile asm is ordered against the surrounding sched_barriers, which keeps this
     // VALU work in the MFMA group it was written next to instead of being sunk to the end of the chunk
     int hb = __builtin_bit_cast(int, hh), lb = __builtin_bit_cast(int, ll);
@@ -234,133 +226,5 @@ __device__ __forceinline__ void l2_chunk(const char *__restrict__ L, char *__res
     }
 }
 
-// =============================================================================================
-// v2 chunk bodies (persistent fused kernel): TRIPLE-buffered weight stream.
-//   * chunk g+2 is DMA'd while chunk g is multiplied, so chunk g+1 is already complete in LDS during
-//     chunk g: its first A operands are read into registers BEFORE the barrier that ends chunk g, and
-//     the first MFMAs of every chunk issue straight after the barrier instead of waiting ~200 cycles
-//     for ds_read_b128 (20 barriers per 256-point tile);
-//   * only waves 0-3 - one per SIMD - issue the LDS-DMA pieces; their SIMD partners (waves 4-7) run
-//     their MFMAs meanwhile, so the ~60-100 cycles each piece costs its issuing wave no longer idle the
-//     matrix pipe (in v1 both waves of a SIMD issue their pieces at the same moment, right after the barrier);
-//   * the layer-0 MFMAs of the next chunk come after the first layer-1 group, their operands (resident
-//     region) loaded underneath it;
-//   * the last layer-1 chunk prepares layer 2's first B operand instead of a (discarded) 17th layer-0 tile.
-// Same products in the same accumulation order as v1: results are bit-identical.
-// LDS: [3 x 32 KiB buffers][resident: W0 32 KiB + raw-input k-step of layer 2, 8 KiB][side arrays]...
-// =============================================================================================
-// Issue order inside one group region: the four ds_read_b128 of the NEXT group first, then MFMA / VALU
-// alternating (NV VALU instructions behind every MFMA).  Without it the scheduler emits the six MFMAs
-// back to back and the activation VALU block after them; the two waves of a SIMD run the same stream in
-// phase, so their VALU blocks coincide and the matrix pipe idles meanwhile (PMC round 2: MFMA busy 65 % +
-// VALU busy 34 % = 99 % of the kernel, i.e. no overlap at all).
-#define ICON_INTERLEAVE(NV)                                                          \
-    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                               \
-    _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                               \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                           \
-        __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);                        \
-    }
-
-constexpr int kBuf2Bytes = 32 * 1024;
-constexpr int kRes2Off = 3 * kBuf2Bytes;
-constexpr int kL2XOff = kRes2Off + 32 * 1024;
-constexpr int kRes2Bytes = 40 * 1024;
-constexpr int kSide2Off = kRes2Off + kRes2Bytes;
-
-__device__ __forceinline__ void issue_chunk_v2(const char *image, char *buf, int k, int wave, int lane)
-{
-#ifdef ICON_EXP_NODMA      // timing experiment only (tools/exp_fused.sh): wrong results
-    return;
-#endif
-    if (wave < 4) {
-        const char *src = image + (size_t)chunk_offset(k) * 1024;
-        for (int u = wave; u < 32; u += 4)
-            __builtin_amdgcn_global_load_lds((gvoid_t *)(src + u * 1024 + lane * 16), (lvoid_t *)(buf + u * 1024), 16, 0, 0);
-    }
-}
-
-// layers 0+1, chunk c (buffer L), first A operands preloaded in a[0]; leaves the first A operands of the
-// NEXT chunk (buffer Ln, already complete) in a[0].  LAST: chunk 15.
-template <bool LAST>
-__device__ __forceinline__ void l01_chunk_v2(const char *__restrict__ L, const char *__restrict__ Ln, char *__restrict__ dma_dst, int dma_chunk,
-                                             const char *__restrict__ W0, const float *__restrict__ sb0, const char *image, int c,
-                                             f32x16 (&acc1)[8], half8 xhi, half8 xlo, float inv0, float inv1, int h, int lane, int wave,
-                                             half8 (&bh)[2], half8 (&bl)[2], half8 (&a)[2][4])
-{
-    if (dma_chunk >= 0) issue_chunk_v2(image, dma_dst, dma_chunk, wave, lane);
-    f32x16 h0n;
-    half8 w0h, w0l;
-    if (!LAST) {
-        h0n = ld16(sb0 + ((c + 1) * 2 + h) * 16);
-        w0h = lds_op(W0, 2 * (c + 1), lane); w0l = lds_op(W0, 2 * (c + 1) + 1, lane);
-    }
-    load_group(L, 1, lane, a[1]);
-    half8 nh[2], nl[2];
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const half8 ah[2] = {a[0][0], a[0][1]}, al[2] = {a[0][2], a[0][3]};
-        TRIPLE2(acc1, 0, ah, al, bh[0], bl[0])
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LAST) { h0n = MFMA16(w0h, xhi, h0n); h0n = MFMA16(w0h, xlo, h0n); h0n = MFMA16(w0l, xhi, h0n); }
-#pragma unroll
-    for (int g = 1; g < 8; ++g) {
-        if (g + 1 < 8) load_group(L, g + 1, lane, a[(g + 1) & 1]);
-        else load_group(Ln, 0, lane, a[0]);
-        const int u = g >> 2, m0 = (g & 3) * 2;
-        const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
-        TRIPLE2(acc1, m0, ah, al, bh[u], bl[u])
-        if (!LAST) act_part(h0n, g - 1, inv0, nh, nl);
-        else if (g >= 5) {                       // acc1[0] is final after group 4: its activation = layer 2's first B operand
-            act_part(acc1[0], 3 * (g - 5), inv1, nh, nl); act_part(acc1[0], 3 * (g - 5) + 1, inv1, nh, nl);
-            if (g < 7) act_part(acc1[0], 3 * (g - 5) + 2, inv1, nh, nl);
-        }
-        if (LAST && g >= 5) { ICON_INTERLEAVE(6) } else { ICON_INTERLEAVE(2) }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!LAST) act_part(h0n, 7, inv0, nh, nl);
-    bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1];
-}
-
-// layer 2, chunk 16+Q as one pipeline of 8 groups (hidden tiles 2Q, 2Q+1); Ln = next chunk's buffer or null
-template <int Q>
-__device__ __forceinline__ void l2_chunk_v2(const char *__restrict__ L, const char *__restrict__ Ln, char *__restrict__ dma_dst, int dma_chunk,
-                                            const char *__restrict__ L2X, const char *image, f32x16 (&acc1)[8], f32x16 (&acc2)[4],
-                                            half8 xhi, half8 xlo, float inv1, int lane, int wave, half8 (&bh)[2], half8 (&bl)[2],
-                                            half8 (&a)[2][4])
-{
-    if (dma_chunk >= 0) issue_chunk_v2(image, dma_dst, dma_chunk, wave, lane);
-    auto load2 = [&](int G, half8 (&dst)[4]) {          // group G: hidden tile mm = G>>2, k-step u = (G&3)>>1, output tiles 2*(G&1), +1
-        const int mm = G >> 2, g = G & 3;
-        const int slot = (((mm * 2 + (g >> 1)) * 4 + (g & 1) * 2) * 2);
-        dst[0] = lds_op(L, slot, lane); dst[1] = lds_op(L, slot + 2, lane);
-        dst[2] = lds_op(L, slot + 1, lane); dst[3] = lds_op(L, slot + 3, lane);
-    };
-    load2(1, a[1]);
-    half8 nh[2], nl[2];
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int G = 0; G < 8; ++G) {
-        constexpr int kLast = 7;
-        const int mm = G >> 2, g = G & 3, m = 2 * Q + mm;
-        if (G >= 1) {
-            if (G + 1 < 8) load2(G + 1, a[(G + 1) & 1]);
-            else if (Ln != nullptr) load_group(Ln, 0, lane, a[0]);
-        }
-        const int u = g >> 1, m0 = (g & 1) * 2;
-        const half8 ah[2] = {a[G & 1][0], a[G & 1][1]}, al[2] = {a[G & 1][2], a[G & 1][3]};
-        TRIPLE2(acc2, m0, ah, al, bh[u], bl[u])
-        if (m < kLast) { act_part(acc1[m < kLast ? m + 1 : m], 2 * g, inv1, nh, nl); act_part(acc1[m < kLast ? m + 1 : m], 2 * g + 1, inv1, nh, nl); }
-        ICON_INTERLEAVE(4)
-        __builtin_amdgcn_sched_barrier(0);
-        if (g == 3 && m < kLast) { bh[0] = nh[0]; bh[1] = nh[1]; bl[0] = nl[0]; bl[1] = nl[1]; }
-    }
-    if (Q == 3) {
-        half8 ah[4], al[4];
-#pragma unroll
-        for (int i4 = 0; i4 < 4; ++i4) { ah[i4] = lds_op(L2X, i4 * 2, lane); al[i4] = lds_op(L2X, 1 + i4 * 2, lane); }
-        TRIPLE4(acc2, 0, ah, al, xhi, xlo)
-    }
-}
 
 }  // namespace icon
