@@ -217,6 +217,8 @@ struct icon_work {
     int64_t cap_points = 0;
     int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
     int64_t *d_block_offsets = nullptr;   // exclusive prefix of the above
+    int32_t *d_scan_local = nullptr;      // scan scratch: prefix inside each 1024-entry chunk
+    int64_t *d_scan_part = nullptr;       // scan scratch: chunk totals
     int64_t cap_blocks = 0;
     int8_t *d_signs = nullptr;            // compacted outlier signs of the call
     int64_t cap_signs = 0;

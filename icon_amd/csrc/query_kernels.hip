@@ -259,19 +259,15 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_count(const uint8_t *__r
     }
 }
 
-// single-workgroup exclusive scan of the per-block counts (66k entries for a 257^3 call);
-// offsets are int64 (a 513^3 lattice has 1.35e8 points).  Each of the 1024 threads owns a contiguous run;
-// the 1024 run totals are scanned with wave shuffles + one LDS hop (the serial loop this replaces took
-// 0.13 ms - as much as k_sign, k_outlier_count and k_outlier_compact together).
-__global__ __launch_bounds__(1024) void k_scan_blocks(const int32_t *counts, int64_t nblocks, int64_t *offsets, int64_t *total)
+// Exclusive scan of the per-tile outlier counts (66,308 entries for a 257^3 call; int64 offsets: a 513^3
+// lattice has 1.35e8 points) in two coalesced passes: k_scan_local scans 1,024 consecutive counts per
+// workgroup (wave shuffles + one LDS hop) and records the chunk total, k_scan_apply adds the sum of the
+// preceding chunk totals.  (A single workgroup walking 65 strided entries per thread was latency-bound:
+// 0.12 ms - more than k_sign, the count and the compaction together.)
+__device__ __forceinline__ int64_t block_exclusive_scan_1024(int64_t v, int64_t *wtot /* LDS [16] */, int64_t *block_total)
 {
-    __shared__ int64_t wtot[16];
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int64_t per = (nblocks + 1023) / 1024;
-    const int64_t beg = min((int64_t)t * per, nblocks), end = min(beg + per, nblocks);
-    int64_t s = 0;
-    for (int64_t k = beg; k < end; ++k) s += counts[k];
-    int64_t incl = s;                                   // inclusive scan inside the wave
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int64_t incl = v;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
         const int64_t up = __shfl_up(incl, d);
@@ -281,10 +277,36 @@ __global__ __launch_bounds__(1024) void k_scan_blocks(const int32_t *counts, int
     __syncthreads();
     int64_t base = 0, all = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { const int64_t v = wtot[k]; if (k < w) base += v; all += v; }
-    if (t == 0) *total = all;
-    int64_t run = base + incl - s;
-    for (int64_t k = beg; k < end; ++k) { offsets[k] = run; run += counts[k]; }
+    for (int k = 0; k < 16; ++k) { const int64_t t = wtot[k]; if (k < w) base += t; all += t; }
+    *block_total = all;
+    return base + incl - v;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_local(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ local, int64_t *__restrict__ part)
+{
+    __shared__ int64_t wtot[16];
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    const int64_t v = (i < n) ? counts[i] : 0;
+    int64_t total;
+    const int64_t ex = block_exclusive_scan_1024(v, wtot, &total);
+    if (i < n) local[i] = (int32_t)ex;
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(1024) void k_scan_apply(const int32_t *__restrict__ local, const int64_t *__restrict__ part, int64_t nchunks, int64_t n,
+                                                     int64_t *__restrict__ offsets, int64_t *__restrict__ total)
+{
+    __shared__ int64_t wtot[16];
+    // sum of the chunk totals before this chunk (and of all chunks, for *total): nchunks <= a few hundred
+    int64_t before = 0, all = 0;
+    for (int64_t k = threadIdx.x; k < nchunks; k += 1024) { const int64_t t = part[k]; all += t; if (k < blockIdx.x) before += t; }
+    int64_t sum_all, sum_before;
+    (void)block_exclusive_scan_1024(all, wtot, &sum_all);
+    __syncthreads();
+    (void)block_exclusive_scan_1024(before, wtot, &sum_before);
+    const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) offsets[i] = sum_before + local[i];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *total = sum_all;
 }
 
 __device__ __forceinline__ int64_t outlier_rank(bool o, const int64_t *block_offsets, int *wsum)
@@ -480,7 +502,7 @@ extern "C" int icon_work_create(icon_work_t **out)
 extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
-    (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
+    (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
@@ -558,10 +580,12 @@ int ensure_work(icon_work *w, int64_t n_points, bool need_x)
     }
     const int64_t nblk = (n_points + kScanBlock - 1) / kScanBlock;
     if (nblk > w->cap_blocks) {
-        (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets);
-        w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->cap_blocks = 0;
+        (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
+        w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->d_scan_local = nullptr; w->d_scan_part = nullptr; w->cap_blocks = 0;
         ICON_HIP(hipMalloc((void **)&w->d_block_counts, (size_t)nblk * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&w->d_block_offsets, (size_t)nblk * sizeof(int64_t)));
+        ICON_HIP(hipMalloc((void **)&w->d_scan_local, (size_t)nblk * sizeof(int32_t)));
+        ICON_HIP(hipMalloc((void **)&w->d_scan_part, (size_t)((nblk + 1023) / 1024) * sizeof(int64_t)));
         w->cap_blocks = nblk;
     }
     if (n_points > w->cap_signs) {
@@ -663,7 +687,9 @@ int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
 {
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
     hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
-    hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_block_offsets, w->d_total);
+    const int64_t nchunks = (nblk + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total);
     hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
     ICON_HIP(hipGetLastError());
     return ICON_OK;

@@ -246,8 +246,10 @@ class DenseReconEngine(nn.Module):
                 be.slab_finish(res, z0, z1, signs_global, sum(counts), sum(counts[:rank]),
                                out=slab[: z1 - z0], device=dev)
             self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world, slabs=parts)
-        elif z1 > z0:
-            be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
+        else:
+            if z1 > z0:
+                be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
+            self.last_stats = dict(exchanged_bytes=0, collectives=1, slabs=parts)
         allv = self._all_gather_cat(dist, slab, world, g)
         if all(b - a == per for a, b in parts):
             return allv[:res]

@@ -1,0 +1,21 @@
+#!/bin/bash
+# One GPU call that regenerates everything profiles/ quotes: tests, bench lines, kernel stats, HBM traffic, PMC.
+#   usage: gpurun -- 'bash tools/gpu_round.sh <tag>'      (outputs under gpurun_out/<tag>_*; summarise with tools/rocprof_summary.py)
+T=${1:-rX}
+R=$PWD
+mkdir -p gpurun_out
+timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1; tail -3 gpurun_out/${T}_pytest.log
+timeout 600 python bench.py > gpurun_out/${T}_bench.log 2>&1; tail -1 gpurun_out/${T}_bench.log | cut -c1-400
+timeout 600 python bench.py --prior pamir --no-cpu-baseline > gpurun_out/${T}_bench_pamir.log 2>&1; tail -1 gpurun_out/${T}_bench_pamir.log | cut -c1-300
+timeout 600 python bench.py --precision f32 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > gpurun_out/${T}_bench_f32.log 2>&1; tail -1 gpurun_out/${T}_bench_f32.log | cut -c1-300
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_stats.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${T}_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${T}_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_write.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $R/gpurun_out/${T}_pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_pmc.log 2>&1
+cd $R
+python tools/rocprof_summary.py stats $(find gpurun_out/${T}_stats -name "*.db" | head -1) > gpurun_out/${T}_kernel_stats.csv; head -9 gpurun_out/${T}_kernel_stats.csv
+python tools/rocprof_summary.py traffic $(find gpurun_out/${T}_fetch -name "*.db" | head -1) $(find gpurun_out/${T}_write -name "*.db" | head -1) > gpurun_out/${T}_traffic.json
+python tools/pmc_extract.py $(find gpurun_out/${T}_pmc -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc.txt
+python tools/mlp_power_probe.py f16x3 5 > gpurun_out/${T}_power_probe.txt; cat gpurun_out/${T}_power_probe.txt
+find gpurun_out -name "*.db" -delete
