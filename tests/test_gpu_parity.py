@@ -820,3 +820,29 @@ def test_pamir_lattice_vs_oracle():
     assert np.abs(v.ravel()[idx] - ref).max() <= OCC_TOL
     split = torch.cat([eng.eval_slab(T(feat), res, 0, 100), eng.eval_slab(T(feat), res, 100, res)])
     assert torch.equal(split, occ)
+
+
+# ---------------------------------------------------------------------------------------------
+# icon-nofilter.yaml: raw normal maps as "features" (use_filter False, lib/net/HGPIFuNet.py:230-233):
+# [1,6,H,W] planes -> 3 image channels + 7 SMPL channels = a 10-channel regressor
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", F32_CLASS)
+def test_icon_nofilter_layout(body, precision):
+    from icon_amd.engine import IconQueryEngine
+    dims = [10, 512, 256, 128, 1]
+    sd = synth.make_mlp_state_dict(seed=synth.SEED + 9, dims=dims, sdf_channel=3)
+    feat = synth.make_feature_planes(6, 96, synth.SEED + 4)           # not 128 x 128: plane size is free
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, precision=precision)
+    eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=77)
+    occ = eng.query([T(feat)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    ref, X = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], feat,
+                            orc.Mlp(sd), pts, sdf_clip=body.sdf_clip)
+    assert X.shape[1] == 10
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    res = 33
+    vol = eng.eval_slab(T(feat), res, 0, res).cpu().numpy().ravel()
+    ref_l, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], feat,
+                              orc.Mlp(sd), synth.lattice_points(res), sdf_clip=body.sdf_clip)
+    assert np.abs(vol - ref_l).max() <= OCC_TOL
