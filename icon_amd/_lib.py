@@ -43,7 +43,7 @@ class IconAmdError(RuntimeError):
 
 def build(force: bool = False) -> str:
     """Compile libicon_amd.so with hipcc for gfx950 (cross-compiles without a GPU)."""
-    args = ["make", "-C", CSRC] + (["-B"] if force else [])
+    args = ["make", "-j8", "-C", CSRC] + (["-B"] if force else [])
     proc = subprocess.run(args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if proc.returncode != 0:
         raise IconAmdError("building libicon_amd.so failed:\n" + proc.stdout[-4000:])
