@@ -96,3 +96,23 @@ def test_display_on_device_volume():
     g = golden("display_33.npz")
     eng = DenseReconEngine(resolutions=[17, 33], align_corners=True)
     assert np.array_equal(eng.display(torch.from_numpy(g["vol"]).cuda()), g["image"])
+
+
+@pytest.mark.gpu
+def test_chamfer_p2s_on_the_hip_closest_point_engine():
+    """icon_amd.metrics.chamfer_p2s (lib/dataset/Evaluator.py:200-230 on the exact nearest-triangle kernel): zero for a
+    mesh against itself, equal to the checker-based restatement (tests/common.py: chamfer) within sampling noise for
+    two different surfaces, and p2s == the gt-samples -> prediction half."""
+    from common import chamfer
+    from icon_amd import metrics, synth
+    dev = torch.device("cuda:0")
+    v1, f1 = synth.icosphere(3, radius=0.6)
+    v2, f2 = synth.icosphere(3, radius=0.63, center=(0.05, -0.02, 0.01))
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    c0, p0 = metrics.chamfer_p2s(T(v1), T(f1), T(v1), T(f1), n=100_000)
+    assert c0 <= 1e-3 and p0 <= 1e-3                                  # x100 scale: 1e-5 in cube units
+    c, p = metrics.chamfer_p2s(T(v2), T(f2), T(v1), T(f1), n=100_000)
+    c_ref, _ = chamfer(v2, f2, v1, f1, n=20000)
+    assert abs(c - c_ref) <= 0.03 * c_ref + 0.02, (c, c_ref)
+    assert 0.5 * c <= p <= 2.0 * c
+    assert 2.0 <= c <= 6.0                                            # radii differ by 0.03, centres by 0.055 -> a few x100 units
