@@ -212,7 +212,7 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
 struct icon_work {
     float *d_x = nullptr;                 // [cap_x][16] MLP input rows (materialising paths only: f32 / mx6 / brute force)
     int64_t cap_x = 0;
-    void *d_near = nullptr;               // [cap_points] (slot, d^2 bits) from k_nearest
+    void *d_near = nullptr;               // nearest-triangle result: int32 slot [cap_points] followed by float d^2 [cap_points]
     uint8_t *d_code8 = nullptr;           // [cap_points] byte copy of each row's code word
     int64_t cap_points = 0;
     int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
@@ -252,3 +252,8 @@ struct icon_work {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
 };
+
+namespace icon {
+inline int32_t *work_near_slot(const icon_work *w) { return reinterpret_cast<int32_t *>(w->d_near); }
+inline float *work_near_d2(const icon_work *w) { return reinterpret_cast<float *>(w->d_near) + w->cap_points; }
+}  // namespace icon

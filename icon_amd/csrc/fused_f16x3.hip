@@ -9,11 +9,11 @@
 //     k_outlier_patch_self -> X rows rewritten         1 + 64 r + 64 w     (reference cmap mode)
 //     k_mlp_f16x3          <- X rows                      64 r + 4 w      => ~280 B/pt, 4.8 GB per 257^3
 //   now
-//     k_nearest            -> (slot, d^2)                  8 B  w
-//     k_sign               -> 1-byte code (outlier, sign, inside, in_cube)   8 r + 1 w
+//     k_nearest            -> slot 4 B + d^2 4 B (structure of arrays)        8 B  w
+//     k_sign               -> 1-byte code (outlier, sign, inside, in_cube)   4 r + 1 w
 //     count / scan / compact over the codes                2 r + <=1 w
-//     k_fused_f16x3        <- (slot, d^2), code, sign list; -> occupancy     8 + 1 + ~3 r + 4 w
-//                                                                         => ~36 B/pt, 0.6 GB per 257^3
+//     k_fused_f16x3        <- slot, code, d^2 only inside the clip band (~6 %), sign list; -> occupancy
+//                                                                         4 + 1 + ~3 r + 4 w  => ~30 B/pt
 // (the algorithmic traffic is the 4-byte occupancy; what is left on top is the
 // nearest-triangle result handed from the VALU-bound traversal kernel to the MFMA-bound one.)
 //
@@ -61,19 +61,23 @@ struct FusedGeom {
     int64_t N;
     float sdf_clip;
     int cmap_local;
-    const int2 *near;            // icon prior: (slot, bits of d^2) from k_nearest / k_nearest_coop
-    const uint8_t *code8;        // icon prior: k_sign
+    const int32_t *near_slot;    // icon prior: slot of the nearest triangle (k_nearest / k_nearest_coop)
+    const float *near_d2;        //             its squared distance - valid for the points inside the clip band only
+    const uint8_t *code8;        // icon prior: outlier / sign / inside / in_cube (k_nearest<.., SIGN> or k_sign)
     const int64_t *tile_offsets; // exclusive scan of the outlier counts per 256-point tile
     SignSrc sg;
 };
 
 // ---------------------------------------------------------------------------------------------
-// k_sign: outlier flag, sign, inside flag and in_cube flag of every point (icon prior), 1 byte
+// k_sign: outlier flag, sign, inside flag and in_cube flag of every point (icon prior), 1 byte.  Reads only
+// the squared distances (4 B/pt of the structure-of-arrays result of k_nearest).  Folding this epilogue into
+// k_nearest itself was measured: its registers (75 VGPRs / 106 SGPRs instead of 50 / 70) cost the traversal
+// two of its eight waves per SIMD, 4.48 vs 4.31 ms for the pre-pass - so it stays a separate 0.07 ms launch.
 // ---------------------------------------------------------------------------------------------
 template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                              const int2 *__restrict__ near, uint8_t *__restrict__ code8)
+                                              const float *__restrict__ near_d2, uint8_t *__restrict__ code8)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
@@ -87,14 +91,7 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
         ins = inside_bins(m, p);
     }
-    const float dist = sqrtf(__int_as_float(near[i].y)) / sqrtf(3.0f);     // mesh_util.py:391
-    const float s = ins ? dist : -dist;                                   // :393-394
-    uint32_t code = in_cube_bit(p) | (ins ? kCodeInside : 0u);
-    if (fabsf(s) >= sdf_clip) {                                            // HGPIFuNet.py:298
-        const int sg = (s > 0.0f) ? 1 : ((s < 0.0f) ? -1 : 0);
-        code |= kCodeOutlier | ((uint32_t)(sg + 1) << kCodeSignShift);
-    }
-    code8[i] = (uint8_t)code;
+    code8[i] = (uint8_t)sign_code(p, near_d2[i], ins, sdf_clip);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -167,12 +164,14 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const bool live = i < G.N;
         if (!live) i = G.N - 1;
         uint32_t code = 0;
-        int2 nn = make_int2(0, 0);
+        int slot = 0;
+        float d2 = 0.0f;
         bool outl = false;
         if (PRIOR == ICON_PRIOR_ICON) {
             if (worker) {
                 code = G.code8[i];
-                nn = G.near[i];
+                slot = G.near_slot[i];
+                if (!(code & kCodeOutlier)) d2 = G.near_d2[i];      // an outlier's sdf is its sign
                 outl = live && (code & kCodeOutlier);
             }
             const unsigned long long b = __ballot(outl);
@@ -186,7 +185,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
                 } else {
                     p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
                 }
-                Nearest nr; nr.slot = nn.x; nr.d2 = __int_as_float(nn.y); nr.face = 0;
+                Nearest nr; nr.slot = slot; nr.d2 = d2; nr.face = 0;
                 const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
                 float s = o.sdf;
                 f3 cmv = o.cm;
@@ -319,11 +318,10 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
 {
     const int64_t nb = (N + 255) / 256;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    const int2 *near = reinterpret_cast<const int2 *>(work->d_near);
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, near, work->d_code8);
+                                    work->d_row_count, work->d_row_slots, work_near_d2(work), work->d_code8);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, near, work->d_code8);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_d2(work), work->d_code8);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
@@ -336,7 +334,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     FusedGeom G{};
     if (mesh) G.m = mesh->dev;
     G.f = feat->dev; G.cal = cal; G.res = res; G.z0 = z0; G.pts = d_points; G.N = N; G.sdf_clip = sdf_clip; G.cmap_local = cmap_local;
-    G.near = reinterpret_cast<const int2 *>(work->d_near); G.code8 = work->d_code8; G.tile_offsets = work->d_block_offsets;
+    G.near_slot = work_near_slot(work); G.near_d2 = work_near_d2(work); G.code8 = work->d_code8; G.tile_offsets = work->d_block_offsets;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;
     if (fs.mode == kSignSeg) {

@@ -699,6 +699,20 @@ __device__ __forceinline__ uint32_t in_cube_bit(f3 p)
     return in ? kCodeInCube : 0u;
 }
 
+// the 1-byte code of a point (icon prior): in_cube, inside (check_sign), and for |sdf| >= sdf_clip the outlier
+// flag with sign(sdf) + 1 (lib/net/HGPIFuNet.py:298-299); sdf = +-sqrt(d^2)/sqrt(3) exactly as sdf_attrs forms it
+__device__ __forceinline__ uint32_t sign_code(f3 p, float d2, bool ins, float sdf_clip)
+{
+    const float dist = sqrtf(d2) / sqrtf(3.0f);      // mesh_util.py:391
+    const float s = ins ? dist : -dist;              // :393-394
+    uint32_t code = in_cube_bit(p) | (ins ? kCodeInside : 0u);
+    if (fabsf(s) >= sdf_clip) {
+        const int sg = (s > 0.0f) ? 1 : ((s < 0.0f) ? -1 : 0);
+        code |= kCodeOutlier | ((uint32_t)(sg + 1) << kCodeSignShift);
+    }
+    return code;
+}
+
 __device__ __forceinline__ void store_row(float *X, int64_t i, const float *row)
 {
     float4 *dst = reinterpret_cast<float4 *>(X + i * kXRow);

@@ -49,15 +49,15 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
 }
 
 // point mode, one wavefront per point (see nearest_coop)
-__global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, int2 *__restrict__ near,
-                                                                 int cap)
+__global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N,
+                                                                 int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int cap)
 {
     extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
-    if ((threadIdx.x & 63) == 0) near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
+    if ((threadIdx.x & 63) == 0) { near_slot[i] = nr.slot; near_d2[i] = nr.d2; }
 }
 
 __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, const float *__restrict__ pts, int64_t N,
@@ -80,12 +80,14 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
     if (inside_out) inside_out[i] = ins ? 1 : 0;
 }
 
-// Nearest-triangle search as its own launch: the packet traversal needs ~36 VGPRs, so it runs at
+// Nearest-triangle search as its own launch: the packet traversal needs ~50 VGPRs, so it runs at
 // full occupancy (8 waves / SIMD hide the dependent scalar-load chain), which the register-heavier
-// attribute / gather code below would cap at 5.  Output: (slot, bits of d^2) per point, 8 B.
+// attribute / gather code would cap at 5.  Output per point, structure of arrays: the slot of the nearest
+// triangle and its squared distance (k_sign reads only the latter, the fused kernel only the former except
+// inside the clip band).
 template <bool LATTICE>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
-                                                    int2 *__restrict__ near, const int32_t *__restrict__ perm)
+                                                    int32_t *__restrict__ near_slot, float *__restrict__ near_d2, const int32_t *__restrict__ perm)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     }
     const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
-    if (live) near[i] = make_int2(nr.slot, __float_as_int(nr.d2));
+    if (live) { near_slot[i] = nr.slot; near_d2[i] = nr.d2; }
 }
 
 // Feature assembly: one 16-float row per point,
@@ -115,19 +117,17 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
                                                      const float *__restrict__ pts, int64_t N,
                                                      float sdf_clip, int cmap_local,
                                                      const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                                     const int2 *__restrict__ near, float *__restrict__ X,
-                                                     uint8_t *__restrict__ code8)
+                                                     const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2,
+                                                     float *__restrict__ X, uint8_t *__restrict__ code8)
 {
     __shared__ int lds[(PRIOR == ICON_PRIOR_ICON && BRUTE) ? kBruteTile * 24 : 1];
     int64_t i; bool live; f3 p;
-    int64_t yz_row = 0;
     if (LATTICE) {
         int ix, iy, iz;
         live = lattice_point(L, ix, iy, iz);
         const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
         p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
-        yz_row = (int64_t)cz * L.res + cy;
     } else {
         i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         live = i < N;
@@ -141,19 +141,26 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
     if (PRIOR == ICON_PRIOR_ICON) {
         Nearest nr;
         bool ins;
-        if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
-        else {
-            const int2 nn = near[i];                       // k_nearest ran on the same stream just before
-            nr.slot = nn.x; nr.d2 = __int_as_float(nn.y); nr.face = 0;
-            ins = LATTICE ? inside_row(m, p, row_count, row_slots, yz_row) : inside_bins(m, p);
+        float s;
+        f3 cmv;
+        SdfOut o;
+        if (BRUTE) {
+            nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p);
+            o = sdf_attrs(m, p, nr, ins);
+            code = sign_code(p, nr.d2, ins, sdf_clip);
+        } else {
+            // the geometry pre-pass ran on the same stream just before: slot of the nearest triangle, the code byte
+            // (outlier / sign / inside / in_cube) and, for points inside the clip band only, d^2
+            code = code8[i];
+            nr.slot = near_slot[i]; nr.face = 0;
+            nr.d2 = (code & kCodeOutlier) ? 0.0f : near_d2[i];
+            ins = (code & kCodeInside) != 0;
+            o = sdf_attrs(m, p, nr, ins);
         }
-        const SdfOut o = sdf_attrs(m, p, nr, ins);
-        float s = o.sdf;
-        f3 cmv = o.cm;
-        if (fabsf(s) >= sdf_clip) {            // HGPIFuNet.py:298-305
-            const int sg = (s > 0.0f) ? 1 : ((s < 0.0f) ? -1 : 0);
-            s = (float)sg;
-            code |= kCodeOutlier | ((uint32_t)(sg + 1) << kCodeSignShift);
+        s = o.sdf;
+        cmv = o.cm;
+        if (code & kCodeOutlier) {            // HGPIFuNet.py:298-305
+            s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
             if (cmap_local) cmv = mk3(s, s, s);   // reference mode: patched later from the sign list
         }
         float g[16];
@@ -621,7 +628,7 @@ int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int
 
 // geometry pre-pass of the icon prior (BVH search): per-row crossing lists (lattice), nearest triangle -> near
 template <bool LATTICE>
-int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N,
+int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, float sdf_clip,
                    icon_work *work, hipStream_t st)
 {
     if (LATTICE) {
@@ -639,7 +646,8 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    int2 *near = reinterpret_cast<int2 *>(work->d_near);
+    int32_t *near_slot = work_near_slot(work);
+    float *near_d2 = work_near_d2(work);
     // point mode: sparse batches walk the tree one wavefront per point; a batch dense enough for a wave's 64
     // Morton neighbours to be close together goes through the packet kernel
     const int32_t *perm = nullptr;
@@ -647,16 +655,16 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
         const int cap = coop_cap((int)mesh->stats[1]);
         hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
-                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near, cap);
+                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near_slot, near_d2, cap);
     } else {
         if (!LATTICE) {
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm);
+        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm);
     }
     ICON_HIP(hipGetLastError());
-    return ICON_OK;
+    return launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
 }
 
 // X rows + codes (the materialising path): k_features, reading `near` unless the search is brute force
@@ -672,8 +680,7 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     const MeshDev md = mesh ? mesh->dev : MeshDev{};
     const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
     const bool brute = (search == ICON_SEARCH_BRUTE);
-    const int2 *near = reinterpret_cast<const int2 *>(work->d_near);
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, near, work->d_x, work->d_code8)
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_x, work->d_code8)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
@@ -734,8 +741,7 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
         if ((rc = launch_features<LATTICE>(mesh, feat, prior, sdf_clip, cmap_mode, cal, L, d_points, N, search, work, st))) return rc;
         work->q_rows_ready = true;
     } else {
-        if ((rc = launch_nearest<LATTICE>(mesh, cal, L, d_points, N, work, st))) return rc;
-        if ((rc = launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st))) return rc;
+        if ((rc = launch_nearest<LATTICE>(mesh, cal, L, d_points, N, sdf_clip, work, st))) return rc;
     }
     if (work->slab_needs_patch) {
         int8_t *signs = d_signs_out ? d_signs_out : work->d_signs;
