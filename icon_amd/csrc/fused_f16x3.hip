@@ -74,13 +74,17 @@ struct FusedGeom {
 // k_nearest itself was measured: its registers (75 VGPRs / 106 SGPRs instead of 50 / 70) cost the traversal
 // two of its eight waves per SIMD, 4.48 vs 4.31 ms for the pre-pass - so it stays a separate 0.07 ms launch.
 // ---------------------------------------------------------------------------------------------
+static_assert(kScanBlock == 256, "k_sign's 256-point blocks are the blocks of the outlier scan and the tiles of the fused kernel");
 template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                              const float *__restrict__ near_d2, uint8_t *__restrict__ code8)
+                                              const float *__restrict__ near_d2, uint8_t *__restrict__ code8, int32_t *__restrict__ block_counts)
 {
+    __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    const bool live = i < N;
+    uint32_t code = 0;
+    if (live) {
     f3 p; bool ins;
     if (LATTICE) {
         const int64_t row = i / res;
@@ -91,7 +95,14 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
         ins = inside_bins(m, p);
     }
-    code8[i] = (uint8_t)sign_code(p, near_d2[i], ins, sdf_clip);
+    code = sign_code(p, near_d2[i], ins, sdf_clip);
+    code8[i] = (uint8_t)code;
+    }
+    // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
+    const unsigned long long b = __ballot(live && (code & kCodeOutlier));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -319,9 +330,9 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
     const int64_t nb = (N + 255) / 256;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, work_near_d2(work), work->d_code8);
+                                    work->d_row_count, work->d_row_slots, work_near_d2(work), work->d_code8, work->d_block_counts);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_d2(work), work->d_code8);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_d2(work), work->d_code8, work->d_block_counts);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }

@@ -105,6 +105,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     }
     const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+    // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
+    //  writes - 209 MB at HBM for 136 MB of results - but the block-wide barrier costs 0.14 ms; not kept)
     if (live) { near_slot[i] = nr.slot; near_d2[i] = nr.d2; }
 }
 
@@ -690,10 +692,11 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
 }
 
 // count + scan + compact over the codes of points [0, N): fills w->d_block_offsets, w->d_total, and `signs`
-int outlier_list(icon_work *w, int64_t N, int8_t *signs, hipStream_t st)
+int outlier_list(icon_work *w, int64_t N, int8_t *signs, bool counted, hipStream_t st)
 {
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
-    hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
+    // `counted`: k_sign already left the outlier count of every 256-point block in d_block_counts
+    if (!counted) hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
     const int64_t nchunks = (nblk + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total);
@@ -745,7 +748,7 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
     }
     if (work->slab_needs_patch) {
         int8_t *signs = d_signs_out ? d_signs_out : work->d_signs;
-        if ((rc = outlier_list(work, N, signs, st))) return rc;
+        if ((rc = outlier_list(work, N, signs, search != ICON_SEARCH_BRUTE, st))) return rc;
     }
     return ICON_OK;
 }
