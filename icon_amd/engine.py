@@ -434,6 +434,8 @@ class IconQueryEngine:
         if not points.is_cuda:
             raise IconAmdError("points are on the CPU; icon_amd has no CPU path")
         n = int(points.shape[2])
+        if n == 0:
+            return [torch.empty((1, 1, 0), dtype=torch.float32, device=points.device) for _ in features]
         if transforms is not None:
             # lib/net/geometry.py:57-60 indexes `transforms[:2, :2]` / `transforms[:2, 2:3]` and feeds the slices to
             # torch.baddbmm: for the documented [B,2,3] layout the shift slice is empty and for a [2,3] matrix the

@@ -846,3 +846,44 @@ def test_icon_nofilter_layout(body, precision):
     ref_l, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], feat,
                               orc.Mlp(sd), synth.lattice_points(res), sdf_clip=body.sdf_clip)
     assert np.abs(vol - ref_l).max() <= OCC_TOL
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: empty query, degenerate / tiny meshes (the oracle defines the behaviour; both sides agree)
+# ---------------------------------------------------------------------------------------------
+def test_empty_query_and_tiny_batches(body, eng_body):
+    feat = T(body.features)
+    eye = torch.eye(4, device=dev())[None]
+    out = eng_body.query([feat], torch.zeros((1, 3, 0), device=dev()), eye)
+    assert out[0].shape == (1, 1, 0)
+    for n in (1, 2, 5):
+        pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 64, seed=n)[:n]
+        occ = eng_body.query([feat], T(pts.T.copy())[None], eye)[0][0, 0].cpu().numpy()
+        ref, _ = oracle_query(body, pts)
+        assert np.abs(occ - ref).max() <= OCC_TOL
+
+
+def test_degenerate_and_tiny_meshes_match_the_oracle():
+    """zero-area triangles (repeated vertex, collinear corners), a duplicated face, a two-triangle open sheet: nearest
+    face / sdf / inside flag are whatever the linear-scan definitions of the checker say - bit for bit"""
+    from icon_amd.engine import MeshHandle
+    rng = np.random.RandomState(12)
+    v = np.array([[0, 0, 0], [0.5, 0, 0], [0, 0.5, 0], [0.5, 0.5, 0.1], [0.25, 0.25, 0.3], [0.25, 0.0, 0.0]], np.float32)
+    v += rng.normal(0, 1e-3, v.shape).astype(np.float32)
+    f = np.array([[0, 1, 2], [1, 3, 2], [0, 1, 1],       # repeated vertex
+                  [0, 5, 1],                              # nearly collinear sliver
+                  [1, 3, 2],                              # duplicate of face 1: ties -> lowest face index
+                  [2, 3, 4], [0, 2, 4]], np.int64)
+    cm = rng.rand(len(v), 3).astype(np.float32)
+    vis = (rng.rand(len(v)) > 0.5).astype(np.float32)
+    pts = rng.uniform(-0.4, 0.9, (4000, 3)).astype(np.float32)
+    ref = orc.cal_sdf(v, f, cm, vis, pts)
+    mesh = MeshHandle(T(v[None]), T(f[None]), T(cm[None]), T(vis[None, :, None]))
+    for search in ("bvh", "brute"):
+        got = mesh.sdf_query(T(pts), search=search)
+        assert np.array_equal(got["face"].cpu().numpy(), ref["idx"]), search
+        assert np.array_equal(got["inside"].cpu().numpy(), ref["inside"]), search
+        assert np.array_equal(got["sdf"].cpu().numpy().view(np.int32), ref["sdf"].view(np.int32)), search
+        assert np.array_equal(got["vis"].cpu().numpy(), ref["vis"]), search
+        ok = np.isfinite(ref["norm"]).all(1)
+        assert np.abs(got["norm"].cpu().numpy()[ok] - ref["norm"][ok]).max() <= 1e-5
