@@ -100,3 +100,49 @@ def test_reference_transforms_branch_is_dead_code(ref):
     from common import ROOT
     src = open(os.path.join(ROOT, "icon_amd", "engine.py")).read()
     assert "transforms is not None" in src and "is not supported" in src
+
+
+def test_reference_voxelization_wrapper_around_the_leaf(ref, monkeypatch):
+    """lib/net/voxelize.py:64-137 run verbatim on CPU around a stub of the missing voxelize_cuda leaf: pins what
+    the reference hands to the leaf (surface vertices = the first len(vertex_code) of voxel_verts, tetrahedra as
+    gathered POSITIONS [B,T,4,3], sigma), that the padding is stripped before (HGPIFuNet.py:316-319), and the
+    (b,z,y,x,c) -> (b,c,d,h,w) permutation - i.e. that icon_amd.engine.semantic_voxelization(voxel_verts,
+    voxel_tets, vertex_code) is fed and laid out like Voxelization.forward.  The leaf's arithmetic stays
+    PARITY UNPINNED (restated in oracle/icon_accel.c)."""
+    import sys
+    vox_mod = __import__("lib.net.voxelize", fromlist=["Voxelization"])
+    a = assets("ico")
+    vv, tets, code = synth.make_tetra_body(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0])
+    res, sigma, seen = 16, 0.05, {}
+
+    def leaf(verts, vcode, tet_pos, occ, sem, wsum, sg):
+        seen.update(verts=verts.numpy().copy(), code=vcode.numpy().copy(), tet_pos=tet_pos.numpy().copy(), sigma=sg,
+                    shapes=(tuple(occ.shape), tuple(sem.shape), tuple(wsum.shape)), wsum0=float(wsum.flatten()[0]))
+        ns = verts.shape[1]
+        allv = np.concatenate([verts[0].numpy(), tet_pos[0].numpy().reshape(-1, 3)])
+        t = ns + np.arange(tet_pos.shape[1] * 4, dtype=np.int64).reshape(-1, 4)
+        out = orc.semantic_voxelize(allv, ns, vcode[0].numpy(), t, res=sem.shape[1], sigma=sg)
+        return occ, torch.from_numpy(out)[None], wsum
+
+    monkeypatch.setattr(sys.modules["voxelize_cuda"], "forward_semantic_voxelization", leaf, raising=False)
+    monkeypatch.setattr(torch.cuda, "FloatTensor", torch.FloatTensor)
+    monkeypatch.setattr(vox_mod.Voxelization, "check_input", lambda self, x: None)         # "supports only cuda tensors"
+    faces = a.smpl_faces[0].astype(np.int32)
+    vox = vox_mod.Voxelization(code, code[faces].mean(1), faces, tets.astype(np.int32), volume_res=res, sigma=sigma,
+                               smooth_kernel_size=7, batch_size=1, device=torch.device("cpu"))
+    # the dataset pads voxel_verts / voxel_faces (TestDataset.py:165-170); query() strips it (HGPIFuNet.py:316-319)
+    pad_v, pad_f = 5, 3
+    voxel_verts = T(np.concatenate([vv, np.zeros((pad_v, 3), np.float32)]))[None]
+    voxel_faces = T(np.concatenate([tets, np.zeros((pad_f, 4), np.int64)]).astype(np.int32))[None]
+    vs, fs = voxel_verts[:, :-pad_v, :], voxel_faces[:, :-pad_f, :]
+    vox.update_param(batch_size=fs.shape[0], smpl_tetra=fs[0].detach().cpu().numpy())
+    vol = vox(vs)
+    assert vol.shape == (1, 3, res, res, res)
+    assert seen["shapes"] == ((1, res, res, res), (1, res, res, res, 3), (1, res, res, res)) and abs(seen["wsum0"] - 1e-3) < 1e-9
+    assert seen["sigma"] == sigma
+    assert np.array_equal(seen["verts"][0], vv[: len(code)]) and np.array_equal(seen["code"][0], code)
+    assert np.array_equal(seen["tet_pos"][0], vv[tets])
+    # what our host function computes from (voxel_verts, voxel_tets, vertex_code), checker standing in for the HIP kernel
+    mine = orc.semantic_voxelize(vv, len(code), code, tets, res=res, sigma=sigma)
+    assert np.array_equal(vol[0].permute(1, 2, 3, 0).numpy(), mine)
+    assert mine.any()
