@@ -887,3 +887,62 @@ def test_degenerate_and_tiny_meshes_match_the_oracle():
         assert np.array_equal(got["vis"].cpu().numpy(), ref["vis"]), search
         ok = np.isfinite(ref["norm"]).all(1)
         assert np.abs(got["norm"].cpu().numpy()[ok] - ref["norm"][ok]).max() <= 1e-5
+
+
+def test_lattice_rows_with_more_crossings_than_the_row_list_holds(body):
+    """12 concentric shells: the lattice rows through the middle are covered by 24 triangles, more than the
+    per-row crossing list of the lattice kernels holds (kRowCap = 16, geom_device.h) - those rows take the
+    (y,z)-bin scan instead; inside / outside alternates from shell to shell.  Lattice == checker, and the lattice
+    kernel == the explicit-point path (which never uses row lists) bit for bit."""
+    from types import SimpleNamespace
+    v0, f0 = synth.icosphere(1)
+    v0 = v0 / np.linalg.norm(v0, axis=1, keepdims=True)
+    rng = np.random.RandomState(5)
+    vs, fs = [], []
+    for k in range(12):
+        rot = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+        vs.append((v0 @ rot.T) * (0.12 + 0.065 * k) + rng.normal(0, 1e-3, 3))
+        fs.append(f0 + k * len(v0))
+    verts, faces = np.concatenate(vs).astype(np.float32), np.concatenate(fs).astype(np.int64)
+    vis, cmap = synth.make_vis_cmap(verts, faces)
+    a = SimpleNamespace(**vars(body))
+    a.smpl_verts, a.smpl_faces, a.smpl_vis, a.smpl_cmap = verts[None], faces[None], vis[None], cmap[None]
+    res = 33
+    pts = synth.lattice_points(res)
+    # triangles whose (y,z) projection covers the row y = z = 0 (float64 edge functions)
+    t = verts[faces][:, :, 1:].astype(np.float64)
+    e = [t[:, i, 0] * t[:, (i + 1) % 3, 1] - t[:, i, 1] * t[:, (i + 1) % 3, 0] for i in range(3)]
+    assert int(((np.sign(e[0]) == np.sign(e[1])) & (np.sign(e[1]) == np.sign(e[2]))).sum()) == 24
+    eng = make_engine(a)
+    occ = eng.eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
+    ref, _ = oracle_query(a, pts)
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    q = eng.query([T(a.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    assert np.array_equal(q, occ)
+
+
+def test_smplx_size_mesh(body):
+    """A body with SMPL-X's size (V = 10,242 / F = 20,480 here; SMPL-X: 10,475 / 20,908 - SURVEY.md section 8d): deeper BVH,
+    more leaves, larger ray bins.  Nearest face / inside / sdf bit-exact, lattice occupancy <= 1e-4."""
+    from types import SimpleNamespace
+    from icon_amd.engine import MeshHandle
+    v, f = synth.icosphere(5)
+    v = v / np.linalg.norm(v, axis=1, keepdims=True)
+    rng = np.random.RandomState(31)
+    bump = 1.0 + 0.15 * np.sin(5 * v[:, :1]) * np.cos(4 * v[:, 1:2]) + 0.1 * np.sin(7 * v[:, 2:3])
+    verts = (v * bump * np.array([0.4, 0.85, 0.3]) + rng.normal(0, 2e-4, v.shape)).astype(np.float32)
+    faces = f.astype(np.int64)
+    vis, cmap = synth.make_vis_cmap(verts, faces)
+    pts = synth.stratified_points(verts, faces, 6000, seed=3)
+    ref = orc.cal_sdf(verts, faces, cmap, vis[:, 0], pts)
+    mesh = MeshHandle(T(verts[None]), T(faces[None]), T(cmap[None]), T(vis[None]))
+    got = mesh.sdf_query(T(pts))
+    assert np.array_equal(got["face"].cpu().numpy(), ref["idx"])
+    assert np.array_equal(got["inside"].cpu().numpy(), ref["inside"])
+    assert np.array_equal(got["sdf"].cpu().numpy().view(np.int32), ref["sdf"].view(np.int32))
+    a = SimpleNamespace(**vars(body))
+    a.smpl_verts, a.smpl_faces, a.smpl_vis, a.smpl_cmap = verts[None], faces[None], vis[None], cmap[None]
+    res = 49
+    occ = make_engine(a).eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
+    ref_occ, _ = oracle_query(a, synth.lattice_points(res))
+    assert np.abs(occ - ref_occ).max() <= OCC_TOL
