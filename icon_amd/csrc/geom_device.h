@@ -110,15 +110,20 @@ __device__ __forceinline__ f2 tri_dist2_pair(f3 p1, cf2 *q)
     const f2 s = fma2(a11, d1, -(a01 * d2)) * inn;
     const f2 u = fma2(a00, d2, -(a01 * d1)) * inn;
     const f2 su = s + u;
-    f3x2 qf; qf.x = fma2(ac.x, u, fma2(ab.x, s, a.x)); qf.y = fma2(ac.y, u, fma2(ab.y, s, a.y)); qf.z = fma2(ac.z, u, fma2(ab.z, s, a.z));
-    const f3x2 df = sub3x2(p, qf);
-    f2 d_face = dot3x2(df, df);
+    const bool in0 = (s.x >= 0.0f) & (u.x >= 0.0f) & (su.x <= 1.0f);
+    const bool in1 = (s.y >= 0.0f) & (u.y >= 0.0f) & (su.y <= 1.0f);
+    // the face distance is selected only where the projection falls inside the triangle: for most of a packet's
+    // candidates no lane's does, and the wave skips it (same selected bits either way)
+    f2 d_face = bc2(0.0f);
+    if (__any(in0 | in1)) {
+        f3x2 qf; qf.x = fma2(ac.x, u, fma2(ab.x, s, a.x)); qf.y = fma2(ac.y, u, fma2(ab.y, s, a.y)); qf.z = fma2(ac.z, u, fma2(ab.z, s, a.z));
+        const f3x2 df = sub3x2(p, qf);
+        d_face = dot3x2(df, df);
+    }
     const f2 e0 = seg_dist2x2(p, a, ab, d1, i00);
     const f2 e1 = seg_dist2x2(p, a, ac, d2, i11);
     const f2 e2 = seg_dist2x2(p, b, bc, d3, ibc);
     f2 d_edge; d_edge.x = fminf(fminf(e0.x, e1.x), e2.x); d_edge.y = fminf(fminf(e0.y, e1.y), e2.y);
-    const bool in0 = (s.x >= 0.0f) & (u.x >= 0.0f) & (su.x <= 1.0f);
-    const bool in1 = (s.y >= 0.0f) & (u.y >= 0.0f) & (su.y <= 1.0f);
     float f0 = d_face.x, f1 = d_face.y, g0 = d_edge.x, g1 = d_edge.y;
     asm volatile("" : "+v"(f0), "+v"(f1), "+v"(g0), "+v"(g1));
     f2 r; r.x = in0 ? f0 : g0; r.y = in1 ? f1 : g1;
@@ -209,12 +214,14 @@ __device__ __forceinline__ f2 box_dist2_pair(cf2 *q, f3 p)
 struct Nearest { float d2; int slot; int face; };
 
 // Pruning bound: a subtree may be skipped only if no triangle in it can tie or beat `best`.
-// Computed distances carry < 1e-6 absolute error (coordinates are O(1)), so the bound is
-// (sqrt(best) + 4e-6)^2 with a relative cushion; see DESIGN.md "BVH conservativeness".
+// Computed distances carry < 1e-6 absolute error (coordinates are O(1)), so the bound must be at least
+// (sqrt(best) + 4e-6)^2 (1 + 1e-6); see DESIGN.md "BVH conservativeness".  Evaluated without the square
+// root (an IEEE sqrtf is ~25 instructions, once per visited leaf): 2 sqrt(b) <= b / c + c for any c > 0, with
+// c = 0.05: (sqrt(b) + e)^2 <= b (1 + 20 e) + 0.05 e + e^2 - looser by < 1e-4 relative, which changes nothing
+// measurable in the candidate sets and nothing at all in the result.
 __device__ __forceinline__ float prune_threshold(float best)
 {
-    const float s = sqrtf(best) + 4e-6f;
-    return s * s * 1.000001f;
+    return fmaf(best, 1.000083f, 2.1e-7f);
 }
 
 // BVH2 PACKET traversal: the 64 lanes of a wavefront descend the tree TOGETHER.  Control flow, the
