@@ -33,18 +33,19 @@ __device__ __forceinline__ f3 cross3(f3 a, f3 b)
 // S2: exact point-triangle squared distance, "face or nearest edge" form on per-triangle constants
 // prepared by the host (TriPre).  Same operations on the same operands as the checker's
 // orc_tri_dist2, hence bit-identical results; no division, no branches:
-//   (s,t) = barycentrics of the plane projection; inside -> |p - (a + s ab + t ac)|^2,
-//   else min over the three segments of |p - (origin + clamp(t,0,1) * edge)|^2.
+//   (s,t) = barycentrics of the plane projection; inside -> |(p - a) - s ab - t ac|^2,
+//   else min over the three segments of |(p - origin) - clamp(t,0,1) * edge|^2  (fma chains on the rounded
+//   p - origin: one fma per axis and term, and the rounding happens at the triangle's scale).
 struct TriC {   // TriPre fields as values (SGPRs when read through the constant address space)
     f3 a, b, ab, ac, bc;
     float i00, i11, ibc, a00, a01, a11, inn;
 };
 
-__device__ __forceinline__ float seg_dist2(f3 p, f3 o, f3 e, float dot_e_po, float inv_len2)
+__device__ __forceinline__ float seg_dist2(f3 po, f3 e, float dot_e_po, float inv_len2)
 {
+    // po = p - origin; residual (p - o) - t e as one fma per axis (spec S2)
     const float t = fminf(fmaxf(dot_e_po * inv_len2, 0.0f), 1.0f);
-    const f3 q = mk3(fmaf(e.x, t, o.x), fmaf(e.y, t, o.y), fmaf(e.z, t, o.z));
-    const f3 d = sub3(p, q);
+    const f3 d = mk3(fmaf(-t, e.x, po.x), fmaf(-t, e.y, po.y), fmaf(-t, e.z, po.z));
     return dot3(d, d);
 }
 
@@ -55,13 +56,12 @@ __device__ __forceinline__ float tri_dist2(f3 p, const TriC &t)
     const float s = fmaf(t.a11, d1, -(t.a01 * d2)) * t.inn;
     const float u = fmaf(t.a00, d2, -(t.a01 * d1)) * t.inn;
     const bool inside = (s >= 0.0f) & (u >= 0.0f) & (s + u <= 1.0f);
-    const f3 q = mk3(fmaf(t.ac.x, u, fmaf(t.ab.x, s, t.a.x)), fmaf(t.ac.y, u, fmaf(t.ab.y, s, t.a.y)),
-                     fmaf(t.ac.z, u, fmaf(t.ab.z, s, t.a.z)));
-    const f3 df = sub3(p, q);
+    const f3 df = mk3(fmaf(-u, t.ac.x, fmaf(-s, t.ab.x, ap.x)), fmaf(-u, t.ac.y, fmaf(-s, t.ab.y, ap.y)),
+                      fmaf(-u, t.ac.z, fmaf(-s, t.ab.z, ap.z)));
     float d_face = dot3(df, df);
-    const float e0 = seg_dist2(p, t.a, t.ab, d1, t.i00);
-    const float e1 = seg_dist2(p, t.a, t.ac, d2, t.i11);
-    const float e2 = seg_dist2(p, t.b, t.bc, d3, t.ibc);
+    const float e0 = seg_dist2(ap, t.ab, d1, t.i00);
+    const float e1 = seg_dist2(ap, t.ac, d2, t.i11);
+    const float e2 = seg_dist2(bp, t.bc, d3, t.ibc);
     float d_edge = fminf(fminf(e0, e1), e2);
     asm volatile("" : "+v"(d_face), "+v"(d_edge));    // keep the final choice a v_cndmask
     return inside ? d_face : d_edge;
@@ -89,11 +89,10 @@ __device__ __forceinline__ f2 clamp01x2(f2 v)
 {
     f2 r; r.x = fminf(fmaxf(v.x, 0.0f), 1.0f); r.y = fminf(fmaxf(v.y, 0.0f), 1.0f); return r;
 }
-__device__ __forceinline__ f2 seg_dist2x2(f3x2 p, f3x2 o, f3x2 e, f2 dot_e_po, f2 inv_len2)
+__device__ __forceinline__ f2 seg_dist2x2(f3x2 po, f3x2 e, f2 dot_e_po, f2 inv_len2)
 {
-    const f2 t = clamp01x2(dot_e_po * inv_len2);
-    f3x2 q; q.x = fma2(e.x, t, o.x); q.y = fma2(e.y, t, o.y); q.z = fma2(e.z, t, o.z);
-    const f3x2 d = sub3x2(p, q);
+    const f2 nt = -clamp01x2(dot_e_po * inv_len2);
+    f3x2 d; d.x = fma2(nt, e.x, po.x); d.y = fma2(nt, e.y, po.y); d.z = fma2(nt, e.z, po.z);
     return dot3x2(d, d);
 }
 
@@ -116,13 +115,13 @@ __device__ __forceinline__ f2 tri_dist2_pair(f3 p1, cf2 *q)
     // candidates no lane's does, and the wave skips it (same selected bits either way)
     f2 d_face = bc2(0.0f);
     if (__any(in0 | in1)) {
-        f3x2 qf; qf.x = fma2(ac.x, u, fma2(ab.x, s, a.x)); qf.y = fma2(ac.y, u, fma2(ab.y, s, a.y)); qf.z = fma2(ac.z, u, fma2(ab.z, s, a.z));
-        const f3x2 df = sub3x2(p, qf);
+        const f2 ns = -s, nu = -u;
+        f3x2 df; df.x = fma2(nu, ac.x, fma2(ns, ab.x, ap.x)); df.y = fma2(nu, ac.y, fma2(ns, ab.y, ap.y)); df.z = fma2(nu, ac.z, fma2(ns, ab.z, ap.z));
         d_face = dot3x2(df, df);
     }
-    const f2 e0 = seg_dist2x2(p, a, ab, d1, i00);
-    const f2 e1 = seg_dist2x2(p, a, ac, d2, i11);
-    const f2 e2 = seg_dist2x2(p, b, bc, d3, ibc);
+    const f2 e0 = seg_dist2x2(ap, ab, d1, i00);
+    const f2 e1 = seg_dist2x2(ap, ac, d2, i11);
+    const f2 e2 = seg_dist2x2(bp, bc, d3, ibc);
     f2 d_edge; d_edge.x = fminf(fminf(e0.x, e1.x), e2.x); d_edge.y = fminf(fminf(e0.y, e1.y), e2.y);
     float f0 = d_face.x, f1 = d_face.y, g0 = d_edge.x, g1 = d_edge.y;
     asm volatile("" : "+v"(f0), "+v"(f1), "+v"(g0), "+v"(g1));

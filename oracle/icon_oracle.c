@@ -113,8 +113,8 @@ void orc_vertex_normals(const float *verts, int64_t V, const int64_t *faces, int
  *     the Gram matrix of (ab, ac) and the reciprocal of its determinant; zero-length / zero-area
  *     cases get a reciprocal of 0 (the formulas below then collapse to a vertex / an edge).
  *     Per point: barycentrics of the plane projection (s, t); if 0 <= s, 0 <= t, s + t <= 1 the
- *     result is |p - (a + s ab + t ac)|^2, otherwise the minimum over the three edge segments
- *     of |p - (origin + clamp(t) * edge)|^2.  No division, no data-dependent branches: on the GPU
+ *     result is |(p - a) - s ab - t ac|^2, otherwise the minimum over the three edge segments
+ *     of |(p - origin) - clamp(t) * edge|^2 (fma chains starting from the rounded p - origin).  No division, no data-dependent branches: on the GPU
  *     this is ~70 VALU operations (sub / mul / fma / max / min / select), all exactly rounded.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -143,11 +143,12 @@ void orc_tri_setup(const float *pa, const float *pb, const float *pc, orc_tri *t
 static inline float max_f(float a, float b) { return (a > b) ? a : b; }
 static inline float min_f(float a, float b) { return (b < a) ? b : a; }
 
-static inline float seg_dist2(v3 p, v3 o, v3 e, float dot_e_po, float inv_len2)
+static inline float seg_dist2(v3 po, v3 e, float dot_e_po, float inv_len2)
 {
+    /* po = p - origin; the residual is formed from it, (p - o) - t e, not as p - (o + t e): one rounding at the
+     * scale of the triangle instead of one at the scale of the coordinates */
     const float t = min_f(max_f(dot_e_po * inv_len2, 0.0f), 1.0f);
-    v3 q; q.x = fmaf(e.x, t, o.x); q.y = fmaf(e.y, t, o.y); q.z = fmaf(e.z, t, o.z);
-    const v3 d = v3_sub(p, q);
+    v3 d; d.x = fmaf(-t, e.x, po.x); d.y = fmaf(-t, e.y, po.y); d.z = fmaf(-t, e.z, po.z);
     return v3_dot(d, d);
 }
 
@@ -159,15 +160,14 @@ float orc_tri_dist2(const float *pp, const orc_tri *t)
     const float s = fmaf(t->a11, d1, -(t->a01 * d2)) * t->inn;
     const float u = fmaf(t->a00, d2, -(t->a01 * d1)) * t->inn;
     const int inside = (s >= 0.0f) & (u >= 0.0f) & (s + u <= 1.0f);
-    v3 q;
-    q.x = fmaf(t->ac.x, u, fmaf(t->ab.x, s, t->a.x));
-    q.y = fmaf(t->ac.y, u, fmaf(t->ab.y, s, t->a.y));
-    q.z = fmaf(t->ac.z, u, fmaf(t->ab.z, s, t->a.z));
-    const v3 df = v3_sub(p, q);
+    v3 df;
+    df.x = fmaf(-u, t->ac.x, fmaf(-s, t->ab.x, ap.x));
+    df.y = fmaf(-u, t->ac.y, fmaf(-s, t->ab.y, ap.y));
+    df.z = fmaf(-u, t->ac.z, fmaf(-s, t->ab.z, ap.z));
     const float d_face = v3_dot(df, df);
-    const float e0 = seg_dist2(p, t->a, t->ab, d1, t->i00);
-    const float e1 = seg_dist2(p, t->a, t->ac, d2, t->i11);
-    const float e2 = seg_dist2(p, t->b, t->bc, d3, t->ibc);
+    const float e0 = seg_dist2(ap, t->ab, d1, t->i00);
+    const float e1 = seg_dist2(ap, t->ac, d2, t->i11);
+    const float e2 = seg_dist2(bp, t->bc, d3, t->ibc);
     const float d_edge = min_f(min_f(e0, e1), e2);
     return inside ? d_face : d_edge;
 }
