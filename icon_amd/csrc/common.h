@@ -98,6 +98,7 @@ struct MeshDev {
     const TriRec *tris;
     const TriAttr *attr;
     const int32_t *slot2face;
+    const int32_t *face2slot;   // [faces] the (real) slot holding face f: the packet traversal tracks (d^2, face) only
     const LeafRec *leaves;
     int32_t n_tris;             // triangle slots = 4 * leaves (incl. padding copies)
     int32_t root_is_leaf;
@@ -154,6 +155,7 @@ struct icon_mesh {
     icon::TriRec *d_tris = nullptr;
     icon::TriAttr *d_attr = nullptr;
     int32_t *d_slot2face = nullptr;
+    int32_t *d_face2slot = nullptr;
     icon::LeafRec *d_leaves = nullptr;
     int32_t *d_bin_start = nullptr;
     int32_t *d_bin_slots = nullptr;

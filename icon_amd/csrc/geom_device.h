@@ -91,7 +91,11 @@ __device__ __forceinline__ f2 clamp01x2(f2 v)
 }
 __device__ __forceinline__ f2 seg_dist2x2(f3x2 po, f3x2 e, f2 dot_e_po, f2 inv_len2)
 {
-    const f2 nt = -clamp01x2(dot_e_po * inv_len2);
+    // t = clamp(dot * inv, 0, 1): the packed multiply carries the clamp itself (the compiler emits a v_max ... clamp
+    // per component after it); NaN -> 0 like fminf(fmaxf(x, 0), 1)
+    f2 t;
+    asm("v_pk_mul_f32 %0, %1, %2 clamp" : "=v"(t) : "v"(dot_e_po), "s"(inv_len2));
+    const f2 nt = -t;
     f3x2 d; d.x = fma2(nt, e.x, po.x); d.y = fma2(nt, e.y, po.y); d.z = fma2(nt, e.z, po.z);
     return dot3x2(d, d);
 }
@@ -236,7 +240,6 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
     unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
-    int slot = 0;
     float thr = live ? thr0 : -INFINITY;
     int sp = 0;
     int cur = 0;
@@ -255,10 +258,9 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
                 // above +inf) never wins; a padding copy has the same key as its original.
                 const unsigned long long k0 = ((unsigned long long)(unsigned)__float_as_int(d2.x) << 32) | (unsigned)__float_as_int(fc.x);
                 const unsigned long long k1 = ((unsigned long long)(unsigned)__float_as_int(d2.y) << 32) | (unsigned)__float_as_int(fc.y);
-                const bool u0 = live & (k0 < key);
-                key = u0 ? k0 : key; slot = u0 ? leaf * kLeafMax + 2 * pr : slot;
-                const bool u1 = live & (k1 < key);
-                key = u1 ? k1 : key; slot = u1 ? leaf * kLeafMax + 2 * pr + 1 : slot;
+                // (the winner's slot is looked up from its face id at the end: nothing else to carry per test)
+                key = (live & (k0 < key)) ? k0 : key;
+                key = (live & (k1 < key)) ? k1 : key;
             }
             const bool improved = key != before;
             nr.d2 = __int_as_float((int)(key >> 32));
@@ -288,7 +290,8 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
             }
         }
     }
-    nr.d2 = __int_as_float((int)(key >> 32)); nr.slot = slot; nr.face = (int)(key & 0xffffffffu);
+    nr.d2 = __int_as_float((int)(key >> 32)); nr.face = (int)(key & 0xffffffffu);
+    nr.slot = (nr.face != 0x7fffffff) ? m.face2slot[nr.face] : 0;
     return nr;
 }
 

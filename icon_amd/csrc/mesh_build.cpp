@@ -384,6 +384,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     std::vector<TriRec> tris(S);
     std::vector<TriAttr> attr(S);
     std::vector<int32_t> slot2face(S);
+    std::vector<int32_t> face2slot(std::max<int64_t>(F, 1), 0);
     std::vector<LeafRec> leafrec(n_leaves);
     std::vector<int64_t> slot_src(S, -1);          // real slots: index into bd.order; padding: -1
     for (int64_t L = 0; L < n_leaves; ++L) {
@@ -402,7 +403,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
             for (int c = 0; c < 3; ++c) a.vis[c] = vis[id[c]];
             a.face = (int32_t)f; a.pad[0] = a.pad[1] = 0;
             slot2face[s] = (int32_t)f;
-            if (real) slot_src[s] = begin + t;
+            if (real) { slot_src[s] = begin + t; face2slot[f] = (int32_t)s; }
             TriPre pre;
             tri_setup(tr.a, tr.b, tr.c, (int32_t)f, pre);
             const float *src = reinterpret_cast<const float *>(&pre);
@@ -453,7 +454,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     int rc;
     if ((rc = upload(&m->d_vnormals, vn, st)) || (rc = upload(&m->d_nodes, bd.nodes, st)) ||
         (rc = upload(&m->d_tris, tris, st)) || (rc = upload(&m->d_attr, attr, st)) ||
-        (rc = upload(&m->d_slot2face, slot2face, st)) || (rc = upload(&m->d_leaves, leafrec, st)) ||
+        (rc = upload(&m->d_slot2face, slot2face, st)) || (rc = upload(&m->d_face2slot, face2slot, st)) || (rc = upload(&m->d_leaves, leafrec, st)) ||
         (rc = upload(&m->d_bin_start, bin_start, st)) ||
         (rc = upload(&m->d_bin_slots, bin_slots, st))) {
         icon_mesh_destroy(m);
@@ -461,7 +462,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     }
     ICON_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
     MeshDev &d = m->dev;
-    d.nodes = m->d_nodes; d.tris = m->d_tris; d.attr = m->d_attr; d.slot2face = m->d_slot2face;
+    d.nodes = m->d_nodes; d.tris = m->d_tris; d.attr = m->d_attr; d.slot2face = m->d_slot2face; d.face2slot = m->d_face2slot;
     d.leaves = m->d_leaves;
     d.n_tris = (int32_t)S; d.root_is_leaf = root_is_leaf;
     d.bin_start = m->d_bin_start; d.bin_slots = m->d_bin_slots;
@@ -481,7 +482,7 @@ extern "C" int icon_mesh_destroy(icon_mesh_t *m)
 {
     if (!m) return ICON_OK;
     (void)hipFree(m->d_vnormals); (void)hipFree(m->d_nodes); (void)hipFree(m->d_tris); (void)hipFree(m->d_attr);
-    (void)hipFree(m->d_slot2face); (void)hipFree(m->d_bin_start); (void)hipFree(m->d_bin_slots); (void)hipFree(m->d_leaves);
+    (void)hipFree(m->d_slot2face); (void)hipFree(m->d_face2slot); (void)hipFree(m->d_bin_start); (void)hipFree(m->d_bin_slots); (void)hipFree(m->d_leaves);
     delete m;
     return ICON_OK;
 }
