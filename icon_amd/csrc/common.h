@@ -130,7 +130,7 @@ struct Lattice {
 struct LatticeMap {
     int res, z0, nz;           // evaluated planes [z0, z0+nz)
     int tx, ty, tz;            // tile counts
-    int remap;                 // 1: contiguous run of tiles per XCD, 0: tiles interleaved over XCDs
+    int remap;                 // 0: single tiles alternate over the XCDs (default), 2: x-rows of tiles, 1: contiguous run of tiles per XCD
 };
 
 // where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)

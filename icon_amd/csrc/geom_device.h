@@ -661,7 +661,18 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
 __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
 {
     const int nb = L.tx * L.ty * L.tz;
-    const int t = L.remap ? xcd_remap(blockIdx.x, nb) : (int)blockIdx.x;
+    int t = (int)blockIdx.x;
+    if (L.remap == 1) t = xcd_remap(t, nb);
+    else if (L.remap == 2) {
+        // the tx workgroups of one (y,z) block row on ONE XCD (block b runs on XCD b % 8): the row's results are
+        // contiguous in memory, and the 64-byte pieces of a 128-byte line written by x-neighbours then meet in the
+        // same L2 instead of leaving two XCDs as partial lines.  Rows still alternate over the XCDs (balance).
+        const int full = (nb / (8 * L.tx)) * (8 * L.tx);
+        if (t < full) {
+            const int r8 = t & 7, k = t >> 3;
+            t = ((k / L.tx) * 8 + r8) * L.tx + (k % L.tx);
+        }
+    }
     const int bty = t / (L.tz * L.tx);
     const int rem = t - bty * (L.tz * L.tx);
     const int btz = rem / L.tx, btx = rem - btz * L.tx;

@@ -864,7 +864,9 @@ static int lattice_map(int res, int z0, int z1, LatticeMap *L)
     L->res = res; L->z0 = z0; L->nz = z1 - z0;
     L->tx = (res + 15) / 16; L->ty = (res + 3) / 4; L->tz = (L->nz + 3) / 4;
     const char *e = getenv("ICON_AMD_XCD_REMAP");
-    L->remap = e ? atoi(e) : 0;   // interleaved is balanced; contiguous XCD bands measured 1.6x slower
+    // 0: single blocks alternate over the XCDs (default, fastest); 2: whole x-rows of blocks per XCD - 14 % fewer HBM
+    // write bytes (partial lines meet in one L2) but 1.5 % slower; 1: contiguous XCD bands, 1.6x slower
+    L->remap = e ? atoi(e) : 0;
     return ICON_OK;
 }
 
