@@ -78,7 +78,8 @@ static_assert(kScanBlock == 256, "k_sign's 256-point blocks are the blocks of th
 template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                              const float *__restrict__ near_d2, uint8_t *__restrict__ code8, int32_t *__restrict__ block_counts)
+                                              const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2, uint8_t *__restrict__ code8,
+                                              int32_t *__restrict__ block_counts)
 {
     __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
         ins = inside_bins(m, p);
     }
-    code = sign_code(p, near_d2[i], ins, sdf_clip);
+    // outside the clip band (flagged by the search, ~94 % of a lattice): the code needs the inside test only
+    code = (near_slot[i] < 0) ? sign_code_far(p, ins) : sign_code(p, near_d2[i], ins, sdf_clip);
     code8[i] = (uint8_t)code;
     }
     // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         if (PRIOR == ICON_PRIOR_ICON) {
             if (worker) {
                 code = G.code8[i];
-                slot = G.near_slot[i];
+                slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar);
                 if (!(code & kCodeOutlier)) d2 = G.near_d2[i];      // an outlier's sdf is its sign
                 outl = live && (code & kCodeOutlier);
             }
@@ -330,9 +332,9 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
     const int64_t nb = (N + 255) / 256;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, work_near_d2(work), work->d_code8, work->d_block_counts);
+                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_d2(work), work->d_code8, work->d_block_counts);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }

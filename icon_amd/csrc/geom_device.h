@@ -733,6 +733,24 @@ __device__ __forceinline__ uint32_t sign_code(f3 p, float d2, bool ins, float sd
     return code;
 }
 
+// Hand-over of the nearest-triangle result to k_sign / the fused kernel.  |sdf| = sqrt(d^2)/sqrt(3) does not depend on
+// the inside test, so the kernel that holds d^2 in a register decides "outside the clip band" (exactly the comparison
+// sign_code makes) and flags it in the slot word; d^2 itself is only stored for the ~6 % of points inside the band,
+// the only ones whose consumers read it: ~90 MB less HBM traffic per 257^3 step.
+constexpr uint32_t kNearFar = 0x80000000u;
+__device__ __forceinline__ void store_near(int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int64_t i, const Nearest &nr, float sdf_clip)
+{
+    const float dist = sqrtf(nr.d2) / sqrtf(3.0f);
+    const bool far = dist >= sdf_clip && dist > 0.0f;       // dist == 0 (sign 0) stays on the general path
+    near_slot[i] = (int32_t)((uint32_t)nr.slot | (far ? kNearFar : 0u));
+    if (!far) near_d2[i] = nr.d2;
+}
+// code byte of a point flagged kNearFar: what sign_code returns for |s| >= sdf_clip, s = +-dist, dist > 0
+__device__ __forceinline__ uint32_t sign_code_far(f3 p, bool ins)
+{
+    return in_cube_bit(p) | (ins ? kCodeInside : 0u) | kCodeOutlier | ((ins ? 2u : 0u) << kCodeSignShift);
+}
+
 __device__ __forceinline__ void store_row(float *X, int64_t i, const float *row)
 {
     float4 *dst = reinterpret_cast<float4 *>(X + i * kXRow);

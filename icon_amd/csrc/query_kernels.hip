@@ -50,14 +50,14 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
 
 // point mode, one wavefront per point (see nearest_coop)
 __global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N,
-                                                                 int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int cap)
+                                                                 int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int cap, float sdf_clip)
 {
     extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
-    if ((threadIdx.x & 63) == 0) { near_slot[i] = nr.slot; near_d2[i] = nr.d2; }
+    if ((threadIdx.x & 63) == 0) store_near(near_slot, near_d2, i, nr, sdf_clip);
 }
 
 __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, const float *__restrict__ pts, int64_t N,
@@ -83,11 +83,11 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
 // Nearest-triangle search as its own launch: the packet traversal needs ~50 VGPRs, so it runs at
 // full occupancy (8 waves / SIMD hide the dependent scalar-load chain), which the register-heavier
 // attribute / gather code would cap at 5.  Output per point, structure of arrays: the slot of the nearest
-// triangle and its squared distance (k_sign reads only the latter, the fused kernel only the former except
-// inside the clip band).
+// triangle with the "outside the clip band" flag, and - inside the band only - its squared distance (store_near).
 template <bool LATTICE>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
-                                                    int32_t *__restrict__ near_slot, float *__restrict__ near_d2, const int32_t *__restrict__ perm)
+                                                    int32_t *__restrict__ near_slot, float *__restrict__ near_d2, const int32_t *__restrict__ perm,
+                                                    float sdf_clip)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
@@ -106,8 +106,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
     }
     const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
     // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
-    //  writes - 209 MB at HBM for 136 MB of results - but the block-wide barrier costs 0.14 ms; not kept)
-    if (live) { near_slot[i] = nr.slot; near_d2[i] = nr.d2; }
+    //  writes but the block-wide barrier costs 0.14 ms; not kept)
+    if (live) store_near(near_slot, near_d2, i, nr, sdf_clip);
 }
 
 // Feature assembly: one 16-float row per point,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
             // the geometry pre-pass ran on the same stream just before: slot of the nearest triangle, the code byte
             // (outlier / sign / inside / in_cube) and, for points inside the clip band only, d^2
             code = code8[i];
-            nr.slot = near_slot[i]; nr.face = 0;
+            nr.slot = (int)((uint32_t)near_slot[i] & ~kNearFar); nr.face = 0;
             nr.d2 = (code & kCodeOutlier) ? 0.0f : near_d2[i];
             ins = (code & kCodeInside) != 0;
             o = sdf_attrs(m, p, nr, ins);
@@ -657,13 +657,13 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
         const int cap = coop_cap((int)mesh->stats[1]);
         hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
-                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near_slot, near_d2, cap);
+                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near_slot, near_d2, cap, sdf_clip);
     } else {
         if (!LATTICE) {
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm);
+        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip);
     }
     ICON_HIP(hipGetLastError());
     return launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
