@@ -250,7 +250,9 @@ inline void tri_setup(const float *a, const float *b, const float *c, int32_t fa
     t.i11 = (t.a11 > 0.0f) ? 1.0f / t.a11 : 0.0f;
     t.ibc = (b11 > 0.0f) ? 1.0f / b11 : 0.0f;
     const float nn = fmaf(t.a00, t.a11, -(t.a01 * t.a01));
-    t.inn = (nn > 0.0f) ? 1.0f / nn : 0.0f;
+    // zero area (or a sliver whose Gram determinant rounds to <= 0): NaN makes both barycentrics NaN, every
+    // comparison of the inside test false, and the distance the minimum over the three edge segments - exact
+    t.inn = (nn > 0.0f) ? 1.0f / nn : std::numeric_limits<float>::quiet_NaN();
     t.face = face; t.pad = 0;
 }
 

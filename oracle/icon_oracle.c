@@ -110,17 +110,19 @@ void orc_vertex_normals(const float *verts, int64_t V, const int64_t *faces, int
  * S2  exact point-triangle squared distance, "face or nearest edge" form.
  *     Per-triangle constants (orc_tri_setup, evaluated once per triangle on the CPU in both the
  *     checker and the product's mesh preparation): edge vectors, reciprocal squared edge lengths,
- *     the Gram matrix of (ab, ac) and the reciprocal of its determinant; zero-length / zero-area
- *     cases get a reciprocal of 0 (the formulas below then collapse to a vertex / an edge).
+ *     the Gram matrix of (ab, ac) and the reciprocal of its determinant; a zero-length edge gets a
+ *     reciprocal of 0 (its segment collapses to the vertex), a zero-area triangle a NaN determinant
+ *     reciprocal (never "inside": the minimum over its edge segments is its exact distance).
  *     Per point: barycentrics of the plane projection (s, t); if 0 <= s, 0 <= t, s + t <= 1 the
  *     result is |(p - a) - s ab - t ac|^2, otherwise the minimum over the three edge segments
- *     of |(p - origin) - clamp(t) * edge|^2 (fma chains starting from the rounded p - origin).  No division, no data-dependent branches: on the GPU
- *     this is ~70 VALU operations (sub / mul / fma / max / min / select), all exactly rounded.
+ *     of |(p - origin) - clamp(t) * edge|^2 (fma chains starting from the rounded p - origin).
+ *     No division, no data-dependent branches: on the GPU this is ~65 VALU operations per
+ *     triangle (sub / mul / fma / clamp / min / select), all exactly rounded.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     v3 a, b, ab, ac, bc;
     float i00, i11, ibc;      /* 1/|ab|^2, 1/|ac|^2, 1/|bc|^2 (0 if the edge has zero length) */
-    float a00, a01, a11, inn; /* ab.ab, ab.ac, ac.ac, 1/(a00*a11 - a01^2) (0 if not positive)  */
+    float a00, a01, a11, inn; /* ab.ab, ab.ac, ac.ac, 1/(a00*a11 - a01^2) (NaN if not positive) */
 } orc_tri;
 
 void orc_tri_setup(const float *pa, const float *pb, const float *pc, orc_tri *t)
@@ -134,7 +136,9 @@ void orc_tri_setup(const float *pa, const float *pb, const float *pc, orc_tri *t
     t->i11 = (t->a11 > 0.0f) ? 1.0f / t->a11 : 0.0f;
     t->ibc = (b11 > 0.0f) ? 1.0f / b11 : 0.0f;
     const float nn = fmaf(t->a00, t->a11, -(t->a01 * t->a01));
-    t->inn = (nn > 0.0f) ? 1.0f / nn : 0.0f;
+    /* zero area (or a sliver whose determinant rounds to <= 0): NaN -> both barycentrics NaN -> never "inside" ->
+     * the distance is the minimum over the three edge segments, which is exact for a degenerate triangle */
+    t->inn = (nn > 0.0f) ? 1.0f / nn : NAN;
 }
 
 /* max / min as plain comparisons (libm's fmaxf/fminf are out-of-line calls without fast-math).

@@ -178,3 +178,29 @@ def test_query_icon_subset_equals_full_call():
     occ_s, X_s = orc.query_icon_subset(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, mlp,
                                        pts, sub)
     assert np.array_equal(X_s, X[sub]) and np.array_equal(occ_s, occ[sub])
+
+
+def _seg_dist2_f64(p, a, b):
+    p, a, b = (np.asarray(x, np.float64) for x in (p, a, b))
+    e = b - a
+    l2 = e @ e
+    t = 0.0 if l2 == 0 else min(max((p - a) @ e / l2, 0.0), 1.0)
+    d = p - (a + t * e)
+    return d @ d
+
+
+def test_degenerate_triangles_are_their_edge_segments():
+    """zero-area triangles (collinear corners in any order, a repeated vertex, three equal vertices): the distance is
+    the distance to the union of the three edge segments - pinned against float64, not merely HIP == checker"""
+    rng = np.random.RandomState(3)
+    a = np.array([0.1, -0.2, 0.05], np.float32)
+    d = np.array([0.5, 0.25, -0.125], np.float32)                       # exactly representable multiples: exactly collinear
+    cases = [(a, a + d, a + 2 * d), (a, a + 2 * d, a + d), (a + d, a, a + 2 * d),        # the far corner first / middle / last
+             (a, a + d, a + d), (a + d, a, a + d), (a + d, a + d, a),                    # repeated vertex
+             (a, a, a)]
+    for A, B, C in cases:
+        for _ in range(200):
+            p = (a + rng.normal(0, 0.6, 3)).astype(np.float32)
+            want = min(_seg_dist2_f64(p, A, B), _seg_dist2_f64(p, A, C), _seg_dist2_f64(p, B, C))
+            got = orc.point_tri_dist2(p, A, B, C)
+            assert abs(got - want) <= 1e-6 * max(want, 1e-3), (A, B, C, p, got, want)
