@@ -29,3 +29,11 @@ def synced():
     eng.eval_slab(feat, 257, 0, 257, out=out); torch.cuda.synchronize()
 print(f"eval_slab + synchronize         {timeit(synced):.3f} ms / volume")
 print(f"DenseReconEngine.forward        {timeit(lambda: recon(opt=opt, netG=eng, features=[feat], proj_matrix=None)):.3f} ms / volume")
+eng._work().profile(True)
+tr = ts = 0.0
+for i in range(23):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = recon(opt=opt, netG=eng, features=[feat], proj_matrix=None); t1 = time.perf_counter()
+    eng._work().stage_ms(); t2 = time.perf_counter()
+    if i >= 3: tr += t1 - t0; ts += t2 - t1
+print(f"with events: forward {tr / 20 * 1e3:.3f} ms, stage_ms() {ts / 20 * 1e3:.3f} ms")
