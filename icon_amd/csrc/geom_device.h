@@ -232,7 +232,8 @@ __device__ __forceinline__ float prune_threshold(float best)
 // word per stack entry per wave); every lane tests its own point against the shared node boxes
 // and triangles, and a subtree is entered when ANY lane still needs it.  In lattice mode a
 // wavefront owns a 4x4x4 block of lattice points, so the lanes' candidate sets nearly coincide.
-// A leaf holds up to 4 TriPre records (96 B each, scalar loads); the distance test is branch-free.  Near child first, ordered by the block's centre lane.
+// A leaf holds up to 4 TriPre records (96 B each, scalar loads); the distance test has no per-lane branch (one
+// wave-uniform skip of the face term).  Near child first, ordered by the block's centre lane.
 // `live` = false parks a padding lane: it never votes and its result is discarded.
 template <bool STATS = false>
 __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
