@@ -947,3 +947,24 @@ def test_smplx_size_mesh(body):
     occ = make_engine(a).eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
     ref_occ, _ = oracle_query(a, synth.lattice_points(res))
     assert np.abs(occ - ref_occ).max() <= OCC_TOL
+
+
+@pytest.mark.parametrize("clip", [0.0, 0.004, 10.0])
+def test_unusual_clip_bands(clip):
+    """sdf_clip = 0 (every point off the surface is an outlier; a point ON the surface has sign 0), a band thinner than
+    the lattice spacing, and a band wider than the cube (no outliers, K = 0): point and lattice mode vs the checker"""
+    from types import SimpleNamespace
+    a = SimpleNamespace(**vars(assets("ico")))
+    a.sdf_clip = clip
+    eng = make_engine(a)
+    v, f = a.smpl_verts[0], a.smpl_faces[0]
+    pts = synth.stratified_points(v, f, 3000, seed=21)
+    pts[:len(v)] = v                                              # exactly on the surface: distance 0
+    pts[200:400] = v[f[:200]].mean(1).astype(np.float32)          # face centroids (rounded: distance ~1e-8)
+    occ = eng.query([T(a.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    ref, _ = oracle_query(a, pts)
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    res = 33
+    vol = eng.eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
+    ref_l, _ = oracle_query(a, synth.lattice_points(res))
+    assert np.abs(vol - ref_l).max() <= OCC_TOL
