@@ -175,11 +175,19 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     _lib.require_device()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # ICON_AMD_DIST_BACKEND=gloo: debugging aid - several ranks on the GPUs that are there (RCCL refuses two ranks on
+    # one device); collectives are staged through the host, the numbers mean nothing, the control flow is the real one
+    backend = os.environ.get("ICON_AMD_DIST_BACKEND", "nccl")
+    local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
+    cdev = dev if backend == "nccl" else torch.device("cpu")     # where the bookkeeping collectives live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     res = args.res
     a = synth.make_assets("body", prior_type=args.prior)
@@ -233,7 +241,7 @@ def main():
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage /= max(args.steps, 1)
@@ -251,13 +259,15 @@ def main():
     if os.path.exists(tpath):
         try:
             traffic = json.load(open(tpath)).get(KERNEL[args.precision] + "_bytes_per_launch")
+            if traffic is not None and my_points != n_points:
+                traffic = traffic * my_points / n_points          # the PMC passes were taken on whole-volume launches
         except Exception:
             traffic = None
 
     # per-rank stage times (every rank's slab differs in traversal cost): makes a SCALE run diagnosable
     rank_stage = None
     if world > 1:
-        mine = torch.tensor([z0, z1, stage[0], stage[1], stage[2], my_elapsed / args.steps * 1e3], dtype=torch.float64, device=dev)
+        mine = torch.tensor([z0, z1, stage[0], stage[1], stage[2], my_elapsed / args.steps * 1e3], dtype=torch.float64, device=cdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         rank_stage = [{"rank": r, "planes": [int(v[0]), int(v[1])], "features_ms": float(v[2]), "cmap_patch_ms": float(v[3]),
