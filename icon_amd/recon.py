@@ -57,11 +57,12 @@ def slab_bounds(res: int, world_size: int, rank: int, weights=None):
     return z0, z1, max(b - a for a, b in parts)
 
 
-def plane_weights(res: int, z_lo: float, z_hi: float, far_cost: float = 1.1) -> np.ndarray:
+def plane_weights(res: int, z_lo: float, z_hi: float, far_cost: float = 1.04) -> np.ndarray:
     """Relative cost of the lattice planes for a body whose vertices span [z_lo, z_hi] in world z: planes farther
     than the clip band from the body are pure far-field, where the exact nearest-triangle search visits more
-    candidates (measured on MI355X: the outer slabs of an 8-way split ran ~10 % longer than the middle ones;
-    the MLP cost per point is uniform)."""
+    candidates; the MLP cost per point is uniform.  Measured on MI355X (tools/time_slab.py, equal 32-plane slabs of
+    the 257^3 lattice, 8 ranks): 2.47 / 2.42 / 2.36 / 2.33 | 2.33 / 2.37 / 2.38 ms from the outside in - a far-field
+    plane costs ~4 % more than one through the body (it was ~10 % before the round-2 work on the search)."""
     z = -1.0 + 2.0 * np.arange(res) / (res - 1)
     near = (z >= z_lo - 0.1) & (z <= z_hi + 0.1)
     return np.where(near, 1.0, far_cost)
