@@ -209,6 +209,13 @@ __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMa
             const float rad = 2.6f * h;                       // > half diagonal of a 4x4x4 block (sqrt(3) * 1.5 h)
             thr0 = prune_threshold((dc + rad) * (dc + rad));
         }
+        if (seeded == 3) {      // the bound a wave walking along x would carry over: this lane's result one packet (4 points) back
+            const float h = 2.0f / (float)(L.res - 1);
+            int na = 0, nb = 0;
+            const Nearest pv = nearest_packet<true>(m, mk3(p.x - 4.0f * h, p.y, p.z), live, lds + (threadIdx.x >> 6) * kStackDepth, &na, &nb);
+            const float dn = sqrtf(pv.d2) + 4.0001f * h;
+            thr0 = prune_threshold(dn * dn);
+        }
         nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt, thr0);
     }
     if ((threadIdx.x & 63) == 0) {
