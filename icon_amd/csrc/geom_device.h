@@ -259,9 +259,11 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
                 // above +inf) never wins; a padding copy has the same key as its original.
                 const unsigned long long k0 = ((unsigned long long)(unsigned)__float_as_int(d2.x) << 32) | (unsigned)__float_as_int(fc.x);
                 const unsigned long long k1 = ((unsigned long long)(unsigned)__float_as_int(d2.y) << 32) | (unsigned)__float_as_int(fc.y);
-                // (the winner's slot is looked up from its face id at the end: nothing else to carry per test)
-                key = (live & (k0 < key)) ? k0 : key;
-                key = (live & (k1 < key)) ? k1 : key;
+                // (the winner's slot is looked up from its face id at the end: nothing else to carry per test; a parked
+                //  lane computes on a clamped copy of a real point and may update its key freely - it never votes
+                //  (thr = -inf) and its result is not stored - so the update needs no `live` mask)
+                key = (k0 < key) ? k0 : key;
+                key = (k1 < key) ? k1 : key;
             }
             const bool improved = key != before;
             nr.d2 = __int_as_float((int)(key >> 32));
