@@ -115,21 +115,20 @@ __device__ __forceinline__ f2 tri_dist2_pair(f3 p1, cf2 *q)
     const f2 su = s + u;
     const bool in0 = (s.x >= 0.0f) & (u.x >= 0.0f) & (su.x <= 1.0f);
     const bool in1 = (s.y >= 0.0f) & (u.y >= 0.0f) & (su.y <= 1.0f);
-    // the face distance is selected only where the projection falls inside the triangle: for most of a packet's
-    // candidates no lane's does, and the wave skips it (same selected bits either way)
-    f2 d_face = bc2(0.0f);
-    if (__any(in0 | in1)) {
-        const f2 ns = -s, nu = -u;
-        f3x2 df; df.x = fma2(nu, ac.x, fma2(ns, ab.x, ap.x)); df.y = fma2(nu, ac.y, fma2(ns, ab.y, ap.y)); df.z = fma2(nu, ac.z, fma2(ns, ab.z, ap.z));
-        d_face = dot3x2(df, df);
-    }
     const f2 e0 = seg_dist2x2(ap, ab, d1, i00);
     const f2 e1 = seg_dist2x2(ap, ac, d2, i11);
     const f2 e2 = seg_dist2x2(bp, bc, d3, ibc);
-    f2 d_edge; d_edge.x = fminf(fminf(e0.x, e1.x), e2.x); d_edge.y = fminf(fminf(e0.y, e1.y), e2.y);
-    float f0 = d_face.x, f1 = d_face.y, g0 = d_edge.x, g1 = d_edge.y;
-    asm volatile("" : "+v"(f0), "+v"(f1), "+v"(g0), "+v"(g1));
-    f2 r; r.x = in0 ? f0 : g0; r.y = in1 ? f1 : g1;
+    f2 r; r.x = fminf(fminf(e0.x, e1.x), e2.x); r.y = fminf(fminf(e0.y, e1.y), e2.y);
+    // the face distance is selected only where the projection falls inside the triangle: for most of a packet's
+    // candidates no lane's does, and the wave skips it and the selection (same selected bits either way)
+    if (__any(in0 | in1)) {
+        const f2 ns = -s, nu = -u;
+        f3x2 df; df.x = fma2(nu, ac.x, fma2(ns, ab.x, ap.x)); df.y = fma2(nu, ac.y, fma2(ns, ab.y, ap.y)); df.z = fma2(nu, ac.z, fma2(ns, ab.z, ap.z));
+        const f2 d_face = dot3x2(df, df);
+        float f0 = d_face.x, f1 = d_face.y, g0 = r.x, g1 = r.y;
+        asm volatile("" : "+v"(f0), "+v"(f1), "+v"(g0), "+v"(g1));     // keep the choice a v_cndmask
+        r.x = in0 ? f0 : g0; r.y = in1 ? f1 : g1;
+    }
     return r;
 }
 
@@ -250,7 +249,8 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
             const int leaf = code >> 2, cnt = (code & 3) + 1;
             if (STATS) *n_tris += cnt;
             const unsigned long long before = key;
-            for (int pr = 0; pr * 2 < cnt; ++pr) {
+            const int npairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);      // 1 or 2, wave-uniform (scalar loop counter)
+            for (int pr = 0; pr < npairs; ++pr) {
                 cf2 *q = reinterpret_cast<cf2 *>(as_const(&m.leaves[leaf].pair[pr]));
                 const f2 d2 = tri_dist2_pair(p, q);
                 const f2 fc = q[22];
