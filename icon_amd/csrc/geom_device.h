@@ -248,7 +248,6 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
             const int code = ~cur;
             const int leaf = code >> 2, cnt = (code & 3) + 1;
             if (STATS) *n_tris += cnt;
-            const unsigned long long before = key;
             const int npairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);      // 1 or 2, wave-uniform (scalar loop counter)
             for (int pr = 0; pr < npairs; ++pr) {
                 cf2 *q = reinterpret_cast<cf2 *>(as_const(&m.leaves[leaf].pair[pr]));
@@ -265,9 +264,8 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
                 key = (k0 < key) ? k0 : key;
                 key = (k1 < key) ? k1 : key;
             }
-            const bool improved = key != before;
             nr.d2 = __int_as_float((int)(key >> 32));
-            if (__any(improved)) thr = live ? prune_threshold(nr.d2) : thr;
+            thr = live ? prune_threshold(nr.d2) : thr;           // one fma + select: cheaper than finding out whether the key moved
             if (sp == 0) break;
             cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
         } else {
