@@ -107,6 +107,7 @@ struct MeshDev {
     const int32_t *bin_slots;   // triangle slots
     float bin_y0, bin_z0, bin_y1, bin_z1, bin_inv_y, bin_inv_z;
     int32_t gy, gz;
+    float box_lo[3], box_hi[3]; // bounding box of the vertices
 };
 
 struct FeatDev {

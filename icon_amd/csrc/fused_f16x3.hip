@@ -79,7 +79,7 @@ template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
                                               const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2, uint8_t *__restrict__ code8,
-                                              int32_t *__restrict__ block_counts)
+                                              int32_t *__restrict__ block_counts, float far_box2)
 {
     __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -96,8 +96,11 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
         ins = inside_bins(m, p);
     }
-    // outside the clip band (flagged by the search, ~94 % of a lattice): the code needs the inside test only
-    code = (near_slot[i] < 0) ? sign_code_far(p, ins) : sign_code(p, near_d2[i], ins, sdf_clip);
+    // outside the clip band (~94 % of a lattice): the code needs the inside test only.  Nine points in ten are
+    // farther from the body's bounding box than the band is wide - they are known to be outside it without
+    // reading anything; for the rest the search left a flag in the slot word
+    const bool far = box_dist2(m.box_lo[0], m.box_lo[1], m.box_lo[2], m.box_hi[0], m.box_hi[1], m.box_hi[2], p) > far_box2 || near_slot[i] < 0;
+    code = far ? sign_code_far(p, ins) : sign_code(p, near_d2[i], ins, sdf_clip);
     code8[i] = (uint8_t)code;
     }
     // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
@@ -331,10 +334,14 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
 {
     const int64_t nb = (N + 255) / 256;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    // box distance^2 beyond which |sdf| = d / sqrt(3) >= sdf_clip for certain (d >= box distance; the computed d^2 is
+    // within 1e-6 relative of the true one): (clip sqrt(3))^2 with a cushion.  Negative clips: every point off the box.
+    const float cb = std::max(sdf_clip, 0.0f) * 1.7320508f;
+    const float far_box2 = cb * cb * 1.0001f + 1e-6f;
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts);
+                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts, far_box2);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts, far_box2);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }

@@ -470,6 +470,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     d.bin_start = m->d_bin_start; d.bin_slots = m->d_bin_slots;
     d.bin_y0 = y0; d.bin_z0 = z0; d.bin_y1 = y1; d.bin_z1 = z1; d.bin_inv_y = inv_y; d.bin_inv_z = inv_z;
     d.gy = gy; d.gz = gz;
+    for (int k = 0; k < 3; ++k) { d.box_lo[k] = mesh_box.lo[k]; d.box_hi[k] = mesh_box.hi[k]; }
     m->stats[0] = (int64_t)bd.nodes.size(); m->stats[1] = bd.max_depth;
     m->stats[2] = (int64_t)bin_slots.size(); m->stats[3] = max_bin;
     m->stats[4] = n_leaves; m->stats[5] = S;
