@@ -112,10 +112,14 @@ def cpu_baseline(assets, res, budget_s=14.0):
     return out
 
 
-def parity_sample(assets, res, occ, cmap_mode, n_each=12288, seed=1993):
+def parity_sample(assets, res, occ, cmap_mode, eng=None, n_each=12288, seed=1993):
     """max / p99.9 |occ - checker| on a stratified sample of the lattice: uniform points, points around the 0.5
     level set (where the mesh comes from) and shell points.  The checker evaluates the geometry half on the
-    WHOLE lattice (the tiled outlier-cmap rule needs every sign) and the MLP in float64 on the sample."""
+    WHOLE lattice (the tiled outlier-cmap rule needs every sign) and the MLP in float64 on the sample.
+    With `eng`: the errors split by TIE stratum - a point is "tied" when the runner-up triangle's d^2 lies within
+    one float32 ulp of the winner's (icon_sdf_query_ties), i.e. its norm / cmap / vis hang on the last bit of the
+    unpinned kaolin leaf (lib/dataset/mesh_util.py:374-390).  Within ONE definition of the leaf (checker == HIP)
+    both strata meet the tolerance; only the untied stratum is comparable point by point with a kaolin run."""
     import numpy as np
     import torch
     from icon_amd import synth
@@ -137,11 +141,74 @@ def parity_sample(assets, res, occ, cmap_mode, n_each=12288, seed=1993):
                                    f64=True, cmap_local=(cmap_mode == "local"))
     got = flat[torch.from_numpy(idx).to(flat.device)].cpu().numpy()
     err = np.abs(got - ref)
-    return {"n": int(len(idx)), "max_abs": float(err.max()), "p999_abs": float(np.quantile(err, 0.999)),
-            "mean_abs": float(err.mean()), "tolerance": 1e-4, "within": bool(err.max() <= 1e-4),
-            "strata": {"uniform": int(len(uni)), "level_set_band": int(len(lvl)), "shell": int(len(shell))},
-            "checker": "oracle/icon_oracle.c, geometry on all %d lattice points, float64 MLP on the sample" % n,
-            "seconds": time.perf_counter() - t0}
+    out = {"n": int(len(idx)), "max_abs": float(err.max()), "p999_abs": float(np.quantile(err, 0.999)),
+           "mean_abs": float(err.mean()), "tolerance": 1e-4, "within": bool(err.max() <= 1e-4),
+           "strata": {"uniform": int(len(uni)), "level_set_band": int(len(lvl)), "shell": int(len(shell))},
+           "checker": "oracle/icon_oracle.c, geometry on all %d lattice points, float64 MLP on the sample" % n}
+    if eng is not None:
+        mesh = eng._mesh_handle()
+        dev = flat.device
+        ulps = mesh.sdf_query_ties(torch.from_numpy(pts[idx]).to(dev))["ulps"].cpu().numpy()
+        tied = ulps <= 1
+        out["max_abs_untied"] = float(err[~tied].max()) if (~tied).any() else None
+        out["max_abs_tied"] = float(err[tied].max()) if tied.any() else None
+        out["frac_tied"] = float(tied.mean())
+        band_s = np.isin(idx, lvl)
+        out["frac_tied_level_set_band"] = float(tied[band_s].mean()) if band_s.any() else None
+        # the whole lattice: how much of it is tie-sensitive at all (histogram of the ulp gap to the runner-up)
+        ul = mesh.sdf_query_ties(torch.from_numpy(pts).to(dev))["ulps"]
+        edges = [0, 1, 2, 5, 17, 255, 256]
+        hist = torch.histc(ul.float(), bins=256, min=0, max=256).cpu().numpy()
+        out["tie_ulps_histogram_lattice"] = {f"{a}" if b == a + 1 else f"{a}-{b - 1}": int(hist[a:b].sum()) for a, b in zip(edges[:-1], edges[1:])}
+        out["frac_tied_lattice"] = float((ul <= 1).float().mean().item())
+        out["tie_definition"] = "runner-up face's d^2 within 1 float32 ulp of the winner's (255 = none within the search bound)"
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
+def tie_sensitivity(assets, res, occ, make_engine, step_with, ulps=1):
+    """The same volume under the ALTERNATIVE tie rule (among the faces within `ulps` ulps of the minimum d^2 the
+    highest index instead of the exact minimum / lowest index): how many lattice values, level-set voxels and how much
+    of the mesh hang on the unpinned tie behaviour of kaolin's point_to_mesh_distance."""
+    import torch
+    from icon_amd import metrics
+    from icon_amd.recon import export_mesh_device
+    t0 = time.perf_counter()
+    e2 = make_engine("f16x3")
+    e2.tie_rule = ("highest", ulps)
+    occ2 = step_with(e2)
+    d = (occ2 - occ).abs()
+    band = (occ - 0.5).abs() < 0.2
+    out = {"rule": f"highest face index among the faces within {ulps} ulp of the minimum d^2 (default: lowest index, exact minimum)",
+           "values_moved_gt_1e-4": int((d > 1e-4).sum().item()), "frac_moved_gt_1e-4": float((d > 1e-4).float().mean().item()),
+           "max_move": float(d.max().item()),
+           "level_set_band_voxels": int(band.sum().item()), "level_set_band_moved_gt_1e-4": int(((d > 1e-4) & band).sum().item()),
+           "level_set_band_max_move": float(d[band].max().item()) if band.any() else 0.0,
+           "voxels_changing_side_of_0.5": int(((occ > 0.5) != (occ2 > 0.5)).sum().item())}
+    va, fa = export_mesh_device(occ, 0.5)
+    vb, fb = export_mesh_device(occ2.contiguous(), 0.5)
+    ch, p2s = metrics.chamfer_p2s(metrics.to_unit_cube(va, res), fa, metrics.to_unit_cube(vb, res), fb, n=100_000)
+    out["mesh_chamfer_x100"] = ch
+    out["mesh_p2s_x100"] = p2s
+    out["voxel_x100"] = 2.0 / (res - 1) * 100.0
+    out["seconds"] = time.perf_counter() - t0
+    return out
+
+
+def self_launch(n: int) -> int:
+    """Run this very command line as n ranks of one node (torch.distributed.run, 127.0.0.1 rendezvous on a free
+    port); the ranks' stdout / stderr pass through, so rank 0's JSON line is this process's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -160,6 +227,12 @@ def main():
                          "use it under rocprofv3 so the trace holds only the dense step")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N`: start the N ranks ourselves - re-exec under torch.distributed.run, one process per
+        # GPU, rendezvous on 127.0.0.1 (the driver's own `python -m torch.distributed.run ... bench.py` form sets WORLD_SIZE
+        # and never comes through here)
+        sys.exit(self_launch(args.gpus))
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -171,13 +244,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     _lib.require_device()
     # ICON_AMD_DIST_BACKEND=gloo: debugging aid - several ranks on the GPUs that are there (RCCL refuses two ranks on
     # one device); collectives are staged through the host, the numbers mean nothing, the control flow is the real one
     backend = os.environ.get("ICON_AMD_DIST_BACKEND", "nccl")
+    if backend == "nccl" and world > torch.cuda.device_count():
+        # rank setup, before any rendezvous: one process per GPU needs one device per rank
+        raise SystemExit(f"bench.py rank {rank}: need {world} HIP devices for --gpus {world} (one process per GPU over RCCL), "
+                         f"this node shows {torch.cuda.device_count()}; ICON_AMD_DIST_BACKEND=gloo runs the ranks on the "
+                         "devices that are there (control flow only, the numbers mean nothing)")
     local_dev = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
@@ -254,15 +331,27 @@ def main():
     value = n_points * args.steps / elapsed
     mlp_s = stage[2] * 1e-3
     achieved = (MLP_FLOP_PER_POINT * my_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
-    traffic = None
+    # HBM bytes of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs,
+    # tools/gpu_round.sh): quoted only while profiles/traffic.json was taken on exactly these kernel sources
+    traffic, traffic_note = None, "profiles/traffic.json absent"
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(KERNEL[args.precision] + "_bytes_per_launch")
-            if traffic is not None and my_points != n_points:
-                traffic = traffic * my_points / n_points          # the PMC passes were taken on whole-volume launches
-        except Exception:
-            traffic = None
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from rocprof_summary import kernel_sources_sha
+            tj = json.load(open(tpath))
+            if tj.get("kernel_sources_sha") != kernel_sources_sha():
+                traffic_note = ("profiles/traffic.json is stale: taken on kernel sources " + str(tj.get("kernel_sources_sha"))
+                                + ", this tree is " + kernel_sources_sha() + " - regenerate with tools/gpu_round.sh")
+            elif res != 257 or args.prior != "icon":
+                traffic_note = "profiles/traffic.json holds the 257^3 icon step only"
+            else:
+                traffic = tj.get(KERNEL[args.precision] + "_bytes_per_launch")
+                traffic_note = "PMC FETCH_SIZE x2 + WRITE_SIZE per launch (profiles/traffic.json, same kernel sources)"
+                if traffic is not None and my_points != n_points:
+                    traffic = traffic * my_points / n_points          # the PMC passes were taken on whole-volume launches
+        except Exception as ex:
+            traffic, traffic_note = None, f"profiles/traffic.json unreadable: {ex!r}"
 
     # per-rank stage times (every rank's slab differs in traversal cost): makes a SCALE run diagnosable
     rank_stage = None
@@ -328,9 +417,18 @@ def main():
                 extras["mesh"] = {"error": repr(ex)}
         # (4) live parity sample against the checker
         try:
-            extras["parity"] = parity_sample(a, res, occ, args.cmap_mode)
+            extras["parity"] = parity_sample(a, res, occ, args.cmap_mode, eng=eng)
         except Exception as ex:
             extras["parity"] = {"error": repr(ex)}
+        # (5) how much of the volume depends on the tie rule of the unpinned nearest-triangle leaf
+        try:
+            def step_with(e):
+                r = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[res],
+                                     align_corners=True, engine=e).to(dev)
+                return step(r, e)
+            extras["tie_sensitivity"] = tie_sensitivity(a, res, occ, make_engine, step_with)
+        except Exception as ex:
+            extras["tie_sensitivity"] = {"error": repr(ex)}
 
     if rank == 0:
         cfg_name = "icon-filter.yaml" if args.prior == "icon" else "pamir.yaml (hoisted VolumeEncoder output [1,7,32^3])"
@@ -349,7 +447,7 @@ def main():
             },
             "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved,
                          "peak": PEAK_TFLOPS[args.precision],
-                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic,
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic, "traffic_note": traffic_note,
                          "flop_per_launch": MLP_FLOP_PER_POINT * my_points, "avg_launch_ms": stage[2],
                          "algorithmic_hbm_bytes_per_launch": ALGO_BYTES_PER_POINT * my_points},
         }

@@ -129,9 +129,19 @@ struct Lattice {
 
 // Lattice tiling of the geometry kernels (see geom_device.h: lattice_point)
 struct LatticeMap {
-    int res, z0, nz;           // evaluated planes [z0, z0+nz)
-    int tx, ty, tz;            // tile counts
+    int res, z0, nz;           // the slab: planes [z0, z0+nz); a point's linear index is relative to plane z0
+    int tx, ty, tz;            // tile counts of the nearest-triangle search
     int remap;                 // 0: single tiles alternate over the XCDs (default), 2: x-rows of tiles, 1: contiguous run of tiles per XCD
+    // Shell skip (lib/net/HGPIFuNet.py:274-275,363: in_cube is strict, so every lattice point with a coordinate of
+    // exactly +-1 - the outermost shell, 2.3 % of a 257^3 lattice - is multiplied by 0).  off = 1: the MLP tiles cover
+    // the interior [off, res-off)^3 only and the shell is written as 0; off = 0: everything is evaluated and masked, as
+    // the reference does.  A shell point still needs its code byte (it is an entry of the call's outlier sign list), but
+    // not its nearest triangle when it is farther from the body's bounding box than the clip band is wide: the faces of
+    // the cube whose distance from the box says so for ALL their points are left out of the SEARCH region as well.
+    int off;
+    int zs, nzi;               // planes of the MLP tiles: global [zs, zs + nzi) = slab planes minus the z shell
+    int sx0, sx1, sy0, sy1;    // search region of k_nearest: lattice indices [s?0, s?1) in x and y ...
+    int sz0, sz1;              // ... and planes [sz0, sz1) RELATIVE to the slab
 };
 
 // where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)
@@ -141,7 +151,7 @@ struct FusedSigns {
     const int8_t *list;           // SELF / GLOBAL: signs in point order
     const int64_t *k_dev;         // SELF: device scalar K
     int64_t k_host, rank_offset;  // GLOBAL
-    const int8_t *gathered;       // SEG: all_gather output, message r = [int64 count][int8 signs]
+    const int8_t *gathered;       // SEG: all_gather output, message r = [int64 count][2-bit packed signs]
     int64_t stride;
     int world, rank;
 };
@@ -204,9 +214,14 @@ float pick_scale(const std::vector<float> &W);     // power of two that brings m
 // fused_f16x3.hip
 int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const float *d_points, int64_t N, float sdf_clip,
                 const icon_work *work, bool lattice, hipStream_t st);
+// lattice: evaluates the planes [za, zb) of the slab L (global plane numbers; the whole slab = [L.z0, L.z0 + L.nz)),
+// d_occ is the SLAB's output buffer; points: the N points of the call
 int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_mlp *mlp, int prior, const Calib &cal,
-                       int res, int z0, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
+                       const LatticeMap &L, int za, int zb, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
                        const icon_work *work, const FusedSigns &fs, float *d_occ, bool lattice, hipStream_t st);
+// per-device launch facts (CU count; one-off kernel attributes): a process may drive several devices
+int device_cu_count(int *n_cu);
+bool first_use_on_device(int kernel_id);   // true exactly once per (kernel_id, current device)
 // mlp_mx6.hip
 int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
 int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
@@ -218,7 +233,8 @@ struct icon_work {
     void *d_near = nullptr;               // nearest-triangle result: int32 slot [cap_points] followed by float d^2 [cap_points]
     uint8_t *d_code8 = nullptr;           // [cap_points] byte copy of each row's code word
     int64_t cap_points = 0;
-    int32_t *d_block_counts = nullptr;    // outliers per 1024-point scan block
+    uint64_t *d_grp_mask = nullptr;       // [4 * cap_blocks] outlier ballot of every 64-point group (k_sign): rank of a point = block offset + popcounts
+    int32_t *d_block_counts = nullptr;    // outliers per 256-point scan block
     int64_t *d_block_offsets = nullptr;   // exclusive prefix of the above
     int32_t *d_scan_local = nullptr;      // scan scratch: prefix inside each 1024-entry chunk
     int64_t *d_scan_part = nullptr;       // scan scratch: chunk totals
@@ -238,7 +254,9 @@ struct icon_work {
     int64_t cap_sort = 0;
     // state of the split slab protocol (icon_grid_slab_features -> icon_grid_slab_finish)
     int slab_res = 0, slab_z0 = 0, slab_z1 = 0, slab_c0 = 0, slab_cmap_slot = 0;
-    bool slab_ready = false, slab_needs_patch = false;
+    bool slab_ready = false, slab_needs_patch = false, slab_patched = false;
+    // diagnostics: tie rule of the nearest-triangle choice (icon_work_set_tie_rule); 0 = the definition (S3)
+    int tie_rule = 0, tie_ulps = 0;
     // what phase 1 of a query recorded for phase 2 (the handles must outlive the pair of calls)
     const icon_mesh *q_mesh = nullptr;
     const icon_feat *q_feat = nullptr;

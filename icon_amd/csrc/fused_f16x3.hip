@@ -24,29 +24,36 @@
 // f16x3 path (tests/test_gpu_parity.py::test_fused_equals_unfused).
 //
 // Workgroup = 512 threads = 8 waves, ONE per CU (LDS: 80 KiB weight double buffer + 32 KiB resident W0 +
-// side arrays + 16 KiB point tile), persistent: it walks tiles of 256 consecutive points of the call's
-// linear order, so the outlier rank of a point = the tile's offset from the scan + a ballot prefix, and the
-// reference's tiled cmap rule cmap[j][k] = s[(3j+k) mod K] (HGPIFuNet.py:303-305) is three byte loads.
+// side arrays + 16 KiB point tile), persistent: it walks tiles of 256 WORK ITEMS.  Point mode: work item q is point
+// q of the call.  Lattice mode: the work items are the lattice points that can be non-zero - with the shell skip
+// (LatticeMap::off = 1) the interior [1, R-2]^3 of the evaluated planes in z,y,x order, 2.3 % fewer tiles at 257^3;
+// the shell itself is written by k_shell_zero (in_cube is strict: lib/net/HGPIFuNet.py:274-275,363).
+// The outlier rank of a point (its position in the call's sign list) = the exclusive scan of the outlier counts
+// per 256 points of the call's LINEAR order + popcounts of the 64-point outlier ballots k_sign left behind, so
+// the tiles need not be aligned with that order, and the reference's tiled cmap rule
+// cmap[j][k] = s[(3j+k) mod K] (HGPIFuNet.py:303-305) is three byte loads.
 // W0 / biases are staged once per workgroup; chunk 0 of the next tile is DMA'd during the last layer-2 chunk.
 #pragma clang fp contract(off)
 
 #include "geom_device.h"
 #include "mlp_f16x3_device.h"
 
+#include <algorithm>
+#include <mutex>
+
 namespace icon {
 
 constexpr int kTilePts = kF16Pts;                     // 256 points per tile
 // LDS map: [2 x 40 KiB weight buffers][W0 32 KiB][side arrays][point tile 16 KiB][wave sums]
 constexpr int kXsOff = kSideOff + 4352;               // point tile [256][16] f32 behind the side arrays
-constexpr int kMiscOff = kXsOff + kTilePts * kXRow * 4;
-constexpr int kFusedLds = kMiscOff + 16;              // + the four wave sums of the outlier ballot
+constexpr int kFusedLds = kXsOff + kTilePts * kXRow * 4;
 
 struct SignSrc {
     int mode;
     const int8_t *list;          // SELF / GLOBAL: the outlier signs of the call in point order
     const int64_t *k_dev;        // SELF: device scalar K
     int64_t k_host, rank_offset; // GLOBAL: K and the number of outliers in lower slabs
-    const int8_t *gathered;      // SEG: all_gather output, message r = [int64 count][int8 signs]
+    const int8_t *gathered;      // SEG: all_gather output, message r = [int64 count][signs, 2 bits each: sign + 1]
     int64_t stride;
     int world, rank;
     const int64_t *seg;          // SEG: [world + 1] exclusive prefix of the counts (k_seg_offsets)
@@ -56,15 +63,17 @@ struct FusedGeom {
     MeshDev m;
     FeatDev f;
     Calib cal;
-    int res, z0;                 // lattice mode
+    int res, z0;                 // lattice mode: resolution, first plane of the slab (linear index i is relative to it)
+    int off, nx, zs;             //   work item q -> (off + q % nx, off + (q / nx) % nx, zs + q / nx^2), nx = res - 2 off
     const float *pts;            // point mode
-    int64_t N;
+    int64_t N;                   // work items of this launch
     float sdf_clip;
     int cmap_local;
     const int32_t *near_slot;    // icon prior: slot of the nearest triangle (k_nearest / k_nearest_coop)
     const float *near_d2;        //             its squared distance - valid for the points inside the clip band only
     const uint8_t *code8;        // icon prior: outlier / sign / inside / in_cube (k_nearest<.., SIGN> or k_sign)
-    const int64_t *tile_offsets; // exclusive scan of the outlier counts per 256-point tile
+    const int64_t *block_offsets;        // exclusive scan of the outlier counts per 256 points of the linear order
+    const unsigned long long *grp_mask;  // outlier ballot of every 64-point group of the linear order (4 per block)
     SignSrc sg;
 };
 
@@ -79,7 +88,7 @@ template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
                                               const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2, uint8_t *__restrict__ code8,
-                                              int32_t *__restrict__ block_counts, float far_box2)
+                                              int32_t *__restrict__ block_counts, unsigned long long *__restrict__ grp_mask, float far_box2)
 {
     __shared__ int wsum[4];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -105,9 +114,25 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
     }
     // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
     const unsigned long long b = __ballot(live && (code & kCodeOutlier));
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(b);
+    if ((threadIdx.x & 63) == 0) {
+        wsum[threadIdx.x >> 6] = __popcll(b);
+        grp_mask[(int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)] = b;    // the fused kernel derives a point's outlier rank from these
+    }
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// the shell of the planes [za, zb) of a slab whose MLP tiles skipped it: exact zeros (in_cube * pred, HGPIFuNet.py:363)
+__global__ __launch_bounds__(64) void k_shell_zero(float *__restrict__ out, int res, int z0, int za, int zb)
+{
+    const int64_t row = blockIdx.x;                       // rows of the planes [za, zb)
+    const int iy = (int)(row % res), iz = za + (int)(row / res);
+    float *o = out + ((int64_t)(iz - z0) * res + iy) * res;
+    if (iz == 0 || iz == res - 1 || iy == 0 || iy == res - 1) {
+        for (int x = threadIdx.x; x < res; x += 64) o[x] = 0.0f;
+    } else if (threadIdx.x < 2) {
+        o[threadIdx.x ? res - 1 : 0] = 0.0f;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -126,9 +151,20 @@ __device__ __forceinline__ float sign_at(const SignSrc &sg, int64_t mm)
             r += ge ? 1 : 0;
             base = ge ? o : base;
         }
-        return (float)sg.gathered[(int64_t)r * sg.stride + 8 + (mm - base)];
+        const int64_t e = mm - base;                             // 2 bits per sign (sign + 1), four to a byte
+        const uint32_t byte = (uint8_t)sg.gathered[(int64_t)r * sg.stride + 8 + (e >> 2)];
+        return (float)((int)((byte >> (2 * (int)(e & 3))) & 3u) - 1);
     }
     return (float)sg.list[mm];
+}
+
+// lattice mode: work item q -> lattice indices and the point's index in the linear order of the slab
+__device__ __forceinline__ int64_t lattice_item(const FusedGeom &G, int64_t q, int &ix, int &iy, int &iz)
+{
+    const uint32_t nx = (uint32_t)G.nx, qq = (uint32_t)q;          // N < 2^31 (checked by the launcher)
+    const uint32_t r = qq / nx, lx = qq - r * nx, lz = r / nx, ly = r - lz * nx;
+    ix = G.off + (int)lx; iy = G.off + (int)ly; iz = G.zs + (int)lz;
+    return ((int64_t)(iz - G.z0) * G.res + iy) * G.res + ix;
 }
 
 __device__ __forceinline__ int64_t uniform64(int64_t v)
@@ -144,7 +180,6 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *Xs = reinterpret_cast<float *>(smem + kXsOff);
-    int *wsum = reinterpret_cast<int *>(smem + kMiscOff);
 
     // ---- once per workgroup: resident layer-0 operands, side arrays, sign-list geometry ------------------
     issue_units(w.image, smem + kW0Off, kW0Bytes / 1024, wave0, lane0);
@@ -173,35 +208,29 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         asm volatile("" : "+v"(tid));
         const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int j = lane & 31, h = lane >> 5;
-        // ---- feature phase: waves 0-3, one point per thread -> Xs[t][16] ---------------------------------
+        // ---- feature phase: waves 0-3, one work item per thread -> Xs[t][16] -----------------------------
         const int t = tid;
         const bool worker = t < kTilePts;                       // wave-uniform
-        int64_t i = tile * kTilePts + (worker ? t : 0);
-        const bool live = i < G.N;
-        if (!live) i = G.N - 1;
-        uint32_t code = 0;
-        int slot = 0;
-        float d2 = 0.0f;
-        bool outl = false;
-        if (PRIOR == ICON_PRIOR_ICON) {
-            if (worker) {
-                code = G.code8[i];
-                slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar);
-                if (!(code & kCodeOutlier)) d2 = G.near_d2[i];      // an outlier's sdf is its sign
-                outl = live && (code & kCodeOutlier);
+        int64_t q = tile * kTilePts + (worker ? t : 0);
+        if (q >= G.N) q = G.N - 1;                               // padding lanes of the last tile recompute its last item
+        if (worker) {
+            // work item -> point: its world position p and its index i in the linear order of the call
+            f3 p;
+            int64_t i;
+            if (LATTICE) {
+                int ix, iy, iz;
+                i = lattice_item(G, q, ix, iy, iz);
+                p = lattice_world(G.res, ix, iy, iz);
+            } else {
+                i = q;
+                p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
             }
-            const unsigned long long b = __ballot(outl);
-            if (worker && lane == 0) wsum[wave] = __popcll(b);
-            __syncthreads();
-            if (worker) {
-                f3 p;
-                if (LATTICE) {
-                    const int64_t row = i / G.res;
-                    p = lattice_world(G.res, (int)(i - row * G.res), (int)(row % G.res), (int)(row / G.res) + G.z0);
-                } else {
-                    p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
-                }
-                Nearest nr; nr.slot = slot; nr.d2 = d2; nr.face = 0;
+            float *xrow = Xs + t * kXRow;
+            if (PRIOR == ICON_PRIOR_ICON) {
+                const uint32_t code = G.code8[i];
+                Nearest nr;
+                nr.slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar); nr.face = 0;
+                nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near_d2[i];    // an outlier's sdf is its sign
                 const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
                 float s = o.sdf;
                 f3 cmv = o.cm;
@@ -209,10 +238,15 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
                     s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
                     if (G.cmap_local) cmv = mk3(s, s, s);
                     else if (K > 0) {
-                        int before = 0;
-                        for (int k = 0; k < wave; ++k) before += wsum[k];
-                        before += __popcll(b & ((1ull << lane) - 1ull));
-                        const int64_t jr = rank0 + G.tile_offsets[tile] + before;
+                        // rank among the call's outliers: scan over 256-point blocks + ballots of the 64-point groups
+                        const int64_t blk = i >> 8;
+                        const int g = (int)(i >> 6) & 3;
+                        const unsigned long long *mk = G.grp_mask + blk * 4;
+                        int before = __popcll(mk[g] & ((1ull << (i & 63)) - 1ull));
+                        if (g > 0) before += __popcll(mk[0]);
+                        if (g > 1) before += __popcll(mk[1]);
+                        if (g > 2) before += __popcll(mk[2]);
+                        const int64_t jr = rank0 + G.block_offsets[blk] + before;
                         float c3[3];
 #pragma unroll
                         for (int k = 0; k < 3; ++k) {
@@ -226,24 +260,13 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
                 }
                 // the row goes to LDS slot by slot (no 16-wide register tuple next to the MFMA accumulators);
                 // slots >= c0 are never read as data (masked by index in the MLP part), slot 15 = in_cube flag
-                float *xrow = Xs + t * kXRow;
                 gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
                 const int hh = G.f.csel;
                 xrow[hh] = s;
                 xrow[hh + 1] = cmv.x; xrow[hh + 2] = cmv.y; xrow[hh + 3] = cmv.z;
                 xrow[hh + 4] = o.nrm.x; xrow[hh + 5] = o.nrm.y; xrow[hh + 6] = o.nrm.z;
                 xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
-            }
-        } else {
-            if (worker) {
-                f3 p;
-                if (LATTICE) {
-                    const int64_t row = i / G.res;
-                    p = lattice_world(G.res, (int)(i - row * G.res), (int)(row % G.res), (int)(row / G.res) + G.z0);
-                } else {
-                    p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
-                }
-                float *xrow = Xs + t * kXRow;
+            } else {
                 gather_planes_dyn(G.f, 0, p.x, p.y, xrow);
                 const int hh = G.f.csel;
                 if (PRIOR == ICON_PRIOR_PAMIR) {
@@ -312,8 +335,13 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
         const float other = __shfl_xor(part, 32);
         const float y = (part + other) + w.b3;
-        const int64_t oi = tile * kTilePts + pt;
-        if (h == 0 && oi < G.N) out[oi] = maskf * y;
+        // where this point's occupancy goes is re-derived from the work item (a handful of integer instructions):
+        // nothing lane-dependent lives across the MFMA body
+        const int64_t oq = tile * kTilePts + pt;
+        if (h == 0 && oq < G.N) {
+            int ix, iy, iz;
+            out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : oq] = maskf * y;
+        }
     }
 }
 
@@ -334,27 +362,74 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
 {
     const int64_t nb = (N + 255) / 256;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    // box distance^2 beyond which |sdf| = d / sqrt(3) >= sdf_clip for certain (d >= box distance; the computed d^2 is
-    // within 1e-6 relative of the true one): (clip sqrt(3))^2 with a cushion.  Negative clips: every point off the box.
-    const float cb = std::max(sdf_clip, 0.0f) * 1.7320508f;
-    const float far_box2 = cb * cb * 1.0001f + 1e-6f;
+    const float far_box2 = far_box_dist2(sdf_clip);
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts, far_box2);
+                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts,
+                                    (unsigned long long *)work->d_grp_mask, far_box2);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts, far_box2);
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts,
+                            (unsigned long long *)work->d_grp_mask, far_box2);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
 
+// ---- per-device launch facts --------------------------------------------------------------------------
+// A process may drive several devices (one image per GPU from one process, threads): the CU count and the
+// "dynamic LDS attribute has been set" flags are per device, guarded by one mutex (touched once per launch).
+namespace {
+constexpr int kMaxDevices = 64, kMaxKernelIds = 16;
+std::mutex g_dev_mutex;
+int g_n_cu[kMaxDevices];
+bool g_attr_set[kMaxKernelIds][kMaxDevices];
+}  // namespace
+
+int device_cu_count(int *n_cu)
+{
+    int dev = 0;
+    ICON_HIP(hipGetDevice(&dev));
+    ICON_ARG(dev >= 0 && dev < kMaxDevices, "device index out of range");
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    if (!g_n_cu[dev]) {
+        int n = 0;
+        ICON_HIP(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+        g_n_cu[dev] = n > 0 ? n : 256;
+    }
+    *n_cu = g_n_cu[dev];
+    return ICON_OK;
+}
+
+bool first_use_on_device(int kernel_id)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || kernel_id < 0 || kernel_id >= kMaxKernelIds) return true;
+    std::lock_guard<std::mutex> lk(g_dev_mutex);
+    const bool first = !g_attr_set[kernel_id][dev];
+    g_attr_set[kernel_id][dev] = true;
+    return first;
+}
+
 int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_mlp *mlp, int prior, const Calib &cal,
-                       int res, int z0, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
+                       const LatticeMap &L, int za, int zb, const float *d_points, int64_t N, float sdf_clip, int cmap_local,
                        const icon_work *work, const FusedSigns &fs, float *d_occ, bool lattice, hipStream_t st)
 {
-    if (N <= 0) return ICON_OK;
     FusedGeom G{};
     if (mesh) G.m = mesh->dev;
-    G.f = feat->dev; G.cal = cal; G.res = res; G.z0 = z0; G.pts = d_points; G.N = N; G.sdf_clip = sdf_clip; G.cmap_local = cmap_local;
-    G.near_slot = work_near_slot(work); G.near_d2 = work_near_d2(work); G.code8 = work->d_code8; G.tile_offsets = work->d_block_offsets;
+    G.f = feat->dev; G.cal = cal; G.pts = d_points; G.sdf_clip = sdf_clip; G.cmap_local = cmap_local;
+    if (lattice) {
+        // planes [za, zb) of the slab, minus the z shell when it is skipped; x / y interior likewise
+        const int zs = std::max(za, L.off), ze = std::min(zb, L.res - L.off);
+        if (L.off) {
+            const int64_t rows = (int64_t)(zb - za) * L.res;
+            if (rows > 0) hipLaunchKernelGGL(k_shell_zero, dim3((unsigned)rows), dim3(64), 0, st, d_occ, L.res, L.z0, za, zb);
+        }
+        G.res = L.res; G.z0 = L.z0; G.off = L.off; G.nx = L.res - 2 * L.off; G.zs = zs;
+        N = (ze > zs) ? (int64_t)(ze - zs) * G.nx * G.nx : 0;
+    }
+    if (N <= 0) { ICON_HIP(hipGetLastError()); return ICON_OK; }
+    ICON_ARG(N < (1ll << 31), "fused: more than 2^31 points in one call");
+    G.N = N;
+    G.near_slot = work_near_slot(work); G.near_d2 = work_near_d2(work); G.code8 = work->d_code8;
+    G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;
     if (fs.mode == kSignSeg) {
@@ -367,28 +442,21 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
 
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        ICON_HIP(hipGetDevice(&dev));
-        ICON_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if (n_cu <= 0) n_cu = 256;
-    }
+    int n_cu = 0;
+    const int rc = device_cu_count(&n_cu);
+    if (rc) return rc;
     const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
-#define ICON_FUSED(P, L)                                                                                                   \
+#define ICON_FUSED(P, L_, ID)                                                                                              \
     do {                                                                                                                   \
-        static bool attr = false;                                                                                          \
-        if (!attr) {                                                                                                       \
-            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L>),                                \
+        if (first_use_on_device(ID))                                                                                       \
+            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));                          \
-            attr = true;                                                                                                   \
-        }                                                                                                                  \
-        hipLaunchKernelGGL((k_fused_f16x3<P, L>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);                \
+        hipLaunchKernelGGL((k_fused_f16x3<P, L_>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);               \
     } while (0)
-    if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true); else ICON_FUSED(ICON_PRIOR_ICON, false); }
-    else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true); else ICON_FUSED(ICON_PRIOR_PAMIR, false); }
-    else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true); else ICON_FUSED(ICON_PRIOR_PIFU, false); }
+    if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }
+    else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true, 2); else ICON_FUSED(ICON_PRIOR_PAMIR, false, 3); }
+    else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true, 4); else ICON_FUSED(ICON_PRIOR_PIFU, false, 5); }
 #undef ICON_FUSED
     ICON_HIP(hipGetLastError());
     return ICON_OK;

@@ -191,6 +191,14 @@ __device__ __forceinline__ void load_tri_full(const TriRec *t, f3 &a, f3 &b, f3 
     ia = __float_as_int(q2.y); ib = __float_as_int(q2.z); ic = __float_as_int(q2.w);
 }
 
+// box distance^2 beyond which |sdf| = d / sqrt(3) >= sdf_clip for certain (d >= box distance; the computed d^2 is
+// within 1e-6 relative of the true one): (clip sqrt(3))^2 with a cushion.  Negative clips: every point off the box.
+__host__ __device__ inline float far_box_dist2(float sdf_clip)
+{
+    const float cb = (sdf_clip > 0.0f ? sdf_clip : 0.0f) * 1.7320508f;
+    return cb * cb * 1.0001f + 1e-6f;
+}
+
 __device__ __forceinline__ float box_dist2(float lx, float ly, float lz, float hx, float hy, float hz, f3 p)
 {
     const float dx = fmaxf(fmaxf(lx - p.x, p.x - hx), 0.0f);
@@ -234,12 +242,18 @@ __device__ __forceinline__ float prune_threshold(float best)
 // A leaf holds up to 4 TriPre records (96 B each, scalar loads); the distance test has no per-lane branch (one
 // wave-uniform skip of the face term).  Near child first, ordered by the block's centre lane.
 // `live` = false parks a padding lane: it never votes and its result is discarded.
-template <bool STATS = false>
+// TIES: also track the runner-up - the smallest key that differs from the winner's (a padding copy of a short leaf
+// carries the key of its original and is therefore never its own runner-up).  Every face whose d^2 lies within
+// the pruning bound of the final winner is visited (the bound only ever shrinks towards its final value), so the
+// runner-up is exact whenever it is within ~8e-5 relative of the winner - far beyond the 255 ulps reported.
+template <bool STATS = false, bool TIES = false>
 __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
-                                                  int *n_nodes = nullptr, int *n_tris = nullptr, float thr0 = INFINITY)
+                                                  int *n_nodes = nullptr, int *n_tris = nullptr, float thr0 = INFINITY,
+                                                  unsigned long long *runner_up = nullptr)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
     unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
+    unsigned long long key2 = 0x7f8000007fffffffull;
     float thr = live ? thr0 : -INFINITY;
     int sp = 0;
     int cur = 0;
@@ -261,8 +275,13 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
                 // (the winner's slot is looked up from its face id at the end: nothing else to carry per test; a parked
                 //  lane computes on a clamped copy of a real point and may update its key freely - it never votes
                 //  (thr = -inf) and its result is not stored - so the update needs no `live` mask)
-                key = (k0 < key) ? k0 : key;
-                key = (k1 < key) ? k1 : key;
+                if (TIES) {
+                    if (k0 < key) { key2 = key; key = k0; } else if (k0 != key && k0 < key2) key2 = k0;
+                    if (k1 < key) { key2 = key; key = k1; } else if (k1 != key && k1 < key2) key2 = k1;
+                } else {
+                    key = (k0 < key) ? k0 : key;
+                    key = (k1 < key) ? k1 : key;
+                }
             }
             nr.d2 = __int_as_float((int)(key >> 32));
             thr = live ? prune_threshold(nr.d2) : thr;           // one fma + select: cheaper than finding out whether the key moved
@@ -293,6 +312,58 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
     }
     nr.d2 = __int_as_float((int)(key >> 32)); nr.face = (int)(key & 0xffffffffu);
     nr.slot = (nr.face != 0x7fffffff) ? m.face2slot[nr.face] : 0;
+    if (TIES) *runner_up = key2;
+    return nr;
+}
+
+// Diagnostics - the ALTERNATIVE tie rule: among the faces whose d^2 lies within `ulps` float32 ulps of the minimum
+// `best_bits` (found by a first nearest_packet pass), the one with the HIGHEST face index, together with its own
+// d^2.  ulps = 0 is "highest index on exact ties" - the mirror image of S3; ulps >= 1 stands for any other
+// correctly-rounding implementation of the same point-triangle distance (kaolin's), whose last bits decide between
+// the mathematically tied triangles around a vertex or an edge differently.  Same boxes, same S2 distance, same
+// pruning bound (now constant) as nearest_packet.
+__device__ __forceinline__ Nearest nearest_packet_alt(const MeshDev &m, f3 p, bool live, int *wstack, uint32_t best_bits, uint32_t ulps)
+{
+    const float thr = live ? prune_threshold(__int_as_float((int)best_bits)) : -INFINITY;
+    const uint32_t lim = best_bits + ulps;                 // d^2 >= 0: bit patterns order like the values
+    int face = -1;
+    uint32_t fbits = best_bits;
+    int sp = 0, cur = 0;                                   // the root is always node 0 (mesh_build.cpp)
+    while (true) {
+        if (cur < 0) {
+            const int code = ~cur;
+            const int leaf = code >> 2, cnt = (code & 3) + 1;
+            const int npairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);
+            for (int pr = 0; pr < npairs; ++pr) {
+                cf2 *q = reinterpret_cast<cf2 *>(as_const(&m.leaves[leaf].pair[pr]));
+                const f2 d2 = tri_dist2_pair(p, q);
+                const f2 fc = q[22];
+                const uint32_t b0 = (uint32_t)__float_as_int(d2.x), b1 = (uint32_t)__float_as_int(d2.y);
+                const int f0 = __float_as_int(fc.x), f1 = __float_as_int(fc.y);
+                if (b0 <= lim && f0 > face) { face = f0; fbits = b0; }
+                if (b1 <= lim && f1 > face) { face = f1; fbits = b1; }
+            }
+            if (sp == 0) break;
+            cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
+        } else {
+            cf2 *q = reinterpret_cast<cf2 *>(as_const(m.nodes + cur));
+            const f2 dd = box_dist2_pair(q, p);
+            const f2 ids = q[6];
+            const int c0 = __float_as_int(ids.x), c1 = __float_as_int(ids.y);
+            const bool v0 = __any(dd.x <= thr), v1 = __any(dd.y <= thr);
+            if (v0 && v1) { wstack[sp++] = c1; cur = c0; }
+            else if (v0) cur = c0;
+            else if (v1) cur = c1;
+            else {
+                if (sp == 0) break;
+                cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
+            }
+        }
+    }
+    Nearest nr;
+    nr.face = face >= 0 ? face : 0x7fffffff;
+    nr.d2 = __int_as_float((int)fbits);
+    nr.slot = face >= 0 ? m.face2slot[face] : 0;
     return nr;
 }
 
@@ -678,10 +749,17 @@ __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int 
     const int rem = t - bty * (L.tz * L.tx);
     const int btz = rem / L.tx, btx = rem - btz * L.tx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    ix = btx * 16 + wave * 4 + (lane & 3);
-    iy = bty * 4 + ((lane >> 2) & 3);
-    iz = btz * 4 + (lane >> 4);
-    return ix < L.res && iy < L.res && iz < L.nz;
+    // tiles cover the search region [sx0, sx1) x [sy0, sy1) x planes [sz0, sz1) (iz is relative to the slab)
+    ix = L.sx0 + btx * 16 + wave * 4 + (lane & 3);
+    iy = L.sy0 + bty * 4 + ((lane >> 2) & 3);
+    iz = L.sz0 + btz * 4 + (lane >> 4);
+    return ix < L.sx1 && iy < L.sy1 && iz < L.sz1;
+}
+
+// a padding lane of a boundary tile works on a clamped copy of a real point of the region
+__device__ __forceinline__ void lattice_clamp(const LatticeMap &L, int ix, int iy, int iz, int &cx, int &cy, int &cz)
+{
+    cx = min(ix, L.sx1 - 1); cy = min(iy, L.sy1 - 1); cz = min(iz, L.sz1 - 1);
 }
 
 __device__ __forceinline__ f3 lattice_world(int res, int ix, int iy, int iz)

@@ -224,11 +224,9 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
     const int64_t nb = (N + kF16Pts - 1) / kF16Pts;
     ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
-    static bool attr_set = false;
-    if (!attr_set) {
+    if (first_use_on_device(6)) {          // per device: a process may drive several (common.h)
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f16x3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
-        attr_set = true;
     }
     if (mask) hipLaunchKernelGGL(k_mlp_f16x3<true>, dim3((unsigned)nb), dim3(kF16Block), kLdsBytes, st, d_x, N, d_out, w);
     else      hipLaunchKernelGGL(k_mlp_f16x3<false>, dim3((unsigned)nb), dim3(kF16Block), kLdsBytes, st, d_x, N, d_out, w);

@@ -610,13 +610,9 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
     if (want_trace) { ICON_HIP(hipMalloc((void **)&w.trace, 8 * 64 * 8)); ICON_HIP(hipMemsetAsync(w.trace, 0, 8 * 64 * 8, st)); }
     const int64_t nt = (N + kMxPts - 1) / kMxPts;
     ICON_ARG(nt < (1ll << 31), "mlp: N too large for one launch");
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        ICON_HIP(hipGetDevice(&dev));
-        ICON_HIP(hipGetDeviceProperties(&prop, dev));
-        n_cu = prop.multiProcessorCount;
+    int n_cu = 0;
+    { const int rc = device_cu_count(&n_cu); if (rc) return rc; }
+    if (first_use_on_device(7)) {          // per device: a process may drive several (common.h)
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
     }

@@ -84,17 +84,20 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
 // full occupancy (8 waves / SIMD hide the dependent scalar-load chain), which the register-heavier
 // attribute / gather code would cap at 5.  Output per point, structure of arrays: the slot of the nearest
 // triangle with the "outside the clip band" flag, and - inside the band only - its squared distance (store_near).
-template <bool LATTICE>
+// ALT (diagnostics, icon_work_set_tie_rule): the alternative tie rule - highest face index among the faces within
+// `tie_ulps` float32 ulps of the minimum d^2 (nearest_packet_alt) - for measuring how much of the output hangs on
+// the unpinned tie behaviour of the kaolin leaf (lib/dataset/mesh_util.py:374-390).
+template <bool LATTICE, bool ALT = false>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
                                                     int32_t *__restrict__ near_slot, float *__restrict__ near_d2, const int32_t *__restrict__ perm,
-                                                    float sdf_clip)
+                                                    float sdf_clip, int tie_ulps)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
     if (LATTICE) {
-        int ix, iy, iz;
+        int ix, iy, iz, cx, cy, cz;
         live = lattice_point(L, ix, iy, iz);
-        const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+        lattice_clamp(L, ix, iy, iz, cx, cy, cz);
         p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
     } else {
@@ -104,10 +107,32 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         if (perm) i = perm[i];          // Morton order: the wave's 64 points are neighbours (sort_points.hip)
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     }
-    const Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+    Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+    if (ALT) nr = nearest_packet_alt(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, (uint32_t)__float_as_int(nr.d2), (uint32_t)tie_ulps);
     // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
     //  writes but the block-wide barrier costs 0.14 ms; not kept)
     if (live) store_near(near_slot, near_d2, i, nr, sdf_clip);
+}
+
+// Diagnostics (icon_sdf_query_ties): winner, runner-up and the ulp gap between their squared distances
+__global__ __launch_bounds__(kBlock) void k_nearest_ties(MeshDev m, const float *__restrict__ pts, int64_t N, const int32_t *__restrict__ perm,
+                                                         int32_t *__restrict__ face, int32_t *__restrict__ face2, uint8_t *__restrict__ ulps)
+{
+    __shared__ int lds[(kBlock / 64) * kStackDepth];
+    int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    const bool live = i < N;
+    if (!live) i = N - 1;
+    if (perm) i = perm[i];
+    const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    unsigned long long k2 = 0;
+    const Nearest nr = nearest_packet<false, true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, nullptr, nullptr, INFINITY, &k2);
+    if (!live) return;
+    const uint32_t b1 = (uint32_t)__float_as_int(nr.d2), b2 = (uint32_t)(k2 >> 32);
+    const int f2 = (int)(k2 & 0xffffffffu);
+    const bool has2 = f2 != 0x7fffffff && b2 >= b1;
+    face[i] = nr.face;
+    face2[i] = has2 ? f2 : -1;
+    ulps[i] = (uint8_t)(has2 ? min(b2 - b1, 255u) : 255u);
 }
 
 // Feature assembly: one 16-float row per point,
@@ -120,16 +145,32 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
                                                      float sdf_clip, int cmap_local,
                                                      const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
                                                      const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2,
-                                                     float *__restrict__ X, uint8_t *__restrict__ code8)
+                                                     float *__restrict__ X, uint8_t *__restrict__ code8, int skip_shell)
 {
     __shared__ int lds[(PRIOR == ICON_PRIOR_ICON && BRUTE) ? kBruteTile * 24 : 1];
     int64_t i; bool live; f3 p;
     if (LATTICE) {
-        int ix, iy, iz;
+        // L tiles the WHOLE slab here (every point gets a row); skip_shell: the geometry pre-pass left the shell out
+        int ix, iy, iz, cx, cy, cz;
         live = lattice_point(L, ix, iy, iz);
-        const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+        lattice_clamp(L, ix, iy, iz, cx, cy, cz);
         p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
+        if (skip_shell && !in_cube_bit(p)) {
+            // a shell point: multiplied by 0 whatever its row holds (in_cube, HGPIFuNet.py:363) - a zero row and the code
+            // byte k_sign wrote (icon) / in_cube = 0, without touching the search results that do not exist for it
+            if (live) {
+                float z[kXRow];
+#pragma unroll
+                for (int k = 0; k < kXRow; ++k) z[k] = 0.0f;
+                uint32_t c = 0;
+                if (PRIOR == ICON_PRIOR_ICON) c = code8[i];
+                z[kCodeSlot] = __int_as_float((int)c);
+                store_row(X, i, z);
+                if (PRIOR != ICON_PRIOR_ICON) code8[i] = (uint8_t)c;
+            }
+            return;
+        }
     } else {
         i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
         live = i < N;
@@ -193,9 +234,9 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
 __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMap L, unsigned long long *out /* [4] */, int seeded)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
-    int ix, iy, iz;
+    int ix, iy, iz, cx, cy, cz;
     const bool live = lattice_point(L, ix, iy, iz);
-    const int cx = min(ix, L.res - 1), cy = min(iy, L.res - 1), cz = min(iz, L.nz - 1);
+    lattice_clamp(L, ix, iy, iz, cx, cy, cz);
     const f3 p = lattice_world(L.res, cx, cy, cz + L.z0);
     int nn = 0, nt = 0;
     Nearest nr = nearest_packet<true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, &nn, &nt);
@@ -401,9 +442,25 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_patch_seg(float *__restr
             if (mm >= K) mm -= K;
             int r = 0;
             while (mm >= off[r + 1]) ++r;
-            row[k] = (float)gathered[(int64_t)r * stride + 8 + (mm - off[r])];
+            const int64_t e = mm - off[r];                      // 2 bits per sign (sign + 1), four to a byte
+            const uint32_t byte = (uint8_t)gathered[(int64_t)r * stride + 8 + (e >> 2)];
+            row[k] = (float)((int)((byte >> (2 * (int)(e & 3))) & 3u) - 1);
         }
     }
+}
+
+// sign message of the multi-GPU exchange: [int64 K][K signs, 2 bits each (sign + 1), four to a byte, zero padded]
+__global__ __launch_bounds__(256) void k_pack_signs(const int8_t *__restrict__ signs, const int64_t *__restrict__ k_dev, uint8_t *__restrict__ msg, int64_t cap_bytes)
+{
+    const int64_t K = *k_dev;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t == 0) *reinterpret_cast<int64_t *>(msg) = K;
+    if (t >= cap_bytes || 4 * t >= K) return;
+    uint32_t b = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (4 * t + j < K) b |= (uint32_t)(signs[4 * t + j] + 1) << (2 * j);
+    msg[8 + t] = (uint8_t)b;
 }
 
 // repack feature planes [C][H][W] -> [n_select][H][W][cpad] (channel-last, zero padded)
@@ -518,7 +575,7 @@ extern "C" int icon_work_create(icon_work_t **out)
 extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
-    (void)hipFree(w->d_x); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
+    (void)hipFree(w->d_x); (void)hipFree(w->d_grp_mask); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
@@ -598,6 +655,8 @@ int ensure_work(icon_work *w, int64_t n_points, bool need_x)
     if (nblk > w->cap_blocks) {
         (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
         w->d_block_counts = nullptr; w->d_block_offsets = nullptr; w->d_scan_local = nullptr; w->d_scan_part = nullptr; w->cap_blocks = 0;
+        (void)hipFree(w->d_grp_mask); w->d_grp_mask = nullptr;
+        ICON_HIP(hipMalloc((void **)&w->d_grp_mask, (size_t)nblk * 4 * sizeof(uint64_t)));
         ICON_HIP(hipMalloc((void **)&w->d_block_counts, (size_t)nblk * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&w->d_block_offsets, (size_t)nblk * sizeof(int64_t)));
         ICON_HIP(hipMalloc((void **)&w->d_scan_local, (size_t)nblk * sizeof(int32_t)));
@@ -654,23 +713,25 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     }
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
-    ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
+    ICON_ARG(nb >= 0 && nb < (1ll << 31), "too many workgroups for one launch");
     int32_t *near_slot = work_near_slot(work);
     float *near_d2 = work_near_d2(work);
     // point mode: sparse batches walk the tree one wavefront per point; a batch dense enough for a wave's 64
     // Morton neighbours to be close together goes through the packet kernel
     const int32_t *perm = nullptr;
     static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
-    if (!LATTICE && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
+    const bool alt = work->tie_rule != 0;        // diagnostics: the alternative tie rule lives in the packet kernel only
+    if (!LATTICE && !alt && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
         const int cap = coop_cap((int)mesh->stats[1]);
         hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
                            kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near_slot, near_d2, cap, sdf_clip);
-    } else {
+    } else if (nb > 0) {                         // nb == 0: a slab that is all shell (nothing to search)
         if (!LATTICE) {
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_nearest<LATTICE>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip);
+        if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip, work->tie_ulps);
+        else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip, 0);
     }
     ICON_HIP(hipGetLastError());
     return launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
@@ -682,14 +743,21 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
                     const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, int search,
                     icon_work *work, hipStream_t st)
 {
+    // every point of the slab gets a row: tile the whole slab, whatever region the geometry pre-pass covered
+    LatticeMap Lf = L;
+    const int skip_shell = L.off;
+    if (LATTICE) {
+        Lf.sx0 = Lf.sy0 = Lf.sz0 = 0; Lf.sx1 = Lf.sy1 = L.res; Lf.sz1 = L.nz;
+        Lf.tx = (L.res + 15) / 16; Lf.ty = (L.res + 3) / 4; Lf.tz = (L.nz + 3) / 4;
+    }
     int64_t nb;
-    if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
+    if (LATTICE) nb = (int64_t)Lf.tx * Lf.ty * Lf.tz; else nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
     const dim3 grid((unsigned)nb), block(kBlock);
     const MeshDev md = mesh ? mesh->dev : MeshDev{};
     const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
     const bool brute = (search == ICON_SEARCH_BRUTE);
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, L, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_x, work->d_code8)
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, Lf, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_x, work->d_code8, skip_shell)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);
@@ -724,6 +792,7 @@ int patch_self(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
 // The f16x3 precision (the default) with the BVH search runs FUSED: no input rows in HBM (fused_f16x3.hip).
 // ICON_AMD_UNFUSED=1 forces the materialising path (tests compare the two bit for bit).
 int g_unfused = -1;      // -1: read ICON_AMD_UNFUSED once; 0 / 1: set by icon_debug_set_unfused
+int g_shell_skip = -1;   // -1: read ICON_AMD_SHELL_SKIP once (default on); 0 / 1: set by icon_debug_set_shell_skip
 inline bool want_fused(int precision, int search)
 {
     if (g_unfused < 0) g_unfused = (getenv("ICON_AMD_UNFUSED") && atoi(getenv("ICON_AMD_UNFUSED")) != 0) ? 1 : 0;
@@ -742,7 +811,7 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
     int rc;
     work->q_mesh = mesh; work->q_feat = feat; work->q_prior = prior; work->q_sdf_clip = sdf_clip; work->q_cmap_mode = cmap_mode;
     work->q_cal = cal; work->q_L = L; work->q_points = d_points; work->q_N = N; work->q_search = search; work->q_lattice = LATTICE;
-    work->q_rows_ready = false;
+    work->q_rows_ready = false; work->slab_patched = false;
     work->slab_needs_patch = (prior == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
     work->slab_cmap_slot = feat->dev.csel + 1;
     if (prior != ICON_PRIOR_ICON) return ICON_OK;
@@ -761,16 +830,20 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
 }
 
 // Phase 2: the MLP input of every point and the MLP itself, given where the call's outlier signs are.
-int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precision, icon_work *work, hipStream_t st)
+// Lattice calls evaluate the planes [za, zb) of the prepared slab into the SLAB's buffer d_occ (several calls may
+// cover a slab piece by piece: the multi-GPU driver gathers the first half while the second is computed).
+int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precision, icon_work *work, hipStream_t st, int za = 0, int zb = 0)
 {
     int rc;
     const int prior = work->q_prior;
     const int64_t N = work->q_N;
     const bool fused = want_fused(precision, work->q_search);
     const int local = (work->q_cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
+    const LatticeMap &L = work->q_L;
+    const bool first = !work->q_lattice || za == L.z0;
     if (fused) {
-        mark(work, 2, st);
-        rc = launch_fused_f16x3(work->q_mesh, work->q_feat, mlp, prior, work->q_cal, work->q_L.res, work->q_L.z0, work->q_points, N,
+        if (first) mark(work, 2, st);
+        rc = launch_fused_f16x3(work->q_mesh, work->q_feat, mlp, prior, work->q_cal, L, za, zb, work->q_points, N,
                                 work->q_sdf_clip, local, work, fs, d_occ, work->q_lattice, st);
         mark(work, 3, st);
         return rc;
@@ -782,8 +855,9 @@ int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precis
                              : launch_features<false>(work->q_mesh, work->q_feat, prior, work->q_sdf_clip, work->q_cmap_mode, work->q_cal, work->q_L,
                                                       work->q_points, N, work->q_search, work, st);
         if (rc) return rc;
+        work->q_rows_ready = true;
     }
-    if (work->slab_needs_patch) {
+    if (work->slab_needs_patch && !work->slab_patched) {
         const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
         if (fs.mode == kSignSelf) {
             if ((rc = patch_self(work, N, work->slab_cmap_slot, st))) return rc;
@@ -796,9 +870,15 @@ int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precis
                                work->d_block_offsets, fs.gathered, fs.stride, fs.world, fs.rank);
         }
         ICON_HIP(hipGetLastError());
+        work->slab_patched = true;
     }
-    mark(work, 2, st);
-    rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    if (first) mark(work, 2, st);
+    if (work->q_lattice) {
+        const int64_t o = (int64_t)(za - L.z0) * L.res * L.res, n = (int64_t)(zb - za) * L.res * L.res;
+        rc = mlp_launch(mlp, work->d_x + o * kXRow, n, d_occ + o, precision, st);
+    } else {
+        rc = mlp_launch(mlp, work->d_x, N, d_occ, precision, st);
+    }
     mark(work, 3, st);
     return rc;
 }
@@ -864,12 +944,38 @@ extern "C" int icon_query_points_dcalib(const icon_mesh_t *mesh, const icon_feat
                              precision, work, stream);
 }
 
-static int lattice_map(int res, int z0, int z1, LatticeMap *L)
+// Lattice geometry of a slab.  `shell_ok`: the caller allows the shell skip (everything but the brute-force search,
+// which computes its own rows for every point).  The MLP then never sees the shell (in_cube alone makes it 0); the
+// SEARCH leaves out every face of the cube that is provably all "outside" outliers without looking at the mesh -
+// farther from the body's bounding box than the clip band is wide, k_sign's own far test - and keeps the others: a
+// shell point is an entry of the call's outlier sign list and its code byte must be right.
+static int lattice_map(int res, int z0, int z1, const icon_mesh_t *mesh, float sdf_clip, bool shell_ok, LatticeMap *L)
 {
     ICON_ARG(res >= 3 && (res & 1) == 1, "lattice resolution must be odd and >= 3 (seg3d_lossless.py:84-86)");
     ICON_ARG(z0 >= 0 && z1 > z0 && z1 <= res, "bad z range");
     L->res = res; L->z0 = z0; L->nz = z1 - z0;
-    L->tx = (res + 15) / 16; L->ty = (res + 3) / 4; L->tz = (L->nz + 3) / 4;
+    if (g_shell_skip < 0) g_shell_skip = getenv("ICON_AMD_SHELL_SKIP") ? (atoi(getenv("ICON_AMD_SHELL_SKIP")) != 0) : 1;   // 0: evaluate and mask the shell (A/B runs)
+    const int off = (shell_ok && g_shell_skip) ? 1 : 0;
+    L->off = off;
+    L->zs = std::max(z0, off); L->nzi = std::min(z1, res - off) - L->zs;
+    if (L->nzi < 0) L->nzi = 0;
+    // search region: the whole slab, minus the far faces
+    int lo[3] = {0, 0, 0}, hi[3] = {res, res, res};       // lattice index ranges in x, y, z
+    if (off && mesh) {
+        const MeshDev &m = mesh->dev;
+        const float need = std::sqrt(far_box_dist2(sdf_clip)) * 1.001f + 1e-5f;
+        // lattice_world: x = -1 at ix = 0, +1 at ix = res-1; y = +1 at iy = 0, -1 at iy = res-1; z like x
+        if (m.box_lo[0] + 1.0f > need) lo[0] = 1;
+        if (1.0f - m.box_hi[0] > need) hi[0] = res - 1;
+        if (1.0f - m.box_hi[1] > need) lo[1] = 1;
+        if (m.box_lo[1] + 1.0f > need) hi[1] = res - 1;
+        if (m.box_lo[2] + 1.0f > need) lo[2] = 1;
+        if (1.0f - m.box_hi[2] > need) hi[2] = res - 1;
+    }
+    L->sx0 = lo[0]; L->sx1 = hi[0]; L->sy0 = lo[1]; L->sy1 = hi[1];
+    L->sz0 = std::max(z0, lo[2]) - z0; L->sz1 = std::min(z1, hi[2]) - z0;
+    if (L->sz1 < L->sz0) L->sz1 = L->sz0;
+    L->tx = (L->sx1 - L->sx0 + 15) / 16; L->ty = (L->sy1 - L->sy0 + 3) / 4; L->tz = (L->sz1 - L->sz0 + 3) / 4;
     const char *e = getenv("ICON_AMD_XCD_REMAP");
     // 0: single blocks alternate over the XCDs (default, fastest); 2: whole x-rows of blocks per XCD - 14 % fewer HBM
     // write bytes (partial lines meet in one L2) but 1.5 % slower; 1: contiguous XCD bands, 1.6x slower
@@ -877,19 +983,20 @@ static int lattice_map(int res, int z0, int z1, LatticeMap *L)
     return ICON_OK;
 }
 
-extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
-                                       int prior_type, float sdf_clip, int cmap_mode,
-                                       int res, int z0, int z1, int8_t *d_signs_local, int64_t *d_count_local,
-                                       int search, icon_work_t *work, void *stream)
+static int slab_features_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_type, float sdf_clip, int cmap_mode,
+                              int res, int z0, int z1, int8_t *d_signs_local, int64_t *d_count_local, void *d_msg, int64_t msg_bytes,
+                              int search, icon_work_t *work, void *stream)
 {
     ICON_ARG(work != nullptr, "icon_grid_slab_features: work is null");
     int c0 = 0;
     int rc = check_prior(mesh, feat, prior_type, &c0);
     if (rc) return rc;
     LatticeMap L;
-    if ((rc = lattice_map(res, z0, z1, &L))) return rc;
+    // the brute-force path computes rows for every point itself; everything else may skip the shell
+    if ((rc = lattice_map(res, z0, z1, prior_type == ICON_PRIOR_ICON ? mesh : nullptr, sdf_clip, search != ICON_SEARCH_BRUTE, &L))) return rc;
     hipStream_t st = (hipStream_t)stream;
     const int64_t N = (int64_t)L.nz * res * res;
+    ICON_ARG(N < (1ll << 31), "icon_grid_slab_features: more than 2^31 points in one slab");
     if ((rc = ensure_work(work, N, false))) return rc;
     Calib cal{};
     work->slab_ready = false;
@@ -900,9 +1007,38 @@ extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_
         if (work->slab_needs_patch) ICON_HIP(hipMemcpyAsync(d_count_local, work->d_total, sizeof(int64_t), hipMemcpyDeviceToDevice, st));
         else ICON_HIP(hipMemsetAsync(d_count_local, 0, sizeof(int64_t), st));
     }
+    if (d_msg) {
+        const int64_t cap = msg_bytes - 8;                 // packed bytes available
+        ICON_ARG(msg_bytes >= 8 && cap * 4 >= N, "icon_grid_slab_features_msg: message buffer too small (8 + ceil(points / 4) bytes)");
+        if (work->slab_needs_patch) {
+            const int64_t nb = (std::max<int64_t>(cap, 1) + 255) / 256;
+            hipLaunchKernelGGL(k_pack_signs, dim3((unsigned)nb), dim3(256), 0, st, d_signs_local ? d_signs_local : work->d_signs, work->d_total,
+                               (uint8_t *)d_msg, cap);
+            ICON_HIP(hipGetLastError());
+        } else {
+            ICON_HIP(hipMemsetAsync(d_msg, 0, sizeof(int64_t), st));
+        }
+    }
     mark(work, 1, st);
     work->slab_res = res; work->slab_z0 = z0; work->slab_z1 = z1; work->slab_ready = true;
     return ICON_OK;
+}
+
+extern "C" int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
+                                       int prior_type, float sdf_clip, int cmap_mode,
+                                       int res, int z0, int z1, int8_t *d_signs_local, int64_t *d_count_local,
+                                       int search, icon_work_t *work, void *stream)
+{
+    return slab_features_impl(mesh, feat, prior_type, sdf_clip, cmap_mode, res, z0, z1, d_signs_local, d_count_local, nullptr, 0, search, work, stream);
+}
+
+extern "C" int icon_grid_slab_features_msg(const icon_mesh_t *mesh, const icon_feat_t *feat,
+                                           int prior_type, float sdf_clip, int cmap_mode,
+                                           int res, int z0, int z1, void *d_msg, int64_t msg_bytes,
+                                           int search, icon_work_t *work, void *stream)
+{
+    ICON_ARG(d_msg != nullptr, "icon_grid_slab_features_msg: message buffer is null");
+    return slab_features_impl(mesh, feat, prior_type, sdf_clip, cmap_mode, res, z0, z1, nullptr, nullptr, d_msg, msg_bytes, search, work, stream);
 }
 
 extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
@@ -919,34 +1055,39 @@ extern "C" int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int
         fs.mode = kSignGlobal; fs.list = d_signs_global; fs.k_host = k_total; fs.rank_offset = rank_offset;
     }
     work->slab_ready = false;
-    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream);
+    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream, z0, z1);
 }
 
-extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1,
-                                              const int8_t *d_gathered, int64_t stride, int world, int rank,
+extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1, int za, int zb,
+                                              const void *d_gathered, int64_t stride, int world, int rank,
                                               float *d_occ, int precision, icon_work_t *work, void *stream)
 {
     ICON_ARG(mlp && work && d_occ, "icon_grid_slab_finish_gathered: null argument");
-    ICON_ARG(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "icon_grid_slab_finish_gathered: bad world / rank");
-    ICON_ARG(stride >= 8 && (stride & 7) == 0, "icon_grid_slab_finish_gathered: stride must be a multiple of 8 (int64 header)");
     if (!work->slab_ready || work->slab_res != res || work->slab_z0 != z0 || work->slab_z1 != z1)
         return fail(ICON_ERR_STATE, "icon_grid_slab_finish_gathered: no matching icon_grid_slab_features call on this workspace");
+    ICON_ARG(za >= z0 && zb > za && zb <= z1, "icon_grid_slab_finish_gathered: planes [za, zb) must lie inside the slab");
     ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_slab_finish_gathered: MLP input width does not match the feature layout");
     FusedSigns fs{};
     if (work->slab_needs_patch) {
-        ICON_ARG(d_gathered != nullptr, "icon_grid_slab_finish_gathered: gathered messages are null");
-        fs.mode = kSignSeg; fs.gathered = d_gathered; fs.stride = stride; fs.world = world; fs.rank = rank;
+        if (d_gathered) {
+            ICON_ARG(world >= 1 && world <= kMaxWorld && rank >= 0 && rank < world, "icon_grid_slab_finish_gathered: bad world / rank");
+            ICON_ARG(stride >= 8 && (stride & 7) == 0, "icon_grid_slab_finish_gathered: stride must be a multiple of 8 (int64 header)");
+            fs.mode = kSignSeg; fs.gathered = (const int8_t *)d_gathered; fs.stride = stride; fs.world = world; fs.rank = rank;
+        } else {
+            fs = self_signs(work);              // no exchange: the slab's own list is the whole list
+        }
     }
-    work->slab_ready = false;
-    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream);
+    // the slab stays prepared: its planes may be finished piece by piece (the next icon_grid_slab_features replaces it)
+    return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream, za, zb);
 }
 
 extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3])
 {
     ICON_ARG(mesh && out, "icon_debug_traversal_stats: null argument");
     LatticeMap L;
-    int rc = lattice_map(res, z0, z1, &L);
+    int rc = lattice_map(res, z0, z1, mesh, 0.05f, true, &L);
     if (rc) return rc;
+    if (L.tx * L.ty * L.tz == 0) { out[0] = out[1] = out[2] = 0; return ICON_OK; }
     unsigned long long *d = nullptr;
     ICON_HIP(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
     ICON_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
@@ -971,5 +1112,41 @@ extern "C" int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *f
     ICON_ARG(work->slab_c0 == mlp->c0, "icon_grid_eval_slab: MLP input width does not match the feature layout");
     // the slab's own sign list is the whole list (single call == whole lattice or caller's choice)
     work->slab_ready = false;
-    return phase2(mlp, self_signs(work), d_occ, precision, work, (hipStream_t)stream);
+    return phase2(mlp, self_signs(work), d_occ, precision, work, (hipStream_t)stream, z0, z1);
+}
+
+extern "C" int icon_debug_set_shell_skip(int on)
+{
+    g_shell_skip = on ? 1 : 0;
+    return ICON_OK;
+}
+
+extern "C" int icon_work_set_tie_rule(icon_work_t *work, int rule, int ulps)
+{
+    ICON_ARG(work != nullptr, "icon_work_set_tie_rule: work is null");
+    ICON_ARG(rule == 0 || rule == 1, "icon_work_set_tie_rule: rule must be 0 (definition) or 1 (highest index within ulps)");
+    ICON_ARG(ulps >= 0 && ulps <= 255, "icon_work_set_tie_rule: ulps must be 0..255");
+    work->tie_rule = rule; work->tie_ulps = ulps;
+    return ICON_OK;
+}
+
+extern "C" int icon_sdf_query_ties(const icon_mesh_t *mesh, const float *d_points, int64_t N,
+                                   int32_t *d_face, int32_t *d_face2, uint8_t *d_ulps, void *stream)
+{
+    ICON_ARG(mesh && d_points && d_face && d_face2 && d_ulps, "icon_sdf_query_ties: null argument");
+    ICON_ARG(N >= 0, "icon_sdf_query_ties: negative N");
+    if (N == 0) return ICON_OK;
+    const int64_t nb = (N + kBlock - 1) / kBlock;
+    ICON_ARG(nb < (1ll << 31), "icon_sdf_query_ties: N too large for one launch");
+    hipStream_t st = (hipStream_t)stream;
+    icon_work tmp;
+    static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    const int32_t *perm = nullptr;
+    int rc = morton_order(&tmp, d_points, ident, nullptr, N, st, &perm);
+    if (!rc) {
+        hipLaunchKernelGGL(k_nearest_ties, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, perm, d_face, d_face2, d_ulps);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) rc = fail(ICON_ERR_HIP, "icon_sdf_query_ties: launch failed");
+    }
+    (void)hipFree(tmp.d_sort_keys); (void)hipFree(tmp.d_sort_idx); (void)hipFree(tmp.d_sort_tmp);
+    return rc;
 }

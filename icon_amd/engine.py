@@ -16,6 +16,7 @@ in the HIP kernels.  There is no CPU path: CPU tensors raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -29,6 +30,12 @@ from ._lib import IconAmdError, check, ptr
 
 def _stream() -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _on(t: torch.Tensor):
+    """Make the device of ``t`` current for the duration of a library call: the C ABI allocates and launches on HIP's
+    current device, and one process may drive several (cfg 5: one image per GPU)."""
+    return torch.cuda.device(t.device) if t.is_cuda else contextlib.nullcontext()
 
 
 def _key(*tensors) -> tuple:
@@ -82,8 +89,9 @@ class MeshHandle(_Handle):
             raise IconAmdError("smpl_cmap / smpl_vis do not match smpl_verts")
         self.V, self.F = int(v.shape[0]), int(f.shape[0])
         self.device = v.device
-        check(_lib.lib().icon_mesh_create(ptr(v), C.c_int64(self.V), ptr(f), C.c_int64(self.F), ptr(cm), ptr(vs),
-                                          _stream(), C.byref(self.h)), "icon_mesh_create")
+        with _on(v):
+            check(_lib.lib().icon_mesh_create(ptr(v), C.c_int64(self.V), ptr(f), C.c_int64(self.F), ptr(cm), ptr(vs),
+                                              _stream(), C.byref(self.h)), "icon_mesh_create")
 
     def vertex_normals(self) -> torch.Tensor:
         out = torch.empty((self.V, 3), dtype=torch.float32, device=self.device)
@@ -119,6 +127,20 @@ class MeshHandle(_Handle):
         return out
 
 
+    def sdf_query_ties(self, points: torch.Tensor) -> dict:
+        """Tie sensitivity of the nearest-triangle choice (lib/dataset/mesh_util.py:374-390) for points [N,3] ->
+        dict(face [N] i32 the winner, face2 [N] i32 the runner-up (-1: none), ulps [N] u8: float32 ulps between their
+        squared distances, clipped to 255).  ulps <= 1 marks a point whose norm / cmap / vis depend on how the leaf
+        rounds its last bit - the part of the output that is not comparable with a kaolin run point by point."""
+        p = _dev_f32(points, "points").reshape(-1, 3)
+        n, dev = p.shape[0], p.device
+        out = dict(face=torch.empty(n, dtype=torch.int32, device=dev), face2=torch.empty(n, dtype=torch.int32, device=dev),
+                   ulps=torch.empty(n, dtype=torch.uint8, device=dev))
+        check(_lib.lib().icon_sdf_query_ties(self.h, ptr(p), C.c_int64(n), ptr(out["face"]), ptr(out["face2"]), ptr(out["ulps"]),
+                                             _stream()), "icon_sdf_query_ties")
+        return out
+
+
 class FeatHandle(_Handle):
     """Feature planes ``features[-1]`` of HGPIFuNet.filter ([1,C,H,W]) and, for PaMIR, the volume
     encoder output ([1,Cv,D,H,W]); icon_feat_create."""
@@ -143,9 +165,10 @@ class FeatHandle(_Handle):
             Cv, Dv, Hv, Wv = (int(s) for s in v.shape)
             vp = ptr(v)
         self.C, self.H, self.W, self.n_select, self.Cv = Cc, H, W, n_select, Cv
-        check(_lib.lib().icon_feat_create(ptr(p), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_int(n_select), vp,
-                                          C.c_int(Cv), C.c_int(Dv), C.c_int(Hv), C.c_int(Wv), _stream(),
-                                          C.byref(self.h)), "icon_feat_create")
+        with _on(p):
+            check(_lib.lib().icon_feat_create(ptr(p), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_int(n_select), vp,
+                                              C.c_int(Cv), C.c_int(Dv), C.c_int(Hv), C.c_int(Wv), _stream(),
+                                              C.byref(self.h)), "icon_feat_create")
         # no synchronisation: the repack kernel is enqueued on the current stream, and the caching allocator
         # recycles the (possibly temporary) source tensors in stream order
 
@@ -226,6 +249,8 @@ class MlpHandle(_Handle):
         return float((self.forward(xd, "mx6") - self.forward(xd, "f16x3")).abs().max().item())
 
 
+_WARNED_VOXELIZER = False
+
 # precision="mx6" is accepted only while its calibrated deviation from the f32-class path leaves 4x
 # headroom under the 1e-4 occupancy tolerance of BASELINE.json's north star
 MX6_GATE = 2.5e-5
@@ -237,6 +262,9 @@ class Workspace(_Handle):
     def __init__(self):
         super().__init__()
         check(_lib.lib().icon_work_create(C.byref(self.h)), "icon_work_create")
+
+    def set_tie_rule(self, rule: int, ulps: int = 0) -> None:
+        check(_lib.lib().icon_work_set_tie_rule(self.h, C.c_int(rule), C.c_int(ulps)), "icon_work_set_tie_rule")
 
     def profile(self, enable: bool = True) -> None:
         check(_lib.lib().icon_work_profile(self.h, C.c_int(int(enable))), "icon_work_profile")
@@ -282,6 +310,29 @@ def regressor_state_dict(regressor) -> dict:
     return {k: v for k, v in regressor.state_dict().items() if "num_batches_tracked" not in k}
 
 
+def _device_of(*cands):
+    for c in cands:
+        if isinstance(c, (list, tuple)) and c:
+            c = c[-1]
+        if isinstance(c, torch.Tensor) and c.is_cuda:
+            return c
+    return None
+
+
+def _guarded(fn):
+    """run the method with the device of its first device-tensor argument current (see _on)"""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kw):
+        t = _device_of(*args, *kw.values())
+        if t is None:
+            return fn(self, *args, **kw)
+        with _on(t):
+            return fn(self, *args, **kw)
+    return wrapper
+
+
 class IconQueryEngine:
     """Drop-in for ``HGPIFuNet.query`` (lib/net/HGPIFuNet.py:268-367).
 
@@ -293,7 +344,7 @@ class IconQueryEngine:
     def __init__(self, prior_type: str = "icon", sdf_clip: float = 0.05,
                  smpl_feats: Sequence[str] = ("sdf", "norm", "vis", "cmap"),
                  cmap_mode: str = "reference", search: str = "bvh", precision: str = "f16x3",
-                 res_layers: Sequence[int] = (2, 3, 4)):
+                 res_layers: Sequence[int] = (2, 3, 4), voxelizer: str = "auto"):
         if prior_type not in _lib.PRIOR:
             raise IconAmdError(f"unknown prior_type {prior_type!r}")
         if prior_type == "icon" and set(smpl_feats) != {"sdf", "norm", "vis", "cmap"}:
@@ -302,6 +353,12 @@ class IconQueryEngine:
         self.prior_type, self.sdf_clip = prior_type, float(sdf_clip)
         self.cmap_mode, self.search, self.precision = cmap_mode, search, precision
         self.res_layers = tuple(res_layers)
+        if voxelizer not in ("auto", "hip", "reference"):
+            raise IconAmdError("voxelizer must be 'auto', 'hip' or 'reference'")
+        self.voxelizer = voxelizer       # pamir: which semantic voxeliser feeds netG.ve (see _pamir_volume)
+        self.tie_rule = None             # diagnostics: ("highest", ulps) - see Workspace.set_tie_rule / DESIGN.md section 2
+        self._calibrated = None          # (mlp key, precision) the effective precision was derived for
+        self._work_tie = None
         self.netG = None
         self.work = None
         self._mesh = self._mesh_key = self._mesh_src = None
@@ -341,6 +398,16 @@ class IconQueryEngine:
     def _work(self) -> Workspace:
         if self.work is None:
             self.work = Workspace()
+            self._work_tie = None
+        if self.tie_rule != self._work_tie:
+            if self.tie_rule is None:
+                self.work.set_tie_rule(0, 0)
+            else:
+                kind, ulps = self.tie_rule
+                if kind != "highest":
+                    raise IconAmdError("tie_rule must be None or ('highest', ulps)")
+                self.work.set_tie_rule(1, int(ulps))
+            self._work_tie = self.tie_rule
         return self.work
 
     def _mesh_handle(self) -> Optional[MeshHandle]:
@@ -392,12 +459,43 @@ class IconQueryEngine:
             vv = d["voxel_verts"][:, :-int(d["pad_v_num"][0]), :]
             vf = d["voxel_faces"][:, :-int(d["pad_f_num"][0]), :]
             vox = netG.voxelization
-            vol = semantic_voxelization(vv, vf, vox.smpl_vertex_code, res=int(getattr(vox, "volume_res", 128)),
-                                        sigma=float(getattr(vox, "sigma", 0.05)))
+            if self._use_reference_voxelizer():
+                # the reference's own leaf (lib/net/voxelize.py:119-137 -> voxelize_cuda wheel), exactly as
+                # HGPIFuNet.query calls it (lib/net/HGPIFuNet.py:320) - still once per image, not per query()
+                with torch.no_grad():
+                    vol = vox(vv, vf)
+            else:
+                vol = semantic_voxelization(vv, vf, vox.smpl_vertex_code, res=int(getattr(vox, "volume_res", 128)),
+                                            sigma=float(getattr(vox, "sigma", 0.05)))
             with torch.no_grad():
                 self._vol_cached = netG.ve(vol, intermediate_output=False)[-1]
             self._vol_key, self._vol_src = k, (d["voxel_verts"], d["voxel_faces"])
         return self._vol_cached
+
+    def _use_reference_voxelizer(self) -> bool:
+        """voxelizer='reference': always netG.voxelization (needs the voxelize_cuda wheel); 'hip': always the HIP
+        voxeliser; 'auto' (default): the reference's leaf when its wheel imports, otherwise the HIP voxeliser with ONE
+        warning - its semantics are restated from the call site, not verified against voxelize_cuda (PARITY UNPINNED)."""
+        if self.voxelizer == "hip":
+            return False
+        try:
+            import voxelize_cuda
+            have = hasattr(voxelize_cuda, "forward_semantic_voxelization")      # the entry lib/net/voxelize.py:57 calls
+        except Exception:
+            have = False
+        if self.voxelizer == "reference":
+            if not have:
+                raise IconAmdError("voxelizer='reference' needs the voxelize_cuda wheel (requirements.txt:34), which does not import")
+            return True
+        if not have:
+            global _WARNED_VOXELIZER
+            if not _WARNED_VOXELIZER:
+                import warnings
+                warnings.warn("icon_amd: voxelize_cuda is not installed - the PaMIR semantic volume comes from the HIP voxeliser, whose "
+                              "semantics are restated from lib/net/voxelize.py and NOT verified against the wheel (parity unpinned); "
+                              "pass voxelizer='reference' to insist on the wheel, 'hip' to silence this")
+                _WARNED_VOXELIZER = True
+        return have
 
     def _mlp_handle(self, regressor=None) -> MlpHandle:
         reg = regressor if regressor is not None else self._regressor
@@ -410,23 +508,36 @@ class IconQueryEngine:
         if k != self._mlp_key:
             self._mlp = MlpHandle(sd, self.res_layers)
             self._mlp_key, self._mlp_src = k, list(sd.values())
-            self._effective_precision = self.precision
-            if self.precision == "mx6":
-                # mx6 carries ~15 significant bits: whether it stays inside the 1e-4 occupancy tolerance depends
-                # on the checkpoint (error ~ hidden-activation magnitude x last-layer gain).  Calibrate it against
-                # the f32-class path on representative rows and fall back when it does not have 4x headroom.
-                self.mx6_max_err = self._mlp.calibrate_mx6()
-                if not (self.mx6_max_err <= MX6_GATE):
-                    import warnings
-                    warnings.warn(f"icon_amd: precision='mx6' deviates {self.mx6_max_err:.2e} from the f32-class path on this "
-                                  f"checkpoint (gate {MX6_GATE:.1e}); using 'f16x3' instead")
-                    self._effective_precision = "f16x3"
+        self._resolve_precision()
         return self._mlp
 
+    def _resolve_precision(self) -> None:
+        """The precision the kernels run at for (current checkpoint, current ``self.precision``) - re-derived whenever
+        either changes, so assigning ``eng.precision`` after the first query takes effect and mx6 is never used
+        uncalibrated.  mx6 carries ~15 significant bits: whether it stays inside the 1e-4 occupancy tolerance depends
+        on the checkpoint (error ~ hidden-activation magnitude x last-layer gain); it is calibrated against the
+        f32-class path on representative rows and refused when it does not have 4x headroom."""
+        if self.precision not in _lib.PRECISION:
+            raise IconAmdError(f"unknown precision {self.precision!r}")
+        if self._calibrated == (self._mlp_key, self.precision):
+            return
+        self._effective_precision = self.precision
+        if self.precision == "mx6":
+            self.mx6_max_err = self._mlp.calibrate_mx6()
+            if not (self.mx6_max_err <= MX6_GATE):
+                import warnings
+                warnings.warn(f"icon_amd: precision='mx6' deviates {self.mx6_max_err:.2e} from the f32-class path on this "
+                              f"checkpoint (gate {MX6_GATE:.1e}); using 'f16x3' instead")
+                self._effective_precision = "f16x3"
+        self._calibrated = (self._mlp_key, self.precision)
+
     def _precision(self) -> int:
+        if self._mlp is not None:
+            self._resolve_precision()
         return _lib.PRECISION[getattr(self, "_effective_precision", self.precision)]
 
     # ---- HGPIFuNet.query ---------------------------------------------------------------------------
+    @_guarded
     def query(self, features, points, calibs, transforms=None, regressor=None):
         """features: list of [1,C,H,W]; points [1,3,N]; calibs [1,4,4] (or [1,3,4]) -> list of [1,1,N]"""
         if points.dim() != 3 or points.shape[0] != 1 or points.shape[1] != 3:
@@ -467,6 +578,7 @@ class IconQueryEngine:
         return preds
 
     # ---- dense lattice (one rank's share of reconEngine) ------------------------------------------------
+    @_guarded
     def eval_slab(self, im_feat, res: int, z0: int, z1: int, regressor=None, out=None) -> torch.Tensor:
         mesh, mlp, feat = self._mesh_handle(), self._mlp_handle(regressor), self._feat_handle(im_feat)
         if out is None:
@@ -478,11 +590,22 @@ class IconQueryEngine:
             self._work().h, _stream()), "icon_grid_eval_slab")
         return out
 
-    def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None):
-        """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device);
-        ``signs`` / ``count`` may be views into a caller-owned message buffer (recon.py)."""
+    @_guarded
+    def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None, msg=None):
+        """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device).  With ``msg`` (a
+        contiguous int8 / uint8 device buffer of >= 8 + ceil(points / 4) bytes, e.g. this rank's slot of an all_gather
+        input) the slab's exchange message [int64 K][2-bit packed signs] is written there instead and ``msg`` is returned."""
         mesh, feat = self._mesh_handle(), self._feat_handle(im_feat)
         n = (z1 - z0) * res * res
+        if msg is not None:
+            if not msg.is_contiguous() or msg.element_size() != 1 or msg.numel() < 8 + (n + 3) // 4:
+                raise IconAmdError("slab_features: msg must be a contiguous byte buffer of >= 8 + ceil(points / 4) bytes")
+            check(_lib.lib().icon_grid_slab_features_msg(
+                mesh.h if mesh is not None else C.c_void_p(0), feat.h, C.c_int(_lib.PRIOR[self.prior_type]),
+                C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
+                C.c_int(z1), ptr(msg), C.c_int64(msg.numel()), C.c_int(_lib.SEARCH[self.search]), self._work().h, _stream()),
+                "icon_grid_slab_features_msg")
+            return msg
         if signs is None:
             signs = torch.empty(n, dtype=torch.int8, device=im_feat.device)
         if count is None:
@@ -496,6 +619,7 @@ class IconQueryEngine:
             "icon_grid_slab_features")
         return signs, count
 
+    @_guarded
     def slab_finish(self, res: int, z0: int, z1: int, signs_global, k_total: int, rank_offset: int,
                     regressor=None, out=None, device=None) -> torch.Tensor:
         mlp = self._mlp_handle(regressor)
@@ -509,16 +633,22 @@ class IconQueryEngine:
         return out
 
 
-    def slab_finish_gathered(self, res: int, z0: int, z1: int, gathered: torch.Tensor, stride: int, world: int, rank: int,
-                             regressor=None, out=None) -> torch.Tensor:
-        """Phase 2 on the all_gather output itself: ``gathered`` int8 [world * stride], message r =
-        [int64 count_r][int8 signs_r]; nothing is read back to the host."""
+    @_guarded
+    def slab_finish_gathered(self, res: int, z0: int, z1: int, gathered: Optional[torch.Tensor], stride: int, world: int, rank: int,
+                             regressor=None, out=None, za: Optional[int] = None, zb: Optional[int] = None, device=None) -> torch.Tensor:
+        """Phase 2 on the all_gather output itself: ``gathered`` bytes [world * stride], message r =
+        [int64 count_r][2-bit packed signs_r] (slab_features(msg=...)); nothing is read back to the host.
+        ``gathered=None``: no exchange (cmap_mode local / one rank).  Evaluates the planes [za, zb) of the slab
+        (default: all of it) into ``out`` [(z1-z0), res, res], the SLAB's buffer; may be called piece by piece."""
         mlp = self._mlp_handle(regressor)
         if out is None:
-            out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=gathered.device)
+            out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=gathered.device if gathered is not None else device)
+        za = z0 if za is None else za
+        zb = z1 if zb is None else zb
         check(_lib.lib().icon_grid_slab_finish_gathered(
-            mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), ptr(gathered), C.c_int64(stride), C.c_int(world), C.c_int(rank),
-            ptr(out), C.c_int(self._precision()), self._work().h, _stream()), "icon_grid_slab_finish_gathered")
+            mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), C.c_int(za), C.c_int(zb), ptr(gathered), C.c_int64(stride),
+            C.c_int(world), C.c_int(rank), ptr(out), C.c_int(self._precision()), self._work().h, _stream()),
+            "icon_grid_slab_finish_gathered")
         return out
 
 

@@ -18,6 +18,7 @@ outlier sign lists (one small ``all_gather``); ``cmap_mode="local"`` needs no ex
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Optional
 
 import numpy as np
@@ -92,6 +93,7 @@ class DenseReconEngine(nn.Module):
     process_group torch.distributed group to shard over (default: WORLD if initialised)
     shard         False -> every rank evaluates the whole lattice (replicas, no collectives)
     balance_slabs cost-weighted Z-slab cut (far-field planes count 1.1; see plane_weights); False -> equal plane counts
+    overlap_gather  the volume all_gather in two halves, the first overlapping the second half of the slab's MLP kernel
     backend       object providing eval_slab / slab_features / slab_finish (tests inject a CPU
                   checker here; the default is the HIP engine)
     """
@@ -99,7 +101,7 @@ class DenseReconEngine(nn.Module):
     def __init__(self, query_func=None, b_min=((-1.0, 1.0, -1.0),), b_max=((1.0, -1.0, 1.0),), resolutions=(257,),
                  channels=1, balance_value=0.5, align_corners=False, visualize=False, debug=False,
                  use_cuda_impl=False, faster=False, use_shadow=False, engine=None, process_group=None,
-                 shard=True, backend=None, balance_slabs=True, **kwargs):
+                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, **kwargs):
         super().__init__()
         self.query_func = query_func
         self.register_buffer("b_min", torch.tensor(b_min).float().unsqueeze(1))   # [1,1,3]
@@ -124,6 +126,7 @@ class DenseReconEngine(nn.Module):
         self.process_group = process_group
         self.shard = shard
         self.balance_slabs = balance_slabs
+        self.overlap_gather = overlap_gather
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------
@@ -206,56 +209,112 @@ class DenseReconEngine(nn.Module):
             self._shard_key = key
         return self._shard_slab, self._shard_msg
 
+    def _slab_cuts(self, be, res, dist, world, rank, dev):
+        """The Z-slab partition every rank uses.  The cost-weighted cut depends on float min/max of the SMPL vertices;
+        ranks whose replicas of those tensors differ in the last bit (non-deterministic upstream kernels) could derive
+        different cuts and then disagree on message sizes and offsets - so rank 0's cut is the cut: it is broadcast
+        once per (resolution, world, body) and cached (every rank misses the cache on the same call: the key changes
+        exactly when filter() produced new SMPL tensors, which all ranks do in lockstep)."""
+        if not self.balance_slabs:
+            return slab_partition(res, world, None)
+        key = (res, world, getattr(be, "_mesh_key", None))
+        if getattr(self, "_cuts_key", None) == key and key[2] is not None:
+            return self._cuts
+        parts = slab_partition(res, world, self._plane_weights(be, res))
+        g = self.process_group
+        cpu_group = dist.get_backend(g) == "gloo"
+        t = torch.tensor([a for a, _ in parts] + [parts[-1][1]], dtype=torch.int64, device="cpu" if cpu_group else dev)
+        dist.broadcast(t, src=dist.get_global_rank(g, 0) if g is not None else 0, group=g)
+        c = [int(v) for v in t.tolist()]
+        parts = [(c[r], c[r + 1]) for r in range(world)]
+        self._cuts_key, self._cuts = key, parts
+        return parts
+
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
-        parts = slab_partition(res, world, self._plane_weights(be, res))
+        dev = im_feat.device
+        parts = self._slab_cuts(be, res, dist, world, rank, dev)
         z0, z1 = parts[rank]
         per = max(b - a for a, b in parts)
-        dev = im_feat.device
-        stride = 8 + (per * res * res + 7) // 8 * 8
+        # message of the sign exchange: [int64 count][2 bits per outlier sign, padded to the largest slab], 8-byte aligned
+        stride = 8 + ((per * res * res + 3) // 4 + 7) // 8 * 8
         slab, msg = self._shard_buffers((res, world, rank, str(dev), per), per, res, stride, dev)
         need_exchange = getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
-        if need_exchange and hasattr(be, "slab_finish_gathered"):
-            # ONE collective, no host synchronisation: every rank contributes a fixed-size message
-            # [int64 count][int8 signs, padded to the largest slab]; phase 1 writes straight into it and
-            # phase 2 consumes the gathered buffer as it is (K, rank offset and segment lookup happen
-            # on the device), so the exchange and the MLP launch are enqueued back to back.
-            n = (z1 - z0) * res * res
-            msg[:8].zero_()
-            if z1 > z0:
-                be.slab_features(im_feat, res, z0, z1, signs=msg[8:8 + n], count=msg[:8].view(torch.int64))
-            gathered = self._all_gather_cat(dist, msg, world, g)
-            if z1 > z0:
-                be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0])
-            self.last_stats = dict(exchanged_bytes=stride * world, collectives=2, slabs=parts)   # sign messages + the volume
-        elif need_exchange:
-            if z1 > z0:
-                signs, count = be.slab_features(im_feat, res, z0, z1)
+        pieces = hasattr(be, "slab_finish_gathered")
+        # the volume is gathered in two halves of every rank's (padded) slab: the first half travels over xGMI while
+        # the second half is still in the MLP kernel
+        per_a = (per + 1) // 2 if (self.overlap_gather and pieces and per > 1) else per
+        handles = []
+
+        def gather_async(t):
+            if t.is_cuda and dist.get_backend(g) == "gloo":                    # debugging aid: staged through the host, synchronous
+                return self._all_gather_cat(dist, t, world, g), None
+            out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            return out, dist.all_gather_into_tensor(out, t, group=g, async_op=True)
+
+        if pieces:
+            gathered = None
+            if need_exchange:
+                # ONE collective, no host synchronisation: every rank contributes a fixed-size message; phase 1 writes
+                # straight into it and phase 2 consumes the gathered buffer as it is (K, rank offset and segment lookup
+                # happen on the device), so the exchange and the MLP launch are enqueued back to back.
+                msg[:8].zero_()
+                if z1 > z0:
+                    be.slab_features(im_feat, res, z0, z1, msg=msg)
+                gathered = self._all_gather_cat(dist, msg, world, g)
+            elif z1 > z0:
+                be.slab_features(im_feat, res, z0, z1)
+            zm = min(z1, z0 + per_a)
+            if zm > z0:
+                be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0], za=z0, zb=zm, device=dev)
+            vol_a, h = gather_async(slab[:per_a])
+            handles.append(h)
+            vol_b = None
+            if per_a < per:
+                if z1 > zm:
+                    be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0], za=zm, zb=z1, device=dev)
+                vol_b, h = gather_async(slab[per_a:])
+                handles.append(h)
+            for h in handles:
+                if h is not None:
+                    h.wait()
+            if vol_b is None:
+                allv = vol_a.view(world, per, res, res)
             else:
-                signs = torch.empty(0, dtype=torch.int8, device=dev)
-                count = torch.zeros(1, dtype=torch.int64, device=dev)
-            counts = self._all_gather_cat(dist, count.view(1), world, g).tolist()      # one host sync
-            kmax = max(max(counts), 1)
-            mine = torch.zeros(kmax, dtype=torch.int8, device=dev)
-            mine[:counts[rank]] = signs[:counts[rank]]
-            gathered = self._all_gather_cat(dist, mine, world, g).view(world, kmax)
-            if sum(counts):
-                signs_global = torch.cat([gathered[r, :c] for r, c in enumerate(counts)]).contiguous()
-            else:
-                signs_global = mine[:0]
-            if z1 > z0:
-                be.slab_finish(res, z0, z1, signs_global, sum(counts), sum(counts[:rank]),
-                               out=slab[: z1 - z0], device=dev)
-            self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world, slabs=parts)
+                allv = torch.empty((world, per, res, res), dtype=torch.float32, device=vol_a.device)
+                allv[:, :per_a] = vol_a.view(world, per_a, res, res)
+                allv[:, per_a:] = vol_b.view(world, per - per_a, res, res)
+            self.last_stats = dict(exchanged_bytes=stride * world if need_exchange else 0, collectives=(1 if need_exchange else 0) + len(handles),
+                                   slabs=parts)
         else:
-            if z1 > z0:
-                be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
-            self.last_stats = dict(exchanged_bytes=0, collectives=1, slabs=parts)
-        allv = self._all_gather_cat(dist, slab, world, g)
+            # backends without the device-side protocol: counts through the host, explicit global list
+            if need_exchange:
+                if z1 > z0:
+                    signs, count = be.slab_features(im_feat, res, z0, z1)
+                else:
+                    signs = torch.empty(0, dtype=torch.int8, device=dev)
+                    count = torch.zeros(1, dtype=torch.int64, device=dev)
+                counts = self._all_gather_cat(dist, count.view(1), world, g).tolist()      # one host sync
+                kmax = max(max(counts), 1)
+                mine = torch.zeros(kmax, dtype=torch.int8, device=dev)
+                mine[:counts[rank]] = signs[:counts[rank]]
+                gl = self._all_gather_cat(dist, mine, world, g).view(world, kmax)
+                if sum(counts):
+                    signs_global = torch.cat([gl[r, :c] for r, c in enumerate(counts)]).contiguous()
+                else:
+                    signs_global = mine[:0]
+                if z1 > z0:
+                    be.slab_finish(res, z0, z1, signs_global, sum(counts), sum(counts[:rank]),
+                                   out=slab[: z1 - z0], device=dev)
+                self.last_stats = dict(outliers=sum(counts), exchanged_bytes=kmax * world, slabs=parts)
+            else:
+                if z1 > z0:
+                    be.eval_slab(im_feat, res, z0, z1, out=slab[: z1 - z0])
+                self.last_stats = dict(exchanged_bytes=0, collectives=1, slabs=parts)
+            allv = self._all_gather_cat(dist, slab, world, g).view(world, per, res, res)
         if all(b - a == per for a, b in parts):
-            return allv[:res]
-        allv = allv.view(world, per, res, res)                    # unequal slabs: drop each rank's padding planes
-        return torch.cat([allv[r, : b - a] for r, (a, b) in enumerate(parts)], 0)
+            return allv.view(world * per, res, res)[:res]
+        return torch.cat([allv[r, : b - a] for r, (a, b) in enumerate(parts)], 0)   # unequal slabs: drop each rank's padding planes
 
     def _forward_generic(self, **kwargs):
         """Any b_min/b_max/align_corners/proj_matrix: materialise the lattice coordinates exactly as
@@ -350,12 +409,35 @@ def mesh_components(faces: torch.Tensor, n_verts: int) -> torch.Tensor:
     return labels
 
 
+def face_components(faces: torch.Tensor, n_verts: int) -> torch.Tensor:
+    """[F] int64 component label of every FACE under trimesh's notion of connectivity (graph.split ->
+    face_adjacency): two faces are adjacent when they share an EDGE that exactly two faces use - faces that merely
+    touch in a vertex (marching-cubes pinch points) are NOT connected.  The edge grouping is torch plumbing (sort by
+    edge key); the components themselves come from the device union-find (icon_mesh_components on the adjacency
+    graph, one node per face).  Label = the smallest face index of the component."""
+    f = faces.detach().to(torch.int64).reshape(-1, 3)
+    F = f.shape[0]
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    key = torch.minimum(e[:, 0], e[:, 1]) * int(n_verts) + torch.maximum(e[:, 0], e[:, 1])
+    fid = torch.arange(F, device=f.device).repeat(3)
+    order = torch.argsort(key)
+    ks, fs = key[order], fid[order]
+    _, counts = torch.unique_consecutive(ks, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    two = starts[counts == 2]                                    # edges used by exactly two faces (grouping.group_rows(..., require_count=2))
+    if two.numel() == 0:
+        return torch.arange(F, device=f.device)
+    a, b = fs[two], fs[two + 1]
+    pairs = torch.stack([a, b, b], 1).contiguous()              # an adjacency as a degenerate "triangle" of the face graph
+    return mesh_components(pairs, F).long()
+
+
 def clean_mesh(verts: torch.Tensor, faces: torch.Tensor):
-    """Drop-in for ``lib.dataset.mesh_util.clean_mesh`` (mesh_util.py:778-791): keep the connected component
-    with the most vertices (ties: the one containing the lowest-index face, the order trimesh's split
-    enumerates them in); vertices and faces keep their relative order, as trimesh's submesh does.
-    Returns (verts float32, faces int32) on the device of ``verts`` - the reference returns
-    ``.float()`` / ``.int()`` tensors on ``verts.device``.  Inputs on the host (export_mesh returns CPU
+    """Drop-in for ``lib.dataset.mesh_util.clean_mesh`` (mesh_util.py:778-791): trimesh's ``split(only_watertight=
+    False)`` - connected components over FACE adjacency (shared edges; see face_components) - and the component with
+    the most vertices kept (ties: the one containing the lowest-index face); vertices and faces keep their relative
+    order, as trimesh's submesh does.  Returns (verts float32, faces int32) on the device of ``verts`` - the reference
+    returns ``.float()`` / ``.int()`` tensors on ``verts.device``.  Inputs on the host (export_mesh returns CPU
     tensors, seg3d_lossless.py:601-602) are moved to the current HIP device for the labelling."""
     if not torch.cuda.is_available():
         raise IconAmdError("clean_mesh needs the HIP device (there is no CPU fallback)")
@@ -365,31 +447,45 @@ def clean_mesh(verts: torch.Tensor, faces: torch.Tensor):
     f = faces.detach().to(dev, torch.int64).reshape(-1, 3)
     if f.shape[0] == 0 or v.shape[0] == 0:
         return v.float().to(out_dev), f.int().to(out_dev)
-    labels = mesh_components(f, v.shape[0]).long()
-    used = torch.zeros(v.shape[0], dtype=torch.bool, device=dev)
-    used[f.reshape(-1)] = True                                   # trimesh drops unreferenced vertices
-    counts = torch.bincount(labels[used], minlength=v.shape[0])
+    V = v.shape[0]
+    if int(f.min()) < 0 or int(f.max()) >= V:
+        raise IconAmdError("clean_mesh: face index out of range")
+    face_label = face_components(f, V)                           # [F], smallest face index of the component
+    # vertices per component = distinct (component, vertex) incidences (a pinch vertex counts for both sides, as in
+    # trimesh's submeshes)
+    inc = torch.unique(face_label.repeat_interleave(3) * V + f.reshape(-1))
+    counts = torch.bincount(inc // V, minlength=f.shape[0])
     best_count = counts.max()
-    face_label = labels[f[:, 0]]
     tied = counts[face_label] == best_count                      # faces of the largest component(s)
     best = face_label[tied.nonzero()[0, 0]]                      # ... the one met first in face order
-    keep_v = (labels == best) & used
     keep_f = face_label == best
+    keep_v = torch.zeros(V, dtype=torch.bool, device=dev)
+    keep_v[f[keep_f].reshape(-1)] = True
     remap = torch.cumsum(keep_v.to(torch.int64), 0) - 1
     return v[keep_v].float().to(out_dev), remap[f[keep_f]].int().to(out_dev)
 
 
-_mc_work = None
+_mc_tls = threading.local()
+
+
+def _mc_workspace(device: torch.device):
+    """marching-cubes scratch: one workspace per (thread, device) - a process may drive several GPUs, from several threads"""
+    from .engine import Workspace
+    pool = getattr(_mc_tls, "pool", None)
+    if pool is None:
+        pool = _mc_tls.pool = {}
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in pool:
+        pool[idx] = Workspace()
+    return pool[idx]
 
 
 def export_mesh_device(occ: torch.Tensor, level: float = 0.5):
     """Marching cubes on the GPU (icon_mc_count / icon_mc_emit): device tensors in, device tensors out."""
-    global _mc_work
-    from .engine import Workspace, _stream
+    from .engine import _stream
     occ = occ.detach().to(torch.float32).contiguous()
     assert occ.dim() == 3 and occ.shape[0] == occ.shape[1] == occ.shape[2]
-    if _mc_work is None:
-        _mc_work = Workspace()
+    _mc_work = _mc_workspace(occ.device)
     L = _lib.lib()
     nv, nf = C.c_int64(0), C.c_int64(0)
     check(L.icon_mc_count(_lib.ptr(occ), C.c_int(occ.shape[0]), C.c_float(level), _mc_work.h, _stream(), C.byref(nv), C.byref(nf)),

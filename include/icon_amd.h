@@ -203,12 +203,26 @@ int icon_grid_slab_features(const icon_mesh_t *mesh, const icon_feat_t *feat,
 int icon_grid_slab_finish(const icon_mlp_t *mlp, int res, int z0, int z1,
                           const int8_t *d_signs_global, int64_t k_total, int64_t rank_offset,
                           float *d_occ, int precision, icon_work_t *work, void *stream);
-/* The same phase 2 with the sign lists left where ONE all_gather put them: rank r's message is
- * d_gathered + r * stride = [int64 count_r][int8 signs_r[count_r] ...] (what icon_grid_slab_features
- * writes when d_signs = msg + 8 and d_count = msg).  K, the rank offset and the segment of every
- * index are computed on the device: no host read of the counts between the exchange and the MLP. */
-int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1,
-                                   const int8_t *d_gathered, int64_t stride, int world, int rank,
+/* The single-collective form of the same protocol (no host read between the exchange and the MLP):
+ *   1. icon_grid_slab_features_msg: phase 1, and the slab's message written to d_msg =
+ *        [int64 K][K outlier signs in lattice order, 2 bits each (sign + 1), four to a byte, low bits first]
+ *      (msg_bytes >= 8 + ceil(points of the slab / 4); every rank uses the same msg_bytes = stride);
+ *   2. ONE all_gather of the fixed-size messages: rank r's message at d_gathered + r * stride;
+ *   3. icon_grid_slab_finish_gathered: K, this rank's offset and the segment of every index are derived on the
+ *      device from the headers.  Evaluates the planes [za, zb) of the slab (z0 <= za < zb <= z1) into the SLAB's
+ *      buffer d_occ [(z1-z0), res, res]; it may be called several times for one prepared slab - the multi-GPU driver
+ *      gathers the first half of a slab while the second half is computed.  d_gathered == NULL: no exchange
+ *      (ICON_CMAP_LOCAL, or a single rank) - the slab's own sign list is the whole list.
+ * Shell skip: in_cube is strict (lib/net/HGPIFuNet.py:274-275,363), so every lattice point with a coordinate of
+ * exactly +-1 is multiplied by 0.  When the body's bounding box is farther from the cube's boundary than the clip
+ * band is wide - then every shell point is an "outside" outlier without looking at the mesh - the search and the MLP
+ * cover the interior only and the shell is written as 0 (results identical, 2.3 % less work at 257^3). */
+int icon_grid_slab_features_msg(const icon_mesh_t *mesh, const icon_feat_t *feat,
+                                int prior_type, float sdf_clip, int cmap_mode,
+                                int res, int z0, int z1, void *d_msg, int64_t msg_bytes,
+                                int search, icon_work_t *work, void *stream);
+int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z1, int za, int zb,
+                                   const void *d_gathered, int64_t stride, int world, int rank,
                                    float *d_occ, int precision, icon_work_t *work, void *stream);
 
 /* Diagnostics: with precision F16X3 and the BVH search the query runs FUSED - the MLP input rows are
@@ -216,6 +230,24 @@ int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z
  * forces the materialising path (rows written by a feature kernel, patched, read back by the MLP kernel) that
  * the other precisions use; both give bit-identical results (tests/test_gpu_parity.py).  Process-wide. */
 int icon_debug_set_unfused(int on);
+/* Diagnostics: on == 0 evaluates and masks the shell of the lattice like every other point (the reference's own
+ * order of operations) instead of skipping it; both give identical results.  Process-wide; default on
+ * (or ICON_AMD_SHELL_SKIP=0 in the environment). */
+int icon_debug_set_shell_skip(int on);
+
+/* ---- tie sensitivity of the nearest-triangle choice ---------------------------------------------------
+ * lib/dataset/mesh_util.py:374-390: the winner of kaolin's point_to_mesh_distance decides the triangle whose
+ * UNCLAMPED barycentric extrapolation gives norm / cmap / vis; around a vertex or an edge several triangles are
+ * mathematically equidistant and the last bits of d^2 decide (PARITY UNPINNED: kaolin is not in the tree).
+ * icon_sdf_query_ties reports, per point: d_face = the winner (S3: smallest d^2, lowest index on exact ties),
+ * d_face2 = the runner-up (next-smallest (d^2, index) key; -1 if none) and d_ulps = how many float32 ulps the
+ * runner-up's d^2 lies above the winner's, clipped to 255.  Synchronises the stream.
+ * icon_work_set_tie_rule(work, 1, ulps) makes every BVH search issued through `work` pick, among the faces within
+ * `ulps` ulps of the minimum d^2, the one with the HIGHEST index (rule 0 = the definition): running the pipeline
+ * both ways measures how much of the output depends on the unpinned tie behaviour. */
+int icon_sdf_query_ties(const icon_mesh_t *mesh, const float *d_points, int64_t N,
+                        int32_t *d_face, int32_t *d_face2, uint8_t *d_ulps, void *stream);
+int icon_work_set_tie_rule(icon_work_t *work, int rule, int ulps);
 
 /* Diagnostics (synchronises): BVH work of the lattice traversal over planes [z0,z1):
  * out[0] = wavefronts (4x4x4 point blocks), out[1] = BVH nodes visited, out[2] = triangles tested,

@@ -229,6 +229,101 @@ void orc_accel_nearest(const orc_accel *A, const float *pts, int64_t N, float *o
     }
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Tie diagnostics (test infrastructure for icon_sdf_query_ties / icon_work_set_tie_rule).
+ * lib/dataset/mesh_util.py:374-390: the winner of point_to_mesh_distance decides the triangle
+ * whose unclamped barycentric extrapolation gives norm / cmap / vis; the triangles around a
+ * vertex or an edge are mathematically equidistant and the last bits of d^2 decide.
+ *   orc_accel_nearest_ties: winner (S3), runner-up = next-smallest (d^2, face) key, and the
+ *     number of float32 ulps between the two squared distances (clipped to 255; 255 and
+ *     face2 = -1 when there is no second face).
+ *   orc_set_tie_rule(1, u): orc_accel_nearest (and so orc_cal_sdf / orc_query_icon) returns,
+ *     among the faces within u ulps of the minimum d^2, the one with the HIGHEST index and its
+ *     own d^2 - the alternative resolution of the unpinned kaolin ties; (0, 0) = the definition.
+ * ---------------------------------------------------------------------------------------- */
+static int g_tie_rule = 0;
+static uint32_t g_tie_ulps = 0;
+void orc_set_tie_rule(int rule, int ulps) { g_tie_rule = rule; g_tie_ulps = (uint32_t)(ulps < 0 ? 0 : ulps); }
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+/* every face with d^2 <= lim (bit pattern order == value order for d^2 >= 0): visit(face, d2) */
+static void accel_within(const orc_accel *A, const float *p, float best, uint32_t lim_bits, int64_t *io_face, float *io_d2)
+{
+    const float thr = prune_thr(best);
+    int32_t stack[256];
+    int sp = 0;
+    if (A->F > 0) stack[sp++] = 0;
+    while (sp > 0) {
+        const anode *n = &A->nodes[stack[--sp]];
+        if (box_d2(n, p) > thr) continue;
+        if (n->left < 0) {
+            const int32_t first = -1 - n->left;
+            for (int32_t k = first; k < first + n->right; ++k) {
+                const int64_t f = A->order[k];
+                const float d = orc_tri_dist2(p, A->tri + f);
+                if (f2u(d) <= lim_bits && f > *io_face) { *io_face = f; *io_d2 = d; }
+            }
+        } else {
+            stack[sp++] = n->right; stack[sp++] = n->left;
+        }
+    }
+}
+
+void orc_accel_nearest_ties(const orc_accel *A, const float *pts, int64_t N, float *out_d2, int64_t *out_idx,
+                            int64_t *out_idx2, uint8_t *out_ulps)
+{
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+        const float *p = pts + 3 * i;
+        float best = INFINITY, second = INFINITY, thr = INFINITY;
+        int64_t bf = -1, sf = -1;
+        int32_t stack[256];
+        int sp = 0;
+        if (A->F > 0) stack[sp++] = 0;
+        while (sp > 0) {
+            const anode *n = &A->nodes[stack[--sp]];
+            if (box_d2(n, p) > thr) continue;
+            if (n->left < 0) {
+                const int32_t first = -1 - n->left;
+                for (int32_t k = first; k < first + n->right; ++k) {
+                    const int64_t f = A->order[k];
+                    const float d = orc_tri_dist2(p, A->tri + f);
+                    if (!(d == d)) continue;                                       /* NaN never wins, never runs up */
+                    if (bf < 0 || d < best || (d == best && f < bf)) {
+                        second = best; sf = bf; best = d; bf = f; thr = prune_thr(best);
+                    } else if (sf < 0 || d < second || (d == second && f < sf)) {
+                        second = d; sf = f;
+                    }
+                }
+            } else {
+                const anode *l = &A->nodes[n->left], *r = &A->nodes[n->right];
+                const float dl = box_d2(l, p), dr = box_d2(r, p);
+                if (dl <= dr) { if (dr <= thr) stack[sp++] = n->right; if (dl <= thr) stack[sp++] = n->left; }
+                else          { if (dl <= thr) stack[sp++] = n->left; if (dr <= thr) stack[sp++] = n->right; }
+            }
+        }
+        out_d2[i] = best; out_idx[i] = bf < 0 ? 0 : bf;
+        /* the runner-up is exact when it lies within the pruning bound of the winner - always the case for the
+         * <= 255 ulps that are reported; farther away it is reported as 255 whatever was seen */
+        uint32_t u = 255;
+        if (sf >= 0 && second >= best) { const uint32_t g = f2u(second) - f2u(best); u = g < 255u ? g : 255u; }
+        out_idx2[i] = sf;                                   /* -1: the mesh has a single face */
+        out_ulps[i] = (uint8_t)u;
+    }
+}
+
+void orc_accel_apply_tie_rule(const orc_accel *A, const float *pts, int64_t N, float *io_d2, int64_t *io_idx)
+{
+    if (!g_tie_rule) return;
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < N; ++i) {
+        int64_t f = -1; float d = io_d2[i];
+        accel_within(A, pts + 3 * i, io_d2[i], f2u(io_d2[i]) + g_tie_ulps, &f, &d);
+        if (f >= 0) { io_idx[i] = f; io_d2[i] = d; }
+    }
+}
+
 void orc_accel_check_sign(const orc_accel *A, const float *pts, int64_t N, uint8_t *inside)
 {
     const float *verts = A->verts;

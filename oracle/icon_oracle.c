@@ -316,6 +316,7 @@ orc_accel *orc_accel_build(const float *verts, int64_t V, const int64_t *faces, 
 void orc_accel_free(orc_accel *A);
 void orc_accel_nearest(const orc_accel *A, const float *pts, int64_t N, float *out_d2, int64_t *out_idx);
 void orc_accel_check_sign(const orc_accel *A, const float *pts, int64_t N, uint8_t *inside);
+void orc_accel_apply_tie_rule(const orc_accel *A, const float *pts, int64_t N, float *io_d2, int64_t *io_idx);
 
 /* 1 (default): cal_sdf / query_icon answer the two O(N*F) leaves through icon_accel.c;
  * 0: through the linear scans above (the definition).  tests/test_oracle_leaves.py holds both equal. */
@@ -336,6 +337,7 @@ void orc_cal_sdf(const float *verts, int64_t V, const int64_t *faces, int64_t F,
     if (g_accel) {
         orc_accel *A = orc_accel_build(verts, V, faces, F);
         orc_accel_nearest(A, pts, N, d2, idx);
+        orc_accel_apply_tie_rule(A, pts, N, d2, idx);          /* diagnostics: no-op unless orc_set_tie_rule(1, u) */
         orc_accel_check_sign(A, pts, N, ins);
         orc_accel_free(A);
     } else {

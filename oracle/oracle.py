@@ -117,6 +117,20 @@ class Accel:
         lib().orc_accel_check_sign(self.h, _p(pts), C.c_int64(len(pts)), _p(out))
         return out.astype(bool)
 
+    def nearest_ties(self, pts):
+        """-> (d2, face, runner-up face (-1: none), ulps between their squared distances clipped to 255)"""
+        pts = _f32(pts).reshape(-1, 3)
+        n = len(pts)
+        d2, idx, idx2, ulps = np.empty(n, np.float32), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint8)
+        lib().orc_accel_nearest_ties(self.h, _p(pts), C.c_int64(n), _p(d2), _p(idx), _p(idx2), _p(ulps))
+        return d2, idx, idx2, ulps
+
+
+def set_tie_rule(rule: int = 0, ulps: int = 0) -> None:
+    """diagnostics: 1 = among the faces within ``ulps`` float32 ulps of the minimum d^2 the HIGHEST index wins
+    (cal_sdf / query_icon through the accelerated leaves); 0 = the definition (lowest index on exact ties)"""
+    lib().orc_set_tie_rule(C.c_int(rule), C.c_int(ulps))
+
 
 def check_sign(verts, faces, pts):
     verts, faces, pts = _f32(verts).reshape(-1, 3), _i64(faces).reshape(-1, 3), _f32(pts).reshape(-1, 3)

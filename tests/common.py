@@ -66,3 +66,11 @@ def chamfer(va, fa, vb, fb, n=20000, seed=0):
     d_ab = np.sqrt(orc.nearest_brute(vb.astype(np.float32), fb, pa)[0])
     d_ba = np.sqrt(orc.nearest_brute(va.astype(np.float32), fa, pb)[0])
     return 0.5 * (d_ab.mean() + d_ba.mean()) * 100.0, d_ab.mean() * 100.0
+
+
+# what IconQueryEngine.attach() / query() read from the network object they replace the method of
+# (lib/net/HGPIFuNet.py:48-165,236-245,268): tests/test_oracle_vs_reference.py checks the list against the reference's
+# real module, tests/test_gpu_ties_shell.py drives the HIP path through a frozen replica carrying exactly these
+ATTACH_NET_ATTRS = ("prior_type", "sdf_clip", "smpl_feats", "if_regressor", "smpl_feat_dict")
+ATTACH_REGRESSOR_ATTRS = ("norm", "last_op", "res_layers", "norms", "filters", "training")
+ATTACH_SMPL_KEYS = ("smpl_verts", "smpl_faces", "smpl_cmap", "smpl_vis")

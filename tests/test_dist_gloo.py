@@ -49,9 +49,20 @@ class OracleBackend:
             return out
         return t
 
-    def slab_features(self, im_feat, res, z0, z1, signs=None, count=None):
+    def slab_features(self, im_feat, res, z0, z1, signs=None, count=None, msg=None):
         self.calls.append(("features", z0, z1))
         lst = self._local_list(z0, z1)
+        if msg is not None:
+            # the exchange message of the single-collective protocol: [int64 K][2 bits per sign (sign + 1), 4 per byte]
+            n = (z1 - z0) * res * res
+            assert msg.element_size() == 1 and msg.numel() >= 8 + (n + 3) // 4
+            m = msg.numpy().view(np.uint8)
+            m[:] = 0xAB                               # garbage past the packed signs must never be used
+            m[:8] = np.array([len(lst)], np.int64).view(np.uint8)
+            pad = np.zeros((len(lst) + 3) // 4 * 4, np.uint8)
+            pad[: len(lst)] = (lst + 1).astype(np.uint8)
+            m[8:8 + len(pad) // 4] = (pad.reshape(-1, 4) << (2 * np.arange(4, dtype=np.uint8))).sum(1).astype(np.uint8)
+            return msg
         if signs is None:
             signs = torch.zeros((z1 - z0) * res * res, dtype=torch.int8)
         if count is None:
@@ -62,18 +73,30 @@ class OracleBackend:
         count[0] = len(lst)
         return signs, count
 
-    def slab_finish_gathered(self, res, z0, z1, gathered, stride, world, rank, out=None):
-        """the single-collective protocol: message r = [int64 count_r][int8 signs_r ...] at r * stride"""
-        self.calls.append(("finish", z0, z1))
-        assert gathered.dtype == torch.int8 and gathered.numel() == world * stride and stride % 8 == 0
-        g = gathered.numpy()
-        counts = [int(g[r * stride: r * stride + 8].view(np.int64)[0]) for r in range(world)]
-        lst = np.concatenate([g[r * stride + 8: r * stride + 8 + c] for r, c in enumerate(counts)])
-        exp = self._local_list(0, res)
-        assert sum(counts) == len(exp)
-        assert np.array_equal(lst, exp), "global sign list differs from lattice order"
-        assert sum(counts[:rank]) == int(self.out_mask[:z0].sum())
-        return self.eval_slab(None, res, z0, z1, out=out)
+    def slab_finish_gathered(self, res, z0, z1, gathered, stride, world, rank, out=None, za=None, zb=None, device=None):
+        """the single-collective protocol: message r = [int64 count_r][2-bit packed signs_r ...] at r * stride;
+        evaluates the planes [za, zb) of the slab into out (the slab's buffer)"""
+        za = z0 if za is None else za
+        zb = z1 if zb is None else zb
+        assert z0 <= za < zb <= z1
+        self.calls.append(("finish", z0, z1, za, zb))
+        if gathered is not None:
+            assert gathered.element_size() == 1 and gathered.numel() == world * stride and stride % 8 == 0
+            g = gathered.numpy().view(np.uint8)
+            counts = [int(g[r * stride: r * stride + 8].view(np.int64)[0]) for r in range(world)]
+            lst = []
+            for r, c in enumerate(counts):
+                b = g[r * stride + 8: r * stride + 8 + (c + 3) // 4]
+                lst.append((((b[:, None] >> (2 * np.arange(4, dtype=np.uint8))) & 3).reshape(-1)[:c]).astype(np.int8) - 1)
+            lst = np.concatenate(lst)
+            exp = self._local_list(0, res)
+            assert sum(counts) == len(exp)
+            assert np.array_equal(lst, exp), "global sign list differs from lattice order"
+            assert sum(counts[:rank]) == int(self.out_mask[:z0].sum())
+        else:
+            assert self.cmap_mode == "local"
+        out[za - z0: zb - z0].copy_(torch.from_numpy(self.full[za:zb].copy()))
+        return out
 
     def slab_finish(self, res, z0, z1, signs_global, k_total, rank_offset, out=None, device=None):
         self.calls.append(("finish", z0, z1))
@@ -92,7 +115,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cmap_mode, q, legacy=False):
+def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -101,6 +124,11 @@ def _worker(rank, world, port, cmap_mode, q, legacy=False):
         a = assets("ico")
         be = OracleBackend(a, cmap_mode)
         be.cmap_mode = cmap_mode
+        if skew:
+            # replicas of the SMPL tensors that differ between ranks (here grossly): every rank would derive another
+            # cost-weighted cut on its own - rank 0's cut must be the one everybody uses
+            be._mesh_key = ("image-1",)
+            be.mesh_z_range = lambda: (-0.9 + 0.5 * rank, -0.6 + 0.5 * rank)
         if legacy:
             class _NoGathered:                   # proxy without slab_finish_gathered -> legacy two-step exchange
                 def __init__(self, inner): self._i = inner
@@ -112,25 +140,44 @@ def _worker(rank, world, port, cmap_mode, q, legacy=False):
         else:
             be_used = be
         recon = DenseReconEngine(query_func=None, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
-                                 resolutions=[9, RES], align_corners=True, backend=be_used)
+                                 resolutions=[9, RES], align_corners=True, backend=be_used, overlap_gather=overlap)
         occ = recon(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)
         ok = occ is not None and occ.shape == (RES, RES, RES) and np.array_equal(occ.numpy(), be.full)
-        z0, z1, _ = slab_bounds(RES, world, rank)
+        if skew:
+            from icon_amd.recon import slab_partition, plane_weights
+            z0, z1 = slab_partition(RES, world, plane_weights(RES, -0.9, -0.6))[rank]       # rank 0's view of the body
+            ok = ok and recon.last_stats["slabs"][rank] == (z0, z1)
+            occ2 = recon(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)   # cached cut: no broadcast
+            ok = ok and np.array_equal(occ2.numpy(), be.full)
+            be.calls = be.calls[: len(be.calls) // 2]
+        else:
+            z0, z1, _ = slab_bounds(RES, world, rank)
         kinds = [c[0] for c in be.calls]
-        ok = ok and all(c[1:] == (z0, z1) for c in be.calls)
-        ok = ok and (kinds == (["features", "finish", "eval"] if cmap_mode == "reference" else ["eval"]))
+        ok = ok and all(c[1:3] == (z0, z1) for c in be.calls)
+        if legacy:
+            ok = ok and (kinds == (["features", "finish", "eval"] if cmap_mode == "reference" else ["eval"]))
+        else:
+            # phase 1, then the slab finished in one piece (overlap off) or two halves of the padded slab (overlap on)
+            pieces = [c[3:] for c in be.calls if c[0] == "finish"]
+            ok = ok and kinds[0] == "features" and set(kinds[1:]) <= {"finish"}
+            ok = ok and len(pieces) in ((1,) if not overlap else (1, 2))
+            ok = ok and pieces[0][0] == z0 and pieces[-1][1] == z1 and all(a1 == b0 for (_, a1), (b0, _) in zip(pieces[:-1], pieces[1:]))
         q.put((rank, bool(ok), kinds))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cmap_mode,legacy", [("reference", False), ("reference", True), ("local", False)])
+@pytest.mark.parametrize("cmap_mode,legacy,overlap,skew", [("reference", False, True, False), ("reference", False, False, False),
+                                                           ("reference", True, True, False), ("local", False, True, False),
+                                                           ("local", True, True, False), ("reference", False, True, True)])
 @pytest.mark.parametrize("world", [2, 3])
-def test_zslab_sharding_gloo(cmap_mode, legacy, world):
+def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, world):
+    """packed sign messages, the two-half volume gather, the legacy host-side exchange, and ranks whose replicas of
+    the body disagree (rank 0's cut is broadcast)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, legacy)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, legacy, overlap, skew)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]

@@ -473,32 +473,50 @@ def test_threaded_bvh_build_equals_sequential(mesh, monkeypatch):
         assert torch.equal(o1[k], o2[k]), k
 
 
+def unpack_signs(msg: np.ndarray):
+    """[int64 K][2 bits per sign (sign + 1), four to a byte, low bits first] -> int8 [K]"""
+    k = int(msg[:8].view(np.int64)[0])
+    b = msg[8:8 + (k + 3) // 4].view(np.uint8)
+    s = ((b[:, None] >> (2 * np.arange(4, dtype=np.uint8))) & 3).reshape(-1)[:k].astype(np.int8) - 1
+    return s
+
+
+@pytest.mark.parametrize("pieces", [1, 2, 3])
 @pytest.mark.parametrize("world", [2, 3, 5])
-def test_lattice_slab_split_gathered_messages(body, world):
-    """the single-collective protocol of the multi-GPU path: every 'rank' writes [int64 count][signs]
-    into a fixed-size message, the concatenation (what all_gather returns) goes to phase 2 as it is"""
+def test_lattice_slab_split_gathered_messages(body, world, pieces):
+    """the single-collective protocol of the multi-GPU path: every 'rank' writes [int64 count][2-bit signs]
+    into a fixed-size message, the concatenation (what all_gather returns) goes to phase 2 as it is; a slab may be
+    finished in several pieces (the driver gathers the first half while the second is computed)"""
     from icon_amd.recon import slab_bounds
     res = 33
     feat = T(body.features)
     full = make_engine(body).eval_slab(feat, res, 0, res)
     engines = [make_engine(body) for _ in range(world)]
     per = slab_bounds(res, world, 0)[2]
-    stride = 8 + (per * res * res + 7) // 8 * 8
+    stride = 8 + ((per * res * res + 3) // 4 + 7) // 8 * 8
     msgs = []
     for r, e in enumerate(engines):
         z0, z1, _ = slab_bounds(res, world, r)
         msg = torch.full((stride,), 77, dtype=torch.int8, device=dev())      # garbage past the count must not matter
         msg[:8] = 0
-        n = (z1 - z0) * res * res
         if z1 > z0:
-            e.slab_features(feat, res, z0, z1, signs=msg[8:8 + n], count=msg[:8].view(torch.int64))
+            assert e.slab_features(feat, res, z0, z1, msg=msg) is msg
         msgs.append(msg)
     gathered = torch.cat(msgs).contiguous()
+    # the messages decode to the oracle's outlier signs in lattice order
+    o = orc.cal_sdf(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], synth.lattice_points(res))
+    exp = np.sign(o["sdf"][np.abs(o["sdf"]) >= np.float32(body.sdf_clip)]).astype(np.int8)
+    got = np.concatenate([unpack_signs(m.cpu().numpy()) for m in msgs])
+    assert np.array_equal(got, exp)
     parts = []
     for r, e in enumerate(engines):
         z0, z1, _ = slab_bounds(res, world, r)
         if z1 > z0:
-            parts.append(e.slab_finish_gathered(res, z0, z1, gathered, stride, world, r))
+            out = torch.full((z1 - z0, res, res), float("nan"), device=dev())
+            cuts = np.unique(np.linspace(z0, z1, pieces + 1).round().astype(int))
+            for za, zb in zip(cuts[:-1], cuts[1:]):
+                e.slab_finish_gathered(res, z0, z1, gathered, stride, world, r, out=out, za=int(za), zb=int(zb))
+            parts.append(out)
     assert torch.equal(torch.cat(parts), full)
 
 

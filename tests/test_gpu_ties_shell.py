@@ -1,0 +1,366 @@
+"""GPU tests of round 3: parity at the headline sizes against the oracle, tie sensitivity of the nearest-triangle
+choice (the unpinned kaolin leaf, lib/dataset/mesh_util.py:374-390), the shell skip (in_cube is strict,
+lib/net/HGPIFuNet.py:274-275,363), per-device / per-thread state, clean_mesh connectivity."""
+import threading
+
+import numpy as np
+import pytest
+import torch
+
+from common import assets, oracle_query, orc
+from icon_amd import synth
+from test_gpu_parity import T, dev, make_engine, OCC_TOL
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def body():
+    return assets("body")
+
+
+def stratified_sample(occ_flat: torch.Tensor, res: int, n_each: int, seed: int = 1993) -> np.ndarray:
+    """uniform points, points around the 0.5 level set (where the mesh comes from) and shell points"""
+    rng = np.random.RandomState(seed)
+    n = occ_flat.numel()
+    uni = rng.randint(0, n, n_each)
+    band = torch.nonzero((occ_flat > 0.2) & (occ_flat < 0.8)).reshape(-1).cpu().numpy()
+    lvl = band[rng.randint(0, len(band), min(n_each, len(band)))] if len(band) else uni[:0]
+    k = rng.randint(0, res, (n_each // 4, 3))
+    k[np.arange(len(k)), rng.randint(0, 3, len(k))] = rng.choice([0, res - 1], len(k))
+    shell = (k[:, 2].astype(np.int64) * res + k[:, 1]) * res + k[:, 0]
+    return np.unique(np.concatenate([uni, lvl, shell])).astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------------
+# the headline configurations against the oracle itself (not only through invariants)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("res,n_each", [(257, 24000), (513, 24000)])
+def test_headline_lattice_vs_oracle(body, res, n_each):
+    """cfg 2 (257^3) and cfg 5's volume (513^3), cmap_mode=reference, f16x3 - the benchmarked mode: the oracle's
+    geometry on the WHOLE lattice (the tiled outlier-cmap rule couples every point to the sign list of the call),
+    outlier count K and the sign list bit-exact, occupancy against the float64 MLP on a stratified sample <= 1e-4"""
+    feat = T(body.features)
+    eng = make_engine(body, cmap_mode="reference", precision="f16x3")
+    occ = eng.eval_slab(feat, res, 0, res).reshape(-1)
+    idx = stratified_sample(occ, res, n_each)
+    assert len(idx) >= 50000
+    pts = synth.lattice_points(res)
+    ref, _ = orc.query_icon_subset(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features,
+                                   orc.Mlp(body.state_dict), pts, idx, sdf_clip=body.sdf_clip, f64=True)
+    got = occ[torch.from_numpy(idx).to(occ.device)].cpu().numpy()
+    err = np.abs(got - ref)
+    assert err.max() <= OCC_TOL, (err.max(), int((err > OCC_TOL).sum()))
+    # K and the sign list: the slab's own list, read back
+    signs, count = eng.slab_features(feat, res, 0, res)
+    k = int(count.item())
+    A = orc.Accel(body.smpl_verts[0], body.smpl_faces[0])
+    d2, _ = A.nearest(pts)
+    ins = A.check_sign(pts)
+    sdf = np.where(ins, 1.0, -1.0).astype(np.float32) * (np.sqrt(d2) / np.sqrt(np.float32(3.0)))
+    outl = np.abs(sdf) >= np.float32(body.sdf_clip)
+    exp = np.sign(sdf[outl]).astype(np.int8)
+    assert k == len(exp)
+    assert np.array_equal(signs[:k].cpu().numpy(), exp)
+
+
+# ---------------------------------------------------------------------------------------------
+# tie sensitivity
+# ---------------------------------------------------------------------------------------------
+def tie_point_sets(a):
+    v, f = a.smpl_verts[0], a.smpl_faces[0]
+    rng = np.random.RandomState(5)
+    nrm = orc.vertex_normals(v, f)
+    on_vertex_normals = v[::7] + 0.3 * nrm[::7]                       # the vertex is the nearest feature: its whole fan ties
+    tri = v[f[::11]]
+    edge_mid_off = 0.5 * (tri[:, 0] + tri[:, 1]) + 0.2 * np.cross(tri[:, 1] - tri[:, 0], rng.randn(len(tri), 3)).astype(np.float32)
+    return np.concatenate([synth.lattice_points(33), synth.stratified_points(v, f, 6000, seed=4), on_vertex_normals.astype(np.float32),
+                           edge_mid_off.astype(np.float32), v[:500]]).astype(np.float32)
+
+
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+def test_tie_flags_vs_oracle(mesh):
+    """winner, runner-up and the ulp gap between their squared distances: HIP == oracle, bit for bit"""
+    from icon_amd.engine import MeshHandle
+    a = assets(mesh)
+    pts = tie_point_sets(a)
+    h = MeshHandle(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    g = {k: v.cpu().numpy() for k, v in h.sdf_query_ties(T(pts)).items()}
+    _, idx, idx2, ulps = orc.Accel(a.smpl_verts[0], a.smpl_faces[0]).nearest_ties(pts)
+    assert np.array_equal(g["face"], idx.astype(np.int32))
+    assert np.array_equal(g["ulps"], ulps)
+    near = ulps < 255                                               # beyond the reported range the runner-up is not defined
+    assert np.array_equal(g["face2"][near], idx2[near].astype(np.int32))
+    # the far field of a closed mesh is dominated by ties: vertices and edges are the nearest features
+    assert (ulps <= 1).mean() > 0.3
+    # and the winner is what the plain query returns
+    assert np.array_equal(h.sdf_query(T(pts))["face"].cpu().numpy(), idx)
+
+
+@pytest.mark.parametrize("ulps", [0, 1, 4])
+def test_alternative_tie_rule_vs_oracle(body, ulps):
+    """the whole pipeline under the alternative rule (highest index within `ulps` of the minimum) equals the oracle
+    under the same rule; it moves far-field values by much more than 1e-4 but not the level set"""
+    res = 33
+    feat = T(body.features)
+    base = make_engine(body).eval_slab(feat, res, 0, res)
+    eng = make_engine(body)
+    eng.tie_rule = ("highest", ulps)
+    alt = eng.eval_slab(feat, res, 0, res)
+    orc.set_tie_rule(1, ulps)
+    try:
+        ref, _ = oracle_query(body, synth.lattice_points(res))
+    finally:
+        orc.set_tie_rule(0, 0)
+    assert np.abs(alt.cpu().numpy().ravel() - ref).max() <= OCC_TOL
+    moved = (alt - base).abs() > 1e-4
+    assert moved.any(), "the synthetic body has exact far-field ties: the rule must matter somewhere"
+    assert torch.equal((alt > 0.5), (base > 0.5)), "no voxel changes side of the level set"
+    # switching the rule back restores the definition on the same engine
+    eng.tie_rule = None
+    assert torch.equal(eng.eval_slab(feat, res, 0, res), base)
+    # the explicit-point API follows the same rule (packets over the Morton order)
+    eng.tie_rule = ("highest", ulps)
+    pts = synth.lattice_points(res)
+    q = eng.query([feat], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0]
+    assert torch.equal(q, alt.reshape(-1))
+
+
+# ---------------------------------------------------------------------------------------------
+# shell skip
+# ---------------------------------------------------------------------------------------------
+def set_shell_skip(on):
+    from icon_amd import _lib
+    _lib.check(_lib.lib().icon_debug_set_shell_skip(int(on)))
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+@pytest.mark.parametrize("res", [3, 5, 17, 33, 65, 129])
+def test_shell_skip_equals_masked_evaluation(body, res, cmap_mode, precision):
+    """skipping the in_cube shell (search + MLP over the interior only, shell written as 0) == evaluating and masking
+    every point, bit for bit, fused and materialising paths, whole lattice and slabs; the sign list is unchanged"""
+    feat = T(body.features)
+    try:
+        set_shell_skip(0)
+        e0 = make_engine(body, cmap_mode=cmap_mode, precision=precision)
+        full0 = e0.eval_slab(feat, res, 0, res)
+        s0, c0 = e0.slab_features(feat, res, 0, res)
+        s0 = s0[: int(c0.item())].clone()
+        set_shell_skip(1)
+        e1 = make_engine(body, cmap_mode=cmap_mode, precision=precision)
+        full1 = e1.eval_slab(feat, res, 0, res, out=torch.full((res, res, res), float("nan"), device=dev()))
+        s1, c1 = e1.slab_features(feat, res, 0, res)
+        assert torch.equal(full0, full1)
+        assert int(c0.item()) == int(c1.item()) and torch.equal(s0, s1[: int(c1.item())])
+        for v in (full1,):
+            assert (v[0] == 0).all() and (v[-1] == 0).all() and (v[:, 0] == 0).all() and (v[:, -1] == 0).all()
+            assert (v[:, :, 0] == 0).all() and (v[:, :, -1] == 0).all()
+        if cmap_mode == "local" and res >= 5:      # slabs incl. ones that are all shell / start or end on it
+            for z0, z1 in [(0, 1), (0, 2), (res - 1, res), (1, res - 1), (res // 2, res)]:
+                out = torch.full((z1 - z0, res, res), float("nan"), device=dev())
+                assert torch.equal(e1.eval_slab(feat, res, z0, z1, out=out), full0[z0:z1]), (z0, z1)
+    finally:
+        set_shell_skip(1)
+
+
+def test_shell_skip_is_not_taken_when_the_body_reaches_the_boundary(body):
+    """a body whose bounding box comes closer to the cube's boundary than the clip band is wide: shell points are not
+    all clip-band outliers, the engine must evaluate everything (and still equal the oracle)"""
+    import copy
+    v = body.smpl_verts.copy()
+    v[..., 1] *= 1.0 / np.abs(v[..., 1]).max() * 0.97               # |y| up to 0.97: margin 0.03 < 0.05 * sqrt(3)
+    a = copy.copy(body)                                             # shallow: the cached assets stay untouched
+    a.smpl_verts = v.astype(np.float32)
+    res = 33
+    eng = make_engine(a)
+    occ = eng.eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
+    ref, _ = oracle_query(a, synth.lattice_points(res))
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    o = orc.cal_sdf(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], synth.lattice_points(res))
+    sdf = o["sdf"].reshape(res, res, res)
+    shell_not_outlier = (np.abs(sdf[:, [0, -1], :]) < np.float32(a.sdf_clip)).sum()
+    assert shell_not_outlier > 0, "the construction must put shell points inside the clip band"
+
+
+def test_fused_kernel_tile_order_is_free(body):
+    """the outlier rank of a point comes from the scan over the LINEAR order + the 64-point ballots, so the MLP tiles
+    need not be aligned with that order: pieces cut at arbitrary planes reproduce the whole slab (reference mode)"""
+    res = 65
+    feat = T(body.features)
+    eng = make_engine(body)
+    full = eng.eval_slab(feat, res, 0, res)
+    for z0, z1, cuts in [(0, res, [0, 1, 2, 31, 64, 65]), (7, 50, [7, 8, 29, 50])]:
+        eng.slab_features(feat, res, z0, z1)
+        if (z0, z1) != (0, res):
+            # a slab that is not the whole call: its own list is the call's list (what eval_slab computes for it)
+            want = eng.eval_slab(feat, res, z0, z1)
+            eng.slab_features(feat, res, z0, z1)
+        else:
+            want = full
+        out = torch.full((z1 - z0, res, res), float("nan"), device=dev())
+        for za, zb in zip(cuts[:-1], cuts[1:]):
+            eng.slab_finish_gathered(res, z0, z1, None, 0, 1, 0, out=out, za=za, zb=zb)
+        assert torch.equal(out, want), (z0, z1)
+
+
+# ---------------------------------------------------------------------------------------------
+# process-wide state
+# ---------------------------------------------------------------------------------------------
+def test_two_threads_drive_engines_on_the_same_device(body):
+    """engines created and used from two host threads (each with its own workspace and stream-ordered launches):
+    both reproduce the single-threaded volume"""
+    from icon_amd.recon import export_mesh_device
+    res = 65
+    feat = T(body.features)
+    want = make_engine(body).eval_slab(feat, res, 0, res)
+    want_mc = export_mesh_device(want, 0.5)
+    results, errors = {}, []
+
+    def worker(k):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                eng = make_engine(body)
+                for _ in range(3):
+                    occ = eng.eval_slab(feat, res, 0, res)
+                v, f = export_mesh_device(occ, 0.5)
+                torch.cuda.current_stream().synchronize()
+                results[k] = (occ, v.shape[0], f.shape[0])
+        except Exception as e:                      # surfaced below
+            errors.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        occ, nv, nf = results[k]
+        assert torch.equal(occ, want)
+        assert (nv, nf) == (want_mc[0].shape[0], want_mc[1].shape[0])
+
+
+def test_precision_can_be_changed_after_the_first_query(body):
+    """assigning eng.precision takes effect on the next call (and mx6 is never used uncalibrated)"""
+    res = 33
+    feat = T(body.features)
+    eng = make_engine(body, precision="f16x3")
+    a = eng.eval_slab(feat, res, 0, res)
+    eng.precision = "f32"
+    b = eng.eval_slab(feat, res, 0, res)
+    assert torch.equal(b, make_engine(body, precision="f32").eval_slab(feat, res, 0, res))
+    assert not torch.equal(a, b) and (a - b).abs().max() <= 1e-4
+    eng.precision = "mx6"
+    import warnings
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        c = eng.eval_slab(feat, res, 0, res)
+    assert eng.mx6_max_err is not None                        # calibrated on the switch
+    assert eng._effective_precision in ("mx6", "f16x3")
+    if eng._effective_precision == "f16x3":
+        assert torch.equal(c, a)
+    eng.precision = "f16x3"
+    assert torch.equal(eng.eval_slab(feat, res, 0, res), a)
+
+
+# ---------------------------------------------------------------------------------------------
+# clean_mesh connectivity (trimesh: faces are connected through shared EDGES)
+# ---------------------------------------------------------------------------------------------
+def test_clean_mesh_splits_components_that_touch_in_one_vertex():
+    from icon_amd.recon import clean_mesh, face_components
+    # two tetrahedra sharing exactly one vertex (a marching-cubes pinch), the second with one more (isolated) triangle fan
+    a = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32)
+    b = np.array([[0, 0, 0], [-1, 0, 0], [0, -1, 0], [0, 0, -1], [-1, -1, -1]], np.float32)
+    v = np.concatenate([a, b[1:]])                                 # vertex 0 is shared
+    fa = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], np.int64)
+    ib = np.array([0, 4, 5, 6, 7])
+    fb_local = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 4], [1, 3, 4], [2, 3, 4]], np.int64)
+    fb = ib[fb_local]
+    f = np.concatenate([fa, fb])
+    lab = face_components(T(f), len(v)).cpu().numpy()
+    assert len(set(lab[:4])) == 1 and len(set(lab[4:])) == 1 and lab[0] != lab[4], lab
+    cv, cf = clean_mesh(T(v), T(f))
+    # the larger component (5 vertices) wins; a vertex union-find would have returned all 8 vertices
+    assert cv.shape[0] == 5 and cf.shape[0] == 6
+    assert cf.dtype == torch.int32 and cv.dtype == torch.float32
+    kept = cv.cpu().numpy()[cf.cpu().numpy().astype(np.int64)]
+    assert np.array_equal(kept, v[fb])
+    # equal vertex counts: the component met first in face order
+    cv2, cf2 = clean_mesh(T(v[:7]), T(np.concatenate([fa, ib[fb_local[:3]]])))
+    assert np.array_equal(cv2.cpu().numpy()[cf2.cpu().numpy().astype(np.int64)], v[fa])
+
+
+# ---------------------------------------------------------------------------------------------
+# attach(): the HIP path behind a network object carrying exactly what the reference's HGPIFuNet carries
+# ---------------------------------------------------------------------------------------------
+def test_attach_on_a_frozen_replica_of_the_reference_network(body):
+    """icon prior: a module with exactly the attributes tests/test_oracle_vs_reference.py verified on the real
+    HGPIFuNet (ATTACH_*): attach -> netG.query == oracle; reconEngine(netG=netG) attaches by itself; a second
+    filter() (new SMPL tensors) is picked up"""
+    from types import SimpleNamespace
+    from common import ATTACH_NET_ATTRS, ATTACH_REGRESSOR_ATTRS, ATTACH_SMPL_KEYS
+    from icon_amd.engine import IconQueryEngine, query_func
+    from icon_amd.recon import DenseReconEngine
+    from oracle.query_torch import TorchMLP
+
+    class FrozenHGPIFuNet(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.prior_type, self.sdf_clip, self.smpl_feats = "icon", body.sdf_clip, ["sdf", "norm", "vis", "cmap"]
+            self.if_regressor = TorchMLP()
+            self.if_regressor.norm, self.if_regressor.last_op = "batch", None
+            self.smpl_feat_dict = None
+
+        def query(self, *a, **k):
+            raise AssertionError("the reference's torch query must have been replaced")
+
+    netG = FrozenHGPIFuNet().eval()
+    netG.if_regressor.load_state_dict({k: torch.from_numpy(v) for k, v in body.state_dict.items()}, strict=False)
+    netG.to(dev())
+    netG.smpl_feat_dict = {k: T(getattr(body, k)) for k in ATTACH_SMPL_KEYS}
+    assert all(hasattr(netG, n) for n in ATTACH_NET_ATTRS) and all(hasattr(netG.if_regressor, n) for n in ATTACH_REGRESSOR_ATTRS)
+    eng = IconQueryEngine.attach(netG)
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 4000, seed=12)
+    feats = [T(body.features)]
+    occ = query_func(SimpleNamespace(num_views=1), netG, feats, T(pts)[None])[0, 0].cpu().numpy()
+    ref, _ = oracle_query(body, pts)
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    # reconEngine(opt=, netG=, features=, proj_matrix=) finds the attached engine (apps/ICON.py:749-751)
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33],
+                             align_corners=True).to(dev())
+    vol = recon(opt=SimpleNamespace(num_views=1), netG=netG, features=feats, proj_matrix=None)
+    ref33, _ = oracle_query(body, synth.lattice_points(33))
+    assert np.abs(vol.cpu().numpy().ravel() - ref33).max() <= OCC_TOL
+    # the next image: filter() binds new SMPL tensors (HGPIFuNet.py:236-240); the engine must notice
+    ico = assets("ico")
+    netG.smpl_feat_dict = {k: T(getattr(ico, k)) for k in ATTACH_SMPL_KEYS}
+    occ2 = query_func(SimpleNamespace(num_views=1), netG, feats, T(pts)[None])[0, 0].cpu().numpy()
+    ref2, _ = orc.query_icon(ico.smpl_verts[0], ico.smpl_faces[0], ico.smpl_cmap[0], ico.smpl_vis[0], body.features,
+                             orc.Mlp(body.state_dict), pts, sdf_clip=body.sdf_clip)
+    assert np.abs(occ2 - ref2).max() <= OCC_TOL
+    assert eng is netG.icon_amd_engine
+
+
+def test_bench_self_launch_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` as the driver calls it: the script starts its own ranks; under
+    ICON_AMD_DIST_BACKEND=gloo two ranks share this one GPU (control flow only) and rank 0 prints the JSON line;
+    with RCCL it stops at rank setup with a message that says how many devices are needed"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from common import ROOT
+    base = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--res", "65",
+            "--no-cpu-baseline", "--no-extras"]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run(base, env=dict(env, ICON_AMD_DIST_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and len(out["config"]["rank_stage_ms"]) == 2 and out["config"]["parallelism"] == "zslab2"
+    planes = [r["planes"] for r in out["config"]["rank_stage_ms"]]
+    assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 65
+    if torch.cuda.device_count() < 2:
+        p = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        assert p.returncode != 0 and "need 2 HIP devices" in p.stderr

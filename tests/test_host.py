@@ -207,3 +207,24 @@ def test_handle_cache_keys_hold_their_tensors():
         assert re.search(rf"self\.{name}\s*=|self\._\w+_key, self\.{name} =", src), name
     eng = IconQueryEngine()
     assert eng._feat_src is None and eng.precision == "f16x3"
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (how the driver calls it) starts two ranks under torch.distributed.run itself; in this
+    container they stop at rank setup for want of a HIP device - with that message, not with a launcher usage error"""
+    import subprocess
+    import sys
+    env = dict(os.environ, ICON_AMD_DIST_BACKEND="gloo", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--res", "17",
+                        "--no-cpu-baseline", "--no-extras"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    import torch
+    if torch.cuda.is_available():
+        assert p.returncode == 0, p.stderr[-2000:]
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")][-1]
+        import json
+        out = json.loads(line)
+        assert out["n_gpus"] == 2 and len(out["config"]["rank_stage_ms"]) == 2
+    else:
+        assert p.returncode != 0
+        assert "needs a HIP device" in p.stderr and "launch multi-GPU runs with" not in p.stderr

@@ -146,3 +146,58 @@ def test_reference_voxelization_wrapper_around_the_leaf(ref, monkeypatch):
     mine = orc.semantic_voxelize(vv, len(code), code, tets, res=res, sigma=sigma)
     assert np.array_equal(vol[0].permute(1, 2, 3, 0).numpy(), mine)
     assert mine.any()
+
+
+def test_attach_reads_the_reference_network(ref):
+    """IconQueryEngine.attach() on the reference's REAL HGPIFuNet (no device needed up to the first kernel launch):
+    every attribute the engine reads exists with the meaning it assumes, the regressor check accepts the shipped
+    configuration and refuses the ones the kernels do not evaluate (lib/net/HGPIFuNet.py:48-165,236-245; MLP.py:8-72)"""
+    from common import ATTACH_NET_ATTRS, ATTACH_REGRESSOR_ATTRS, ATTACH_SMPL_KEYS
+    from icon_amd.engine import IconQueryEngine, IconAmdError, check_regressor, regressor_state_dict
+    a = assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    for name in ATTACH_NET_ATTRS:
+        assert hasattr(netG, name), name
+    for name in ATTACH_REGRESSOR_ATTRS:
+        assert hasattr(netG.if_regressor, name), name
+    assert set(ATTACH_SMPL_KEYS) <= set(netG.smpl_feat_dict)
+    original = netG.query
+    eng = IconQueryEngine.attach(netG)
+    assert eng.netG is netG and netG.icon_amd_engine is eng and netG.query == eng.query and netG.query != original
+    assert eng.prior_type == "icon" == netG.prior_type
+    assert eng.sdf_clip == pytest.approx(cfg.sdf_clip / 100.0) == pytest.approx(netG.sdf_clip)       # HGPIFuNet.py:70
+    assert eng.res_layers == tuple(netG.if_regressor.res_layers) == (2, 3, 4)
+    assert set(netG.smpl_feats) == {"sdf", "norm", "vis", "cmap"}
+    # the real if_regressor: eval-mode BatchNorm1d, no last_op (cfg.test_mode) -> accepted, state_dict in the packed layout
+    check_regressor(netG.if_regressor)
+    sd = regressor_state_dict(netG.if_regressor)
+    assert [tuple(sd[f"filters.{l}.weight"].shape) for l in range(4)] == [(512, 13, 1), (256, 512, 1), (128, 269, 1), (1, 141, 1)]
+    assert all(f"norms.{l}.running_var" in sd for l in range(3)) and not any("num_batches_tracked" in k for k in sd)
+    for k, v in a.state_dict.items():
+        assert np.array_equal(sd[k].numpy(), v), k
+    # what the kernels do not evaluate is refused, by name
+    netG.if_regressor.train()
+    with pytest.raises(IconAmdError, match="training mode"):
+        check_regressor(netG.if_regressor)
+    netG.if_regressor.eval()
+    # the reference's own MLP class built the way HGPIFuNet.py:128-133 builds it, in the configurations that exist upstream
+    # but that the kernels do not evaluate (whole networks are 372 M parameters each - the regressor is what is checked)
+    dims = [13, 512, 256, 128, 1]
+    mlp_group = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="group", last_op=None).eval()   # lib/common/config.py:80 - the config default
+    with pytest.raises(IconAmdError, match="norm"):
+        check_regressor(mlp_group)
+    with pytest.raises(IconAmdError, match="running statistics"):
+        check_regressor(dict(mlp_group.state_dict()))
+    mlp_sig = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="batch", last_op=torch.nn.Sigmoid()).eval()  # cfg.test_mode False
+    with pytest.raises(IconAmdError, match="last_op"):
+        check_regressor(mlp_sig)
+    # subsets of smpl_feats are refused at attach time (HGPIFuNet.py:301-309)
+    netG.smpl_feats = ["sdf", "norm"]
+    with pytest.raises(IconAmdError, match="smpl_feats"):
+        IconQueryEngine.attach(netG)
+    netG.smpl_feats = ["sdf", "norm", "vis", "cmap"]
+    # and without a device the first launch fails loudly instead of falling back to anything
+    if not torch.cuda.is_available():
+        with pytest.raises(IconAmdError):
+            netG.query(features=[T(a.features)], points=T(np.zeros((1, 3, 4), np.float32)), calibs=torch.eye(4)[None],
+                       regressor=netG.if_regressor)

@@ -6,9 +6,25 @@ half of the bytes of a wide (16 B/lane) coalesced streaming read; other access w
 uncalibrated.  Both the raw value and the x2-corrected fetch are written; totals use the corrected fetch
 (an upper bound for the kernels whose loads are narrower than 16 B/lane)."""
 import collections
+import glob
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_sources_sha() -> str:
+    """fingerprint of everything the kernels are compiled from: bench.py reports profiles/traffic.json only while it
+    matches (a PMC pass is a separate run; a stale file must not pose as a measurement of the current kernels)"""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "icon_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "icon_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "icon_amd", "csrc", "*.cpp")) + [os.path.join(ROOT, "icon_amd", "csrc", "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def short(name):
@@ -43,6 +59,7 @@ def traffic(fetch_db, write_db):
         if "pack_planes" in k:          # per-image preparation, not part of a step
             continue
         tot_raw += fr; tot_cor += 2.0 * fr; tot_w += wr
+    out["kernel_sources_sha"] = kernel_sources_sha()
     out["note"] = ("per dispatch, one 257^3 step; FETCH_SIZE doubled per MI355X_MICROARCH.md (exact for 16 B/lane streams, an upper "
                    "bound otherwise); WRITE_SIZE as reported")
     out["per_kernel"] = per
