@@ -131,7 +131,7 @@ struct Lattice {
 struct LatticeMap {
     int res, z0, nz;           // the slab: planes [z0, z0+nz); a point's linear index is relative to plane z0
     int tx, ty, tz;            // tile counts of the nearest-triangle search
-    int remap;                 // 0: single tiles alternate over the XCDs (default), 2: x-rows of tiles, 1: contiguous run of tiles per XCD
+    int remap;                 // 0: single tiles alternate over the XCDs, x rotated per row (default), 3: the same without the rotation, 2: x-rows of tiles, 1: contiguous run of tiles per XCD
     // Shell skip (lib/net/HGPIFuNet.py:274-275,363: in_cube is strict, so every lattice point with a coordinate of
     // exactly +-1 - the outermost shell, 2.3 % of a 257^3 lattice - is multiplied by 0).  off = 1: the MLP tiles cover
     // the interior [off, res-off)^3 only and the shell is written as 0; off = 0: everything is evaluated and masked, as

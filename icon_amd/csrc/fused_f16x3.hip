@@ -306,17 +306,17 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         for (int c = 0; c < 16; ++c) {
             l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
                       w.inv0, h, lane, wave, bh, bl);
-            __syncthreads();
+            ICON_CHUNK_BARRIER();
         }
 #pragma unroll
         for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
         activate_split(acc1[0], w.inv1, bh, bl);
         l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-        __syncthreads();
+        ICON_CHUNK_BARRIER();
         l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-        __syncthreads();
+        ICON_CHUNK_BARRIER();
         l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-        __syncthreads();
+        ICON_CHUNK_BARRIER();
         l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, more ? 0 : -1);
 
         // ---- layer 3 on the VALU (f32) ---------------------------------------------------------------------

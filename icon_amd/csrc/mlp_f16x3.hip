@@ -33,6 +33,9 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
+#if defined(ICON_EXP_PRIO)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses the issue arbitration otherwise
+#endif
     const int64_t base = ((int64_t)blockIdx.x * (kF16Block / 64) + wave) * 32;
     const int64_t pi = min(base + j, N - 1);      // waves past the end still help with the DMA + barriers
 
@@ -71,7 +74,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     for (int c = 0; c < 16; ++c) {
         l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
                   w.inv0, h, lane, wave, bh, bl);
-        __syncthreads();   // all waves done with this buffer AND the next chunk has landed
+        ICON_CHUNK_BARRIER();   // all waves done with this buffer AND the next chunk has landed
     }
 
     // ---- layer 2: K = 256 (registers) + 16 (raw input) ---------------------------------------------
@@ -80,11 +83,11 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
     activate_split(acc1[0], w.inv1, bh, bl);
     l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-    __syncthreads();
+    ICON_CHUNK_BARRIER();
     l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-    __syncthreads();
+    ICON_CHUNK_BARRIER();
     l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
-    __syncthreads();
+    ICON_CHUNK_BARRIER();
     l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
 
     // ---- layer 3 on the VALU (f32) ----------------------------------------------------------------

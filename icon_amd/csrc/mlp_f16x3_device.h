@@ -89,8 +89,20 @@ __device__ __forceinline__ half8 lds_op(const char *buf, int slot, int lane)
 }
 
 // every wave DMAs 1 KiB pieces round-robin: global [piece][lane][16 B] -> LDS, same order
+// Timing-only experiment switches (tools/exp_fused.sh builds variants with -DICON_EXP_*; every one of them gives WRONG
+// results - they price one component of the kernel by removing it): NO_AREADS - one A-operand group per chunk, reused;
+// NO_DMA - no global->LDS weight stream; NO_ACT - no LeakyReLU / hi-lo split VALU work; NO_BAR - no chunk barriers.
+#if defined(ICON_EXP_NO_BAR)
+#define ICON_CHUNK_BARRIER() do { } while (0)
+#else
+#define ICON_CHUNK_BARRIER() __syncthreads()
+#endif
+
 __device__ __forceinline__ void issue_units(const char *src, char *buf, int units, int wave, int lane)
 {
+#if defined(ICON_EXP_NO_DMA)
+    if (units != kW0Bytes / 1024) return;
+#endif
     for (int u = wave; u < units; u += kF16Block / 64)
         __builtin_amdgcn_global_load_lds((gvoid_t *)(src + u * 1024 + lane * 16), (lvoid_t *)(buf + u * 1024), 16, 0, 0);
 }
@@ -112,10 +124,18 @@ __device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k,
 // stays in flight for the whole multiplication of chunk k and is only waited for at the barrier.
 
 // 3-term product group for 2 output tiles sharing one B operand pair
+#if defined(ICON_EXP_GRAY)
+// experiment: every MFMA shares one operand with its predecessor (does operand-latch toggling cost energy?)
+#define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
+    ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); \
+    ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
+    ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]); ACC[M0] = MFMA16(AL[0], BH, ACC[M0]);
+#else
 #define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
     ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AL[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]);
+#endif
 
 // layer 0, hidden tile c (32 channels): 3 MFMAs from the resident W0 region
 __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const float *__restrict__ sb0, int c, half8 xhi, half8 xlo,
@@ -131,11 +151,39 @@ __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const flo
 // hi/lo halves -> pair (k&3) of the next B operand (u = k>>2)
 __device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, half8 (&nh)[2], half8 (&nl)[2])
 {
+#if defined(ICON_EXP_NO_ACT)
+    {   // keep the data dependence on the accumulator (one v_mov-class op per pair), drop the arithmetic
+        const int u = k >> 2, q = k & 3;
+        const fp16x2 raw = __builtin_bit_cast(fp16x2, __float_as_int(acc[2 * k]) ^ __float_as_int(inv));
+        nh[u][2 * q] = (_Float16)raw[0]; nh[u][2 * q + 1] = (_Float16)raw[1];
+        nl[u][2 * q] = (_Float16)raw[1]; nl[u][2 * q + 1] = (_Float16)raw[0];
+        return;
+    }
+#endif
 
+#if defined(ICON_EXP_ACT7)
+    // LeakyReLU(0.01) with the weight scale folded in: max(x, 0.01 x) = 0.505 x + 0.495 |x| -> v = fma(|a|, c2, c1 a),
+    // c1 = 0.505 inv, c2 = 0.495 inv: 2 VALU per value instead of 3 (7 instead of 9 per pair)
+    const float c1 = 0.505f * inv, c2 = 0.495f * inv;
+    const float v0 = fmaf(fabsf(acc[2 * k]), c2, c1 * acc[2 * k]), v1 = fmaf(fabsf(acc[2 * k + 1]), c2, c1 * acc[2 * k + 1]);
+#else
     const float x0 = acc[2 * k] * inv, x1 = acc[2 * k + 1] * inv;
     const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
+#endif
     fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     fp16x2 ll = residual_pair(hh, v0, v1);
+#if defined(ICON_EXP_ACT2X)
+    {   // the same 9 VALU once more on the same data, results discarded: what does a VALU instruction cost on real data?
+        float y0 = acc[2 * k], y1 = acc[2 * k + 1];
+        asm volatile("" : "+v"(y0), "+v"(y1));
+        const float z0 = y0 * inv, z1 = y1 * inv;
+        const float u0 = fmaxf(z0, 0.01f * z0), u1 = fmaxf(z1, 0.01f * z1);
+        fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(u0, u1);
+        fp16x2 l2 = residual_pair(h2, u0, u1);
+        int a2 = __builtin_bit_cast(int, h2), b2 = __builtin_bit_cast(int, l2);
+        asm volatile("" :: "v"(a2), "v"(b2));
+    }
+#endif
     // the (empty) volatile asm is ordered against the surrounding sched_barriers, which keeps this
     // VALU work in the MFMA group it was written next to instead of being sunk to the end of the chunk
     int hb = __builtin_bit_cast(int, hh), lb = __builtin_bit_cast(int, ll);
@@ -172,7 +220,11 @@ __device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__re
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
+#if defined(ICON_EXP_NO_AREADS)
+        if (g == 0) load_group(L, 1, lane, a[1]);
+#else
         if (g + 1 < 8) load_group(L, g + 1, lane, a[(g + 1) & 1]);
+#endif
         const int u = g >> 2, m0 = (g & 3) * 2;
         const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
         TRIPLE2(acc1, m0, ah, al, bh[u], bl[u])
@@ -209,7 +261,11 @@ __device__ __forceinline__ void l2_chunk(const char *__restrict__ L, char *__res
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#if defined(ICON_EXP_NO_AREADS)
+            if (g == 0) load2(1, a[1]);
+#else
             if (g + 1 < 4) load2(g + 1, a[(g + 1) & 1]);
+#endif
             const int u = g >> 1, m0 = (g & 1) * 2;
             const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
             TRIPLE2(acc2, m0, ah, al, bh[u], bl[u])

@@ -717,3 +717,24 @@ def get_visibility(xy: torch.Tensor, z: torch.Tensor, faces: torch.Tensor, image
                                           C.c_void_p(f_d.data_ptr()), C.c_int64(f_d.shape[0]), C.c_int(int(image_size)),
                                           C.c_void_p(vis.data_ptr()), _stream()), "icon_visibility")
     return vis[:, None].to(out_dev)
+
+
+def compute_vis_cmap(smpl_verts, smpl_faces, cmap_table, smplx_ind=None, device=None) -> dict:
+    """Drop-in for ``TestDataset.compute_vis_cmap`` (lib/dataset/TestDataset.py:134-148): the per-image SMPL tensors that
+    ``HGPIFuNet.filter`` copies into ``smpl_feat_dict`` (lib/net/HGPIFuNet.py:236-240).  ``smpl_verts [V,3]`` in the [-1,1]
+    cube, ``smpl_faces [F,3]``; ``cmap_table`` is what ``SMPLX.get_smpl_mat`` loads (data/smpl_related/smpl_data/
+    smplx_cmap.npy - an asset, passed in), ``smplx_ind`` the SMPL->SMPL-X vertex map for ``smpl_type == 'smpl'``
+    (``SMPLX.smpl2smplx``; default: identity, the 'smplx' branch).  Visibility comes from the HIP z-buffer
+    (get_visibility) - no pytorch3d.  Returns the reference's dict: smpl_vis [1,V,1], smpl_cmap [1,V,3] on ``device``,
+    smpl_verts [1,V,3] as passed."""
+    v = torch.as_tensor(smpl_verts)
+    f = torch.as_tensor(smpl_faces).long()
+    if device is None:
+        device = v.device if v.is_cuda else torch.device("cuda", torch.cuda.current_device())
+    (xy, z) = v.split([2, 1], dim=1)
+    smpl_vis = get_visibility(xy, -z, f)
+    ind = torch.arange(smpl_vis.shape[0]) if smplx_ind is None else torch.as_tensor(np.asarray(smplx_ind)).long().reshape(-1)
+    table = torch.as_tensor(np.asarray(cmap_table) if not isinstance(cmap_table, torch.Tensor) else cmap_table).float()
+    smpl_cmap = table[ind.to(table.device), :]
+    return {"smpl_vis": smpl_vis.unsqueeze(0).to(device), "smpl_cmap": smpl_cmap.unsqueeze(0).to(device),
+            "smpl_verts": v.unsqueeze(0)}

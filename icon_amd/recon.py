@@ -70,13 +70,15 @@ def plane_weights(res: int, z_lo: float, z_hi: float, far_cost: float = 1.04) ->
 
 
 def lattice_coords(res, b_min, b_max, align_corners: bool, device) -> torch.Tensor:
-    """[1, res^3, 3] world coordinates in z,y,x-major order: create_grid3D
+    """[1, W*H*D, 3] world coordinates in z,y,x-major order: create_grid3D
     (lib/common/seg3d_utils.py:122-136) followed by the mapping of batch_eval
-    (lib/common/seg3d_lossless.py:125-137), evaluated with the same float32 torch ops."""
-    ar = torch.linspace(0, res - 1, res, device=device).long()
-    gd, gh, gw = torch.meshgrid([ar, ar, ar], indexing="ij")
+    (lib/common/seg3d_lossless.py:125-137), evaluated with the same float32 torch ops.
+    ``res``: an int (cubic lattice) or the reference's (W, H, D) triple (seg3d_lossless.py:66-71)."""
+    W, H, D = (int(res),) * 3 if isinstance(res, (int, np.integer)) else (int(r) for r in res)
+    ax, ay, az = (torch.linspace(0, n - 1, n, device=device).long() for n in (W, H, D))
+    gd, gh, gw = torch.meshgrid([az, ay, ax], indexing="ij")
     coords = torch.stack([gw, gh, gd]).view(3, -1).t().unsqueeze(0)  # (x,y,z), x fastest
-    rr = torch.tensor([res, res, res], device=device)
+    rr = torch.tensor([W, H, D], device=device)
     if align_corners:
         c = coords.float() / (rr - 1)
     else:
@@ -121,6 +123,8 @@ class DenseReconEngine(nn.Module):
         for r in res_t:
             assert r[0] % 2 == 1 and r[1] % 2 == 1, \
                 f"resolution {r} need to be odd becuase of align_corner."
+        if any(len({int(v) for v in r}) != 1 for r in res_t) and query_func is None:
+            raise IconAmdError("per-axis resolutions are evaluated through query_func (one query over the materialised lattice): pass it")
         self.engine = engine
         self.backend = backend
         self.process_group = process_group
@@ -137,9 +141,19 @@ class DenseReconEngine(nn.Module):
         g = self.process_group
         return dist, dist.get_world_size(g), dist.get_rank(g)
 
+    def _res(self):
+        """``resolutions`` as Python ints [[W, H, D], ...].  The buffer lives on the device once the module is moved
+        there (it is a registered buffer, as upstream); every ``int(self.resolutions[...])`` is then a synchronous
+        D2H copy - a dozen of them per forward() cost more than the sign-list kernels.  Read once per (tensor, version)."""
+        key = (self.resolutions.data_ptr(), self.resolutions._version)
+        if getattr(self, "_res_key", None) != key:
+            self._res_cache = [[int(v) for v in row] for row in self.resolutions.cpu().tolist()]
+            self._res_key = key
+        return self._res_cache
+
     def _lattice_fast_path(self, proj_matrix) -> bool:
-        r = self.resolutions[-1]
-        ok = bool(self.align_corners) and proj_matrix is None and int(r[0]) == int(r[1]) == int(r[2])
+        r = self._res()[-1]
+        ok = bool(self.align_corners) and proj_matrix is None and r[0] == r[1] == r[2]
         if not ok:
             return False
         # the bounding-box buffers live on the device: compare them once per (tensor, version), not per call
@@ -171,7 +185,7 @@ class DenseReconEngine(nn.Module):
         if not self._lattice_fast_path(proj_matrix):
             return self._forward_generic(**kwargs)
         be = self._backend_for(netG)
-        res = int(self.resolutions[-1][0])
+        res = self._res()[-1][0]
         im_feat = features[-1] if isinstance(features, (list, tuple)) else features
         dist, world, rank = self._dist()
         if world == 1:
@@ -321,25 +335,22 @@ class DenseReconEngine(nn.Module):
         batch_eval does and issue ONE query over them (Seg3dLossless with a single resolution)."""
         if self.query_func is None:
             raise IconAmdError("generic lattice path needs query_func")
-        r = self.resolutions[-1]
-        if not (int(r[0]) == int(r[1]) == int(r[2])):
-            raise IconAmdError("non-cubic lattices are not supported")
-        res = int(r[0])
+        W, H, D = self._res()[-1]                              # per-axis resolutions (seg3d_lossless.py:66-71) take this path
         feats = kwargs.get("features")
         dev = (feats[-1] if isinstance(feats, (list, tuple)) else feats).device
-        pts = lattice_coords(res, self.b_min.to(dev), self.b_max.to(dev), self.align_corners, dev)
+        pts = lattice_coords((W, H, D), self.b_min.to(dev), self.b_max.to(dev), self.align_corners, dev)
         occ = self.query_func(**kwargs, points=pts)
         if type(occ) is list:
             occ = torch.stack(occ)
         assert len(occ.size()) == 3, "query_func should return a occupancy with shape of [bz, C, N]"
-        return self._none_if_empty(occ.view(res, res, res))
+        return self._none_if_empty(occ.view(D, H, W))
 
     def _none_if_empty(self, occ):
         """The reference returns None when nothing exceeds 0.5 on its coarsest lattice
         (seg3d_lossless.py:173-177); those points are the stride-s sub-lattice of ours."""
-        res, r0 = int(self.resolutions[-1][0]), int(self.resolutions[0][0])
-        s = max((res - 1) // max(r0 - 1, 1), 1)
-        if (occ[::s, ::s, ::s] > 0.5).sum() == 0:
+        rs = self._res()
+        st = [max((rs[-1][k] - 1) // max(rs[0][k] - 1, 1), 1) for k in range(3)]   # x, y, z
+        if (occ[::st[2], ::st[1], ::st[0]] > 0.5).sum() == 0:
             return None
         return occ
 
@@ -347,6 +358,13 @@ class DenseReconEngine(nn.Module):
     def export_mesh(self, occupancys):
         """lib/common/seg3d_lossless.py:583-604: marching cubes at balance_value on occ[1:,1:,1:];
         returns (verts [Nv,3] float32 in voxel units, x,y,z order; faces [Nf,3] int64)."""
+        if len(set(occupancys.shape)) != 1:
+            # per-axis resolutions: the marching-cubes kernels take a cube - pad the high end of the short axes with
+            # zeros (the lattice's own outer shell is 0 by in_cube, so the padding adds no surface and moves no vertex)
+            n = max(occupancys.shape)
+            padded = occupancys.new_zeros((n, n, n))
+            padded[: occupancys.shape[0], : occupancys.shape[1], : occupancys.shape[2]] = occupancys
+            occupancys = padded
         if occupancys.is_cuda:
             verts, faces = export_mesh_device(occupancys, float(self.balance_value))
             return verts.cpu(), faces.cpu()          # the reference returns CPU tensors (:601-602)
@@ -390,7 +408,7 @@ class DenseReconEngine(nn.Module):
 
     def display(self, sdf):
         """[res, 4*res, 3] uint8: front | left | right | back normal renderings (seg3d_lossless.py:566-581)"""
-        res = int(self.resolutions[-1, -1])
+        res = self._res()[-1][-1]
         views = [self.render_normal(res, *self.find_vertices(sdf, d)) for d in ("front", "left", "right", "back")]
         image = torch.cat(views, dim=3)
         return np.uint8(image.detach().cpu().numpy()[0].transpose(1, 2, 0) * 255.0)
@@ -528,7 +546,7 @@ class AdaptiveReconEngine(DenseReconEngine):
         import torch.nn.functional as F
         if self.query_func is None:
             raise IconAmdError("AdaptiveReconEngine needs query_func")
-        res_list = [int(r[0]) for r in self.resolutions]
+        res_list = [r[0] for r in self._res()]
         last = res_list[-1]
         feats = kwargs.get("features")
         dev = (feats[-1] if isinstance(feats, (list, tuple)) else feats).device

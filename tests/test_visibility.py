@@ -122,3 +122,25 @@ def test_gpu_visibility_reference_call_pattern_and_errors():
         get_visibility(xy, -z, torch.from_numpy(f + len(v)).cuda())
     with pytest.raises(IconAmdError):
         get_visibility(xy[:-1], -z, torch.from_numpy(f).cuda())
+
+
+@pytest.mark.gpu
+def test_compute_vis_cmap_returns_the_reference_dict():
+    """TestDataset.compute_vis_cmap (lib/dataset/TestDataset.py:134-148): get_visibility(xy, -z, faces) + a row lookup in
+    the SMPL-X colour-map table, packed the way HGPIFuNet.filter expects them (smpl_feat_dict)"""
+    from icon_amd.engine import compute_vis_cmap
+    a = assets("body")
+    v, f = a.smpl_verts[0], a.smpl_faces[0]
+    rng = np.random.RandomState(3)
+    table = rng.rand(10475, 3).astype(np.float32)                       # SMPL-X sized asset stand-in
+    ind = rng.randint(0, len(table), len(v))                            # smpl2smplx stand-in
+    out = compute_vis_cmap(torch.from_numpy(v), torch.from_numpy(f), table, smplx_ind=ind)
+    assert set(out) == {"smpl_vis", "smpl_cmap", "smpl_verts"}
+    assert out["smpl_vis"].shape == (1, len(v), 1) and out["smpl_cmap"].shape == (1, len(v), 3) and out["smpl_verts"].shape == (1, len(v), 3)
+    assert out["smpl_vis"].is_cuda and out["smpl_cmap"].is_cuda
+    (xy, z) = torch.from_numpy(v).split([2, 1], dim=1)
+    want = orc.visibility(xy.numpy(), (-z).numpy(), f, 4096)             # the reference passes -z (TestDataset.py:137)
+    assert np.array_equal(out["smpl_vis"][0].cpu().numpy(), want)
+    assert np.array_equal(out["smpl_cmap"][0].cpu().numpy(), table[ind])
+    same = compute_vis_cmap(torch.from_numpy(v), torch.from_numpy(f), table[: len(v)])      # 'smplx' branch: identity map
+    assert np.array_equal(same["smpl_cmap"][0].cpu().numpy(), table[: len(v)])
