@@ -12,9 +12,19 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
+#if defined(ICON_EXP_HALFWG)
+// experiment (with NO_DMA + SLOTWRAP): workgroups of 4 waves / 128 points and 52 KiB of LDS, TWO per CU - do the serial
+// phases of one tile (prologue, barriers, layer 3) hide behind the MFMA phases of the other workgroup's tile?
+constexpr int kF16Block = 256;
+#else
 constexpr int kF16Block = 512;                 // 8 waves x 32 points
+#endif
 constexpr int kF16Pts = (kF16Block / 64) * 32; // 256 points per workgroup
+#if defined(ICON_EXP_SLOTWRAP)
+constexpr int kBufBytes = 8 * 1024;            // experiment: every A-operand read wraps into the first 8 slots
+#else
 constexpr int kBufBytes = 40 * 1024;
+#endif
 constexpr int kSideFloats = 512 + 256 + 128 + 144;   // b0 | b1 | b2 | w3, staged once per workgroup
 constexpr int kW0Off = 2 * kBufBytes;                // layer-0 operands, resident for the whole workgroup
 constexpr int kW0Bytes = 32 * 1024;
@@ -85,6 +95,9 @@ __device__ __forceinline__ void activate_split(const f32x16 &acc, float inv, hal
 
 __device__ __forceinline__ half8 lds_op(const char *buf, int slot, int lane)
 {
+#if defined(ICON_EXP_SLOTWRAP)
+    if (slot >= 8) slot &= 7;                  // (the resident W0 region is addressed with slots < 32 through the same helper: keep those)
+#endif
     return *reinterpret_cast<const half8 *>(buf + slot * 1024 + lane * 16);
 }
 

@@ -35,7 +35,7 @@ class TorchMLP(nn.Module):
         for i, f in enumerate(self.filters):
             y = f(y if i not in self.res_layers else torch.cat([y, x], 1))
             if i != len(self.filters) - 1:
-                y = F.leaky_relu(self.norms[i](y), 0.01)
+                y = F.leaky_relu(self.norms[i](y), 0.01, inplace=True)     # the reference's nn.LeakyReLU(inplace=True), MLP.py:24
         return y
 
 
