@@ -196,11 +196,18 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     // 250-register vector budget of the MFMA chain
     K = uniform64(K); rank0 = uniform64(rank0);
 
+    // every workgroup walks a CONTIGUOUS run of tiles: consecutive tiles share the cache lines at their common boundary
+    // (a tile of interior rows does not end on a line) and the triangles / feature texels of neighbouring points, and a
+    // workgroup stays on one XCD - interleaved over the grid, those lines were fetched into two L2s (105 vs 91 MB of HBM
+    // reads per 257^3 launch when the tiles stopped being 1 KiB-aligned runs of the linear order)
     const int64_t ntiles = (G.N + kTilePts - 1) / kTilePts;
-    int64_t tile = blockIdx.x;
-    if (tile < ntiles) issue_chunk(w.image, smem, 0, wave0, lane0);
+    const int64_t per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
+    int64_t tile = (int64_t)blockIdx.x * per + min((int64_t)blockIdx.x, rem);
+    const int64_t tile_end = uniform64(tile + per + ((int64_t)blockIdx.x < rem ? 1 : 0));
+    tile = uniform64(tile);
+    if (tile < tile_end) issue_chunk(w.image, smem, 0, wave0, lane0);
 
-    for (; tile < ntiles; tile += gridDim.x) {
+    for (; tile < tile_end; ++tile) {
         // Everything derived from the thread index is re-derived per tile from an opaque copy: hoisted out of
         // the loop, those ~20 lane-dependent addresses would have to stay live across the 250-register MFMA
         // body, i.e. be spilled to scratch (measured: 1.5 GB of scratch writes per 257^3 launch).
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         half8 bh[2], bl[2];
         activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
         f32x16 acc2[4];
-        const bool more = tile + gridDim.x < ntiles;            // the first chunks of the next tile ride on the last ones
+        const bool more = tile + 1 < tile_end;                  // the first chunks of the next tile ride on the last ones
         for (int c = 0; c < 16; ++c) {
             l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
                       w.inv0, h, lane, wave, bh, bl);

@@ -231,6 +231,9 @@ class DenseReconEngine(nn.Module):
         exactly when filter() produced new SMPL tensors, which all ranks do in lockstep)."""
         if not self.balance_slabs:
             return slab_partition(res, world, None)
+        zr = getattr(be, "mesh_z_range", None)
+        if callable(zr):
+            zr()                                                     # binds the mesh handle: its key is part of the cache key
         key = (res, world, getattr(be, "_mesh_key", None))
         if getattr(self, "_cuts_key", None) == key and key[2] is not None:
             return self._cuts

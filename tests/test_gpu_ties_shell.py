@@ -367,3 +367,60 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     if torch.cuda.device_count() < 2:
         p = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert p.returncode != 0 and "need 2 HIP devices" in p.stderr
+
+
+# ---------------------------------------------------------------------------------------------
+# randomised sweep over lattice sizes, slabs, pieces, clip bands and bodies (tile mapping, shell, ranks)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_random_lattices_slabs_and_pieces_vs_oracle(seed):
+    """whole lattice == oracle (<= 1e-4) and arbitrary slabs finished in arbitrary pieces == the whole-lattice volume of
+    the same sign source, for random resolutions (tile counts below / above the grid size, interiors that are not a
+    multiple of the tile), clip bands, bodies that do or do not reach the cube's boundary, both cmap modes"""
+    import copy
+    rng = np.random.RandomState(1000 + seed)
+    a = copy.copy(assets("body" if seed % 3 else "ico"))
+    v = a.smpl_verts.copy()
+    v *= rng.uniform(0.6, 1.04)                                             # up to the cube's boundary (0.93 * 1.04 = 0.97)
+    v += rng.uniform(-0.02, 0.02, 3).astype(np.float32)
+    a.smpl_verts = v.astype(np.float32)
+    a.sdf_clip = float(rng.choice([0.02, 0.05, 0.11]))
+    res = int(rng.choice([5, 7, 9, 13, 19, 27, 33, 41, 49]))
+    cmap_mode = "reference" if seed % 2 else "local"
+    feat = T(a.features)
+    eng = make_engine(a, cmap_mode=cmap_mode)
+    full = eng.eval_slab(feat, res, 0, res, out=torch.full((res, res, res), float("nan"), device=dev()))
+    ref, _ = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, orc.Mlp(a.state_dict),
+                            synth.lattice_points(res), sdf_clip=a.sdf_clip, cmap_local=(cmap_mode == "local"))
+    assert np.abs(full.cpu().numpy().ravel() - ref).max() <= OCC_TOL
+    if cmap_mode == "local":
+        # any slab, cut into any pieces, reproduces its planes of the whole volume (no coupling between points)
+        z0 = int(rng.randint(0, res - 1)); z1 = int(rng.randint(z0 + 1, res + 1))
+        cuts = sorted(set([z0, z1] + [int(c) for c in rng.randint(z0, z1 + 1, 3)]))
+        eng.slab_features(feat, res, z0, z1)
+        out = torch.full((z1 - z0, res, res), float("nan"), device=dev())
+        for za, zb in zip(cuts[:-1], cuts[1:]):
+            eng.slab_finish_gathered(res, z0, z1, None, 0, 1, 0, out=out, za=za, zb=zb)
+        assert torch.equal(out, full[z0:z1]), (res, z0, z1, cuts)
+    else:
+        # reference mode: "ranks" with their own slabs exchanging packed messages, pieces per rank
+        world = int(rng.randint(2, 5))
+        bounds = sorted(set([0, res] + [int(c) for c in rng.randint(0, res + 1, world - 1)]))
+        parts = list(zip(bounds[:-1], bounds[1:]))
+        per = max(b - x for x, b in parts)
+        stride = 8 + ((per * res * res + 3) // 4 + 7) // 8 * 8
+        engines = [make_engine(a, cmap_mode=cmap_mode) for _ in parts]
+        msgs = []
+        for (x, b), e in zip(parts, engines):
+            m = torch.full((stride,), 0x55, dtype=torch.int8, device=dev()); m[:8] = 0
+            e.slab_features(feat, res, x, b, msg=m)
+            msgs.append(m)
+        gathered = torch.cat(msgs).contiguous()
+        outs = []
+        for r, ((x, b), e) in enumerate(zip(parts, engines)):
+            out = torch.full((b - x, res, res), float("nan"), device=dev())
+            cuts = sorted(set([x, b] + [int(c) for c in rng.randint(x, b + 1, 2)]))
+            for za, zb in zip(cuts[:-1], cuts[1:]):
+                e.slab_finish_gathered(res, x, b, gathered, stride, len(parts), r, out=out, za=za, zb=zb)
+            outs.append(out)
+        assert torch.equal(torch.cat(outs), full), (res, parts)

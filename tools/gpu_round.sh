@@ -4,10 +4,13 @@
 T=${1:-rX}
 R=$PWD
 mkdir -p gpurun_out
+if [ -z "$PROFILES_ONLY" ]; then     # PROFILES_ONLY=1: kernel stats + HBM traffic + PMC only
 timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q > gpurun_out/${T}_pytest.log 2>&1; tail -3 gpurun_out/${T}_pytest.log
 timeout 600 python bench.py > gpurun_out/${T}_bench.log 2>&1; tail -1 gpurun_out/${T}_bench.log | cut -c1-400
 timeout 600 python bench.py --prior pamir --no-cpu-baseline > gpurun_out/${T}_bench_pamir.log 2>&1; tail -1 gpurun_out/${T}_bench_pamir.log | cut -c1-300
 timeout 600 python bench.py --precision f32 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > gpurun_out/${T}_bench_f32.log 2>&1; tail -1 gpurun_out/${T}_bench_f32.log | cut -c1-300
+timeout 600 python bench.py --res 513 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_513.log 2>&1; tail -1 gpurun_out/${T}_bench_513.log | cut -c1-300
+fi
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_stats.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${T}_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_fetch.log 2>&1
