@@ -174,6 +174,52 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
+// The MLP input row of one point of the icon prior, written slot by slot into the LDS tile (no 16-wide register tuple next
+// to the MFMA accumulators); slots >= c0 are never read as data (masked by index in the MLP part), slot 15 = in_cube flag.
+// (Requesting the texels of BOTH feature halves up front - their addresses depend on the position only - instead of after
+//  the dependent chain slot -> triangle attributes -> visibility flag was measured: 14.69 vs 14.36 ms; the phase is bound by
+//  the number of loads, not by the length of the chain.)
+__device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, float *xrow, int64_t K, int64_t rank0)
+{
+    const uint32_t code = G.code8[i];
+    Nearest nr;
+    nr.slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar); nr.face = 0;
+    nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near_d2[i];    // an outlier's sdf is its sign
+    const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
+    float s = o.sdf;
+    f3 cmv = o.cm;
+    if (code & kCodeOutlier) {                      // HGPIFuNet.py:298-305
+        s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
+        if (G.cmap_local) cmv = mk3(s, s, s);
+        else if (K > 0) {
+            // rank among the call's outliers: scan over 256-point blocks + ballots of the 64-point groups
+            const int64_t blk = i >> 8;
+            const int g = (int)(i >> 6) & 3;
+            const unsigned long long *mk = G.grp_mask + blk * 4;
+            int before = __popcll(mk[g] & ((1ull << (i & 63)) - 1ull));
+            if (g > 0) before += __popcll(mk[0]);
+            if (g > 1) before += __popcll(mk[1]);
+            if (g > 2) before += __popcll(mk[2]);
+            const int64_t jr = rank0 + G.block_offsets[blk] + before;
+            float c3[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int64_t mm = 3 * jr + k;            // jr < K  =>  mm < 3K
+                if (mm >= K) mm -= K;
+                if (mm >= K) mm -= K;
+                c3[k] = sign_at(G.sg, mm);
+            }
+            cmv = mk3(c3[0], c3[1], c3[2]);
+        }
+    }
+    gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
+    const int hh = G.f.csel;
+    xrow[hh] = s;
+    xrow[hh + 1] = cmv.x; xrow[hh + 2] = cmv.y; xrow[hh + 3] = cmv.z;
+    xrow[hh + 4] = o.nrm.x; xrow[hh + 5] = o.nrm.y; xrow[hh + 6] = o.nrm.z;
+    xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
+}
+
 template <int PRIOR, bool LATTICE>
 __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float *__restrict__ out, MlpF16Dev w)
 {
@@ -234,45 +280,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
             }
             float *xrow = Xs + t * kXRow;
             if (PRIOR == ICON_PRIOR_ICON) {
-                const uint32_t code = G.code8[i];
-                Nearest nr;
-                nr.slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar); nr.face = 0;
-                nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near_d2[i];    // an outlier's sdf is its sign
-                const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
-                float s = o.sdf;
-                f3 cmv = o.cm;
-                if (code & kCodeOutlier) {                      // HGPIFuNet.py:298-305
-                    s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
-                    if (G.cmap_local) cmv = mk3(s, s, s);
-                    else if (K > 0) {
-                        // rank among the call's outliers: scan over 256-point blocks + ballots of the 64-point groups
-                        const int64_t blk = i >> 8;
-                        const int g = (int)(i >> 6) & 3;
-                        const unsigned long long *mk = G.grp_mask + blk * 4;
-                        int before = __popcll(mk[g] & ((1ull << (i & 63)) - 1ull));
-                        if (g > 0) before += __popcll(mk[0]);
-                        if (g > 1) before += __popcll(mk[1]);
-                        if (g > 2) before += __popcll(mk[2]);
-                        const int64_t jr = rank0 + G.block_offsets[blk] + before;
-                        float c3[3];
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) {
-                            int64_t mm = 3 * jr + k;            // jr < K  =>  mm < 3K
-                            if (mm >= K) mm -= K;
-                            if (mm >= K) mm -= K;
-                            c3[k] = sign_at(G.sg, mm);
-                        }
-                        cmv = mk3(c3[0], c3[1], c3[2]);
-                    }
-                }
-                // the row goes to LDS slot by slot (no 16-wide register tuple next to the MFMA accumulators);
-                // slots >= c0 are never read as data (masked by index in the MLP part), slot 15 = in_cube flag
-                gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
-                const int hh = G.f.csel;
-                xrow[hh] = s;
-                xrow[hh + 1] = cmv.x; xrow[hh + 2] = cmv.y; xrow[hh + 3] = cmv.z;
-                xrow[hh + 4] = o.nrm.x; xrow[hh + 5] = o.nrm.y; xrow[hh + 6] = o.nrm.z;
-                xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
+                icon_row(G, p, i, xrow, K, rank0);
             } else {
                 gather_planes_dyn(G.f, 0, p.x, p.y, xrow);
                 const int hh = G.f.csel;

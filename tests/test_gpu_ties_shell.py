@@ -424,3 +424,29 @@ def test_random_lattices_slabs_and_pieces_vs_oracle(seed):
                 e.slab_finish_gathered(res, x, b, gathered, stride, len(parts), r, out=out, za=za, zb=zb)
             outs.append(out)
         assert torch.equal(torch.cat(outs), full), (res, parts)
+
+
+def test_per_axis_resolutions(body):
+    """resolutions given as (W, H, D) triples (lib/common/seg3d_lossless.py:66-71): one query over the materialised lattice,
+    volume [D, H, W]; equals the oracle on the same points; export_mesh pads to a cube without moving a vertex"""
+    from types import SimpleNamespace
+    from icon_amd.recon import DenseReconEngine, lattice_coords
+    from icon_amd.engine import query_func
+    eng = make_engine(body)
+    W, H, D = 33, 65, 17
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                             resolutions=[(9, 17, 5), (W, H, D)], align_corners=True, balance_value=0.5).to(dev())
+    vol = recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert vol.shape == (D, H, W)
+    pts = lattice_coords((W, H, D), recon.b_min.cpu(), recon.b_max.cpu(), True, "cpu")[0].numpy()
+    # the mapping is batch_eval's: x fastest, y flipped
+    assert np.allclose(pts[0], [-1, 1, -1]) and np.allclose(pts[-1], [1, -1, 1]) and np.allclose(pts[1], [-1 + 2 / (W - 1), 1, -1])
+    ref, _ = oracle_query(body, pts)
+    assert np.abs(vol.cpu().numpy().ravel() - ref).max() <= OCC_TOL
+    verts, faces = recon.export_mesh(vol)
+    assert len(faces) > 50 and verts[:, 0].max() <= W - 1 and verts[:, 1].max() <= H - 1 and verts[:, 2].max() <= D - 1
+    # a cubic lattice through the same generic path equals the fast path
+    recon_c = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                               resolutions=[(33, 33, 33)], align_corners=True).to(dev())
+    fast = recon_c(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert torch.equal(fast, eng.eval_slab(T(body.features), 33, 0, 33))
