@@ -463,7 +463,8 @@ class IconQueryEngine:
                 # the reference's own leaf (lib/net/voxelize.py:119-137 -> voxelize_cuda wheel), exactly as
                 # HGPIFuNet.query calls it (lib/net/HGPIFuNet.py:320) - still once per image, not per query()
                 with torch.no_grad():
-                    vol = vox(vv, vf)
+                    vox.update_param(batch_size=vf.shape[0], smpl_tetra=vf[0].detach().cpu().numpy())   # HGPIFuNet.py:321-323
+                    vol = vox(vv)                                                                        # :324, vol ~ [0,1]
             else:
                 vol = semantic_voxelization(vv, vf, vox.smpl_vertex_code, res=int(getattr(vox, "volume_res", 128)),
                                             sigma=float(getattr(vox, "sigma", 0.05)))

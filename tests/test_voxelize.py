@@ -107,3 +107,68 @@ def test_pamir_query_with_hoisted_voxelisation_and_volume_encoder():
     netG.smpl_feat_dict["voxel_verts"] = vverts.clone()                         # next image: new tensors -> recomputed
     netG.query(features=[T(feat)], points=T(pts.T)[None], calibs=eye, regressor=netG.if_regressor)
     assert ve.calls == 3        # one CPU call above + the recomputation
+
+
+@pytest.mark.gpu
+def test_pamir_uses_the_reference_voxeliser_when_its_wheel_imports(monkeypatch):
+    """voxelizer='auto': with a voxelize_cuda module that has forward_semantic_voxelization the engine calls
+    netG.voxelization exactly as HGPIFuNet.query does (update_param + forward on the stripped tensors,
+    lib/net/HGPIFuNet.py:316-324) - once per image; voxelizer='reference' without the wheel raises; 'hip' never asks"""
+    import sys
+    import types
+    import warnings
+    from icon_amd.engine import IconQueryEngine, IconAmdError, semantic_voxelization
+    from oracle.query_torch import TorchMLP
+    a, (vv, tets, code) = _tetra()
+    dev = torch.device("cuda:0")
+    feat, _, sd = vol_assets("pamir")
+    res_v = 32
+    reg = TorchMLP().eval()
+    reg.norm, reg.last_op = "batch", None
+    reg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    pad_v, pad_f = 4, 6
+    vverts = torch.from_numpy(np.concatenate([vv, np.zeros((pad_v, 3), np.float32)]))[None].to(dev)
+    vfaces = torch.from_numpy(np.concatenate([tets, np.zeros((pad_f, 4), np.int64)]))[None].to(dev)
+
+    class RefVox:                                   # stands in for lib.net.voxelize.Voxelization around the wheel
+        smpl_vertex_code, volume_res, sigma = code, res_v, 0.05
+
+        def __init__(self):
+            self.calls = []
+
+        def update_param(self, batch_size, smpl_tetra):
+            self.calls.append(("update_param", batch_size, smpl_tetra.shape))
+            self.tets = smpl_tetra
+
+        def __call__(self, verts):
+            self.calls.append(("forward", tuple(verts.shape)))
+            return semantic_voxelization(verts, torch.from_numpy(self.tets)[None].to(verts.device), self.smpl_vertex_code,
+                                         res=self.volume_res, sigma=self.sigma)
+
+    def make_net():
+        return SimpleNamespace(prior_type="pamir", sdf_clip=0.05, smpl_feats=["sdf", "norm", "vis", "cmap"], if_regressor=reg.to(dev),
+                               voxelization=RefVox(), ve=_TinyVE().eval().to(dev),
+                               smpl_feat_dict=dict(voxel_verts=vverts, voxel_faces=vfaces,
+                                                   pad_v_num=torch.tensor([pad_v], device=dev), pad_f_num=torch.tensor([pad_f], device=dev)))
+    pts = np.random.RandomState(5).uniform(-1.0, 1.0, (1500, 3)).astype(np.float32)
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    eye = torch.eye(4, device=dev)[None]
+
+    def run(netG):
+        return netG.query(features=[T(feat)], points=T(pts.T)[None], calibs=eye, regressor=netG.if_regressor)[0][0, 0]
+
+    monkeypatch.delitem(sys.modules, "voxelize_cuda", raising=False)
+    net_h = make_net(); IconQueryEngine.attach(net_h, voxelizer="hip")
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")               # 'hip' is silent
+        want = run(net_h)
+    assert net_h.voxelization.calls == []
+    net_r = make_net(); IconQueryEngine.attach(net_r, voxelizer="reference")
+    with pytest.raises(IconAmdError, match="voxelize_cuda"):
+        run(net_r)
+    fake = types.ModuleType("voxelize_cuda"); fake.forward_semantic_voxelization = lambda *a, **k: None
+    monkeypatch.setitem(sys.modules, "voxelize_cuda", fake)
+    net_a = make_net(); IconQueryEngine.attach(net_a)                                   # voxelizer='auto'
+    got = run(net_a); run(net_a)
+    assert net_a.voxelization.calls == [("update_param", 1, tuple(tets.shape)), ("forward", (1, len(vv), 3))]   # once per image, stripped tensors
+    assert torch.equal(got, want)
