@@ -534,6 +534,8 @@ def export_mesh_numpy(occ: np.ndarray, level: float = 0.5):
 
 
 class AdaptiveReconEngine(DenseReconEngine):
+    lattice_level0 = True      # answer the coarsest (dense) level with the lattice kernels; False: through query_func like the rest
+
     """The reference's coarse-to-fine schedule (``Seg3dLossless._forward_faster``,
     lib/common/seg3d_lossless.py:152-265, the mode apps/ICON.py:89 selects) on top of the fast
     query: evaluate the coarsest lattice, then at every finer level only the voxels near the
@@ -576,16 +578,33 @@ class AdaptiveReconEngine(DenseReconEngine):
             m = F.max_pool3d(m, (1, 1, k), stride=1, padding=(0, 0, r))
             return (m > 0)[0, 0]
 
+        # the standard box, align_corners, no projection, an engine behind netG: the dense level can use the lattice kernels
+        lattice_engine = None
+        if self.lattice_level0 and self._lattice_fast_path(kwargs.get("proj_matrix", None)) and kwargs.get("netG") is not None:
+            try:
+                lattice_engine = self._backend_for(kwargs.get("netG"))
+            except Exception:
+                lattice_engine = None
+            if not hasattr(lattice_engine, "eval_slab"):
+                lattice_engine = None
         occupancys = done = None                     # done[z,y,x]: voxel already evaluated (the reference keeps a
         self.last_stats = dict(queries=[])           # sorted coordinate list, coords_accum, for the same purpose)
         for level, res in enumerate(res_list):
             stride = (last - 1) // (res - 1)
             if level == 0:
-                ar = torch.linspace(0, last - 1, res, device=dev).long()
-                gd, gh, gw = torch.meshgrid([ar, ar, ar], indexing="ij")
-                coords = torch.stack([gw, gh, gd]).view(3, -1).t().unsqueeze(0)
-                occupancys = batch_eval(coords).view(1, 1, res, res, res)
-                self.last_stats["queries"].append(int(coords.shape[1]))
+                if lattice_engine is not None and (last - 1) % (res - 1) == 0:
+                    # the coarsest level IS a dense lattice: its points (multiples of the stride, mapped by batch_eval) are
+                    # bit for bit the points of the res^3 lattice, in the same z,y,x order and as ONE call - so the lattice
+                    # kernels answer it (packet search over 4x4x4 blocks instead of one wavefront per scattered point)
+                    im_feat = feats[-1] if isinstance(feats, (list, tuple)) else feats
+                    occupancys = lattice_engine.eval_slab(im_feat, res, 0, res).view(1, 1, res, res, res)
+                    self.last_stats["queries"].append(res ** 3)
+                else:
+                    ar = torch.linspace(0, last - 1, res, device=dev).long()
+                    gd, gh, gw = torch.meshgrid([ar, ar, ar], indexing="ij")
+                    coords = torch.stack([gw, gh, gd]).view(3, -1).t().unsqueeze(0)
+                    occupancys = batch_eval(coords).view(1, 1, res, res, res)
+                    self.last_stats["queries"].append(int(coords.shape[1]))
                 if (occupancys > 0.5).sum() == 0:
                     return None
                 done = torch.ones((res, res, res), dtype=torch.bool, device=dev)

@@ -697,6 +697,10 @@ def test_adaptive_recon_matches_reference_volume(body):
     d = np.abs(vol.cpu().numpy() - g["occ"])
     assert d.max() <= OCC_TOL, d.max()
     assert recon.last_stats["queries"] == [33 ** 3]      # two levels: coarse lattice queried, last level interpolated
+    # the coarsest level through the lattice kernels (default) or through query_func like the other levels: the same bits
+    recon.lattice_level0 = False
+    assert torch.equal(vol, recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None))
+    recon.lattice_level0 = True
     # three levels: the middle one queries only the boundary band - against the reference's volume again
     g3 = golden("seg3d_body_adaptive_17_33_65.npz")
     recon3 = AdaptiveReconEngine(query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
