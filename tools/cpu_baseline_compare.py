@@ -57,5 +57,39 @@ def main():
         print(f"max |reference - port| = {np.abs(vals['reference'] - vals['port']).max():.3e}; port / reference throughput = {out['port'] / out['reference']:.3f}")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--adaptive" not in sys.argv:
     main()
+
+
+def reference_adaptive(repeat=3):
+    """Second baseline line of BASELINE.md section 3: wall clock of the reference's OWN schedule - Seg3dLossless [33,65,129,257],
+    faster=True (apps/ICON.py:62-90), run verbatim on the CPU over the exact accelerated leaves - for one image."""
+    import numpy as np
+    import torch
+    from icon_amd import synth
+    from oracle import oracle as orc, ref_loader
+    cores = len(os.sched_getaffinity(0))
+    torch.set_num_threads(cores); orc.set_num_threads(cores)
+    ref = ref_loader.load()
+    a = synth.make_assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    counts = []
+
+    def qf(opt, netG, features, points, proj_matrix=None):
+        counts.append(int(points.shape[1]))
+        return ref.query_func(opt, netG, features, points, proj_matrix)
+    best = 1e30
+    with torch.no_grad():
+        eng = ref.Seg3dLossless(query_func=qf, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[33, 65, 129, 257],
+                                align_corners=True, balance_value=0.5, faster=True)
+        for _ in range(repeat):
+            counts.clear()
+            t0 = time.perf_counter()
+            vol = eng(opt=cfg, netG=netG, features=[torch.from_numpy(a.features)], proj_matrix=None)
+            best = min(best, time.perf_counter() - t0)
+    print(f"reference Seg3dLossless [33,65,129,257] faster=True, verbatim, {cores} cores: {best * 1e3:.0f} ms per image "
+          f"({sum(counts)} points queried in {len(counts)} calls: {counts}); volume {tuple(vol.shape)}")
+
+
+if __name__ == "__main__" and "--adaptive" in sys.argv:
+    reference_adaptive()
