@@ -579,14 +579,15 @@ class AdaptiveReconEngine(DenseReconEngine):
             return (m > 0)[0, 0]
 
         # the standard box, align_corners, no projection, an engine behind netG: the dense level can use the lattice kernels
+        # (only an engine that is already there - never attach one behind the caller's back: the queries of this class go
+        #  through whatever query_func / netG the caller passed)
         lattice_engine = None
-        if self.lattice_level0 and self._lattice_fast_path(kwargs.get("proj_matrix", None)) and kwargs.get("netG") is not None:
-            try:
-                lattice_engine = self._backend_for(kwargs.get("netG"))
-            except Exception:
-                lattice_engine = None
-            if not hasattr(lattice_engine, "eval_slab"):
-                lattice_engine = None
+        if self.lattice_level0 and self._lattice_fast_path(kwargs.get("proj_matrix", None)):
+            from .engine import IconQueryEngine
+            netG = kwargs.get("netG")
+            cand = netG if isinstance(netG, IconQueryEngine) else (self.engine or getattr(netG, "icon_amd_engine", None))
+            if isinstance(cand, IconQueryEngine) and self.query_func is not None and getattr(self.query_func, "__module__", "") == "icon_amd.engine":
+                lattice_engine = cand
         occupancys = done = None                     # done[z,y,x]: voxel already evaluated (the reference keeps a
         self.last_stats = dict(queries=[])           # sorted coordinate list, coords_accum, for the same purpose)
         for level, res in enumerate(res_list):
