@@ -58,6 +58,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise IconAmdError(f"{LIB_PATH} not found - run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "or `make -C icon_amd/csrc` (needs hipcc); there is no CPU fallback")
+    # torch first: its wheel bundles its own libamdhip64 and must be the HIP runtime of the process - if this library
+    # (linked against /opt/rocm) pulled the system runtime in before `import torch`, torch would later report "No HIP GPUs
+    # are available" (seen with build() followed by smoke() in one interpreter)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     L.icon_last_error.restype = C.c_char_p
     for name in SYMBOLS:
