@@ -26,7 +26,7 @@ SYMBOLS = [
     "icon_mesh_create", "icon_mesh_destroy", "icon_mesh_vertex_normals", "icon_mesh_stats",
     "icon_sdf_query",
     "icon_feat_create", "icon_feat_destroy",
-    "icon_mlp_create", "icon_mlp_destroy", "icon_mlp_forward",
+    "icon_mlp_create", "icon_mlp_destroy", "icon_mlp_forward", "icon_mlp_set_last_op",
     "icon_work_create", "icon_work_destroy", "icon_work_profile", "icon_work_stage_ms",
     "icon_query_points", "icon_query_points_dcalib",
     "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish", "icon_grid_slab_features_msg",

@@ -144,6 +144,12 @@ struct LatticeMap {
     int sz0, sz1;              // ... and planes [sz0, sz1) RELATIVE to the slab
 };
 
+// MLP.last_op (lib/net/MLP.py:68-70; nn.Sigmoid() unless cfg.test_mode, lib/net/HGPIFuNet.py:133)
+__device__ __forceinline__ float apply_last_op(float y, int last_op)
+{
+    return last_op == ICON_LASTOP_SIGMOID ? 1.0f / (1.0f + expf(-y)) : y;
+}
+
 // where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)
 enum { kSignNone = 0, kSignSelf = 1, kSignGlobal = 2, kSignSeg = 3 };
 struct FusedSigns {
@@ -182,6 +188,7 @@ struct icon_feat {
 
 struct icon_mlp {
     int c0 = 0;               // input channels (<= 15)
+    int last_op = 0;          // ICON_LASTOP_*: applied to the network output before the in_cube mask (MLP.py:68-70)
     float *d_blob = nullptr;  // all packed operands, one allocation
     size_t blob_bytes = 0;
     // offsets (in floats) into the blob

@@ -349,7 +349,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
 #pragma unroll
         for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
         const float other = __shfl_xor(part, 32);
-        const float y = (part + other) + w.b3;
+        const float y = apply_last_op((part + other) + w.b3, w.last_op);
         // where this point's occupancy goes is re-derived from the work item (a handful of integer instructions):
         // nothing lane-dependent lives across the MFMA body
         const int64_t oq = tile * kTilePts + pt;
@@ -455,7 +455,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     MlpF16Dev w;
     w.image = mlp->d_f16;
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
-    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
+    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
 
     int n_cu = 0;
     const int rc = device_cu_count(&n_cu);

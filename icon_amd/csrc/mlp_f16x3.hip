@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
 #pragma unroll
     for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
     const float other = __shfl_xor(part, 32);
-    const float y = (part + other) + w.b3;
+    const float y = apply_last_op((part + other) + w.b3, w.last_op);
     if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
 }
 
@@ -224,7 +224,7 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
     MlpF16Dev w;
     w.image = mlp->d_f16;
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
-    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0;
+    w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
     const int64_t nb = (N + kF16Pts - 1) / kF16Pts;
     ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
     if (first_use_on_device(6)) {          // per device: a process may drive several (common.h)

@@ -43,6 +43,7 @@ struct MlpF16Dev {
     float b3;
     float inv0, inv1, inv2;     // 1 / weight scale of layers 0..2
     int c0;
+    int last_op;                // ICON_LASTOP_*
 };
 
 __device__ __forceinline__ f32x16 ld16(const float *p)

@@ -49,6 +49,7 @@ struct MlpDev {
     const float *w0, *b0, *w1, *b1, *w2, *w2x, *b2, *w3;
     float b3;
     int c0;
+    int last_op;
 };
 
 __device__ __forceinline__ f32x16 leaky(f32x16 v)
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(kMlpBlock, 2) void k_mlp_f32(const float *__restric
 #pragma unroll
     for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
     const float other = __shfl_xor(part, 32);
-    const float y = (part + other) + w.b3;
+    const float y = apply_last_op((part + other) + w.b3, w.last_op);
     if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
 }
 
@@ -197,7 +198,7 @@ int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out
     MlpDev w;
     w.w0 = b + mlp->off_w0; w.b0 = b + mlp->off_b0; w.w1 = b + mlp->off_w1; w.b1 = b + mlp->off_b1;
     w.w2 = b + mlp->off_w2; w.w2x = b + mlp->off_w2x; w.b2 = b + mlp->off_b2; w.w3 = b + mlp->off_w3;
-    w.b3 = mlp->b3; w.c0 = mlp->c0;
+    w.b3 = mlp->b3; w.c0 = mlp->c0; w.last_op = mlp->last_op;
     const int64_t nb = (N + kPtsPerBlock - 1) / kPtsPerBlock;
     ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
     if (mask) hipLaunchKernelGGL(k_mlp_f32<true>, dim3((unsigned)nb), dim3(kMlpBlock), 0, st, d_x, N, d_out, w);
@@ -325,6 +326,14 @@ extern "C" int icon_mlp_destroy(icon_mlp_t *m)
     if (!m) return ICON_OK;
     (void)hipFree(m->d_blob); (void)hipFree(m->d_f16); (void)hipFree(m->d_mx6);
     delete m;
+    return ICON_OK;
+}
+
+extern "C" int icon_mlp_set_last_op(icon_mlp_t *m, int last_op)
+{
+    ICON_ARG(m != nullptr, "icon_mlp_set_last_op: mlp is null");
+    ICON_ARG(last_op == ICON_LASTOP_NONE || last_op == ICON_LASTOP_SIGMOID, "icon_mlp_set_last_op: unknown last_op");
+    m->last_op = last_op;
     return ICON_OK;
 }
 

@@ -77,6 +77,7 @@ struct MlpMx6Dev {
     const float *side;
     float b3;
     int c0;
+    int last_op;
     unsigned long long *trace;     // debug (ICON_AMD_MX6_TRACE): s_memtime stamps of workgroup 0, second tile
 };
 
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(kMxBlock, 2) void k_mlp_mx6(const float *__restrict
 #pragma unroll
         for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
         const float other = __shfl_xor(part, 32);
-        const float y = (part + other) + w.b3;
+        const float y = apply_last_op((part + other) + w.b3, w.last_op);
         if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
 
         mx_split8(xn, l0.xhi, l0.xlo);
@@ -605,7 +606,7 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
     MlpMx6Dev w;
     w.image = mlp->d_mx6;
     w.side = reinterpret_cast<const float *>(mlp->d_mx6 + kMxImageBytes);
-    w.b3 = mlp->b3; w.c0 = mlp->c0; w.trace = nullptr;
+    w.b3 = mlp->b3; w.c0 = mlp->c0; w.last_op = mlp->last_op; w.trace = nullptr;
     static const bool want_trace = getenv("ICON_AMD_MX6_TRACE") != nullptr;
     if (want_trace) { ICON_HIP(hipMalloc((void **)&w.trace, 8 * 64 * 8)); ICON_HIP(hipMemsetAsync(w.trace, 0, 8 * 64 * 8, st)); }
     const int64_t nt = (N + kMxPts - 1) / kMxPts;

@@ -185,8 +185,10 @@ class MlpHandle(_Handle):
     icon_mlp_create folds BatchNorm and packs the MFMA operands."""
     _destroy = "icon_mlp_destroy"
 
-    def __init__(self, state_dict, res_layers: Sequence[int] = (2, 3, 4), bn_eps: float = 1e-5):
+    def __init__(self, state_dict, res_layers: Sequence[int] = (2, 3, 4), bn_eps: float = 1e-5, last_op: Optional[str] = None):
         super().__init__()
+        if last_op not in (None, "sigmoid"):
+            raise IconAmdError(f"unsupported last_op {last_op!r} (None or 'sigmoid')")
         _lib.require_device()
         n = 0
         while f"filters.{n}.weight" in state_dict:
@@ -216,6 +218,9 @@ class MlpHandle(_Handle):
         check(_lib.lib().icon_mlp_create(C.c_int(n), cin, cout, is_res, parr(W), parr(b), bn_ptrs[0], bn_ptrs[1],
                                          bn_ptrs[2], bn_ptrs[3], C.c_float(bn_eps), _stream(), C.byref(self.h)),
               "icon_mlp_create")
+        self.last_op = last_op
+        if last_op == "sigmoid":
+            check(_lib.lib().icon_mlp_set_last_op(self.h, C.c_int(1)), "icon_mlp_set_last_op")
 
     def forward(self, x: torch.Tensor, precision: str = "f16x3") -> torch.Tensor:
         """MLP.forward on point-major rows x [N,16] (slots >= c0 ignored) -> [N]"""
@@ -280,7 +285,7 @@ def check_regressor(regressor) -> None:
     """Refuse every ``MLP`` configuration the kernels do not evaluate (lib/net/MLP.py:8-72): the folded
     operands are only equal to the module for eval-mode BatchNorm1d (``norm_mlp: 'batch'`` in every
     configs/*.yaml; the config default 'group', lib/common/config.py:80, and 'instance' normalise over the
-    points of the call) and for ``last_op=None`` (``test_mode: True``, lib/net/HGPIFuNet.py:128-133)."""
+    points of the call); ``last_op`` may be None (``test_mode: True``) or ``nn.Sigmoid`` (lib/net/HGPIFuNet.py:128-133)."""
     if isinstance(regressor, dict):
         if any(k.startswith("norms.") for k in regressor) and "norms.0.running_mean" not in regressor:
             raise IconAmdError("regressor state_dict has norms.* without running statistics (GroupNorm / InstanceNorm): "
@@ -295,11 +300,17 @@ def check_regressor(regressor) -> None:
                            "group / instance statistics depend on the points of the call and cannot be folded")
     if norm == "weight":
         raise IconAmdError("if_regressor.norm = 'weight' (weight_norm) is not supported")
-    if getattr(regressor, "last_op", None) is not None:
-        raise IconAmdError("if_regressor.last_op is set (cfg.test_mode False -> nn.Sigmoid, lib/net/HGPIFuNet.py:133): "
-                           "the HIP path evaluates the test-mode network (no last_op)")
+    lo = getattr(regressor, "last_op", None)
+    if lo is not None and not isinstance(lo, nn.Sigmoid):
+        raise IconAmdError(f"if_regressor.last_op = {type(lo).__name__}: only None (cfg.test_mode) and nn.Sigmoid "
+                           "(lib/net/HGPIFuNet.py:133) are evaluated")
     if getattr(regressor, "training", False):
         raise IconAmdError("if_regressor is in training mode: BatchNorm batch statistics cannot be folded - call .eval()")
+
+
+def regressor_last_op(regressor) -> Optional[str]:
+    """'sigmoid' for a module built with last_op=nn.Sigmoid() (cfg.test_mode False), else None; dicts carry no last_op"""
+    return "sigmoid" if isinstance(getattr(regressor, "last_op", None), nn.Sigmoid) else None
 
 
 def regressor_state_dict(regressor) -> dict:
@@ -356,6 +367,7 @@ class IconQueryEngine:
         if voxelizer not in ("auto", "hip", "reference"):
             raise IconAmdError("voxelizer must be 'auto', 'hip' or 'reference'")
         self.voxelizer = voxelizer       # pamir: which semantic voxeliser feeds netG.ve (see _pamir_volume)
+        self.last_op = None              # for regressors given as a state_dict: None or "sigmoid" (modules carry their own last_op)
         self.tie_rule = None             # diagnostics: ("highest", ulps) - see Workspace.set_tie_rule / DESIGN.md section 2
         self._calibrated = None          # (mlp key, precision) the effective precision was derived for
         self._work_tie = None
@@ -505,9 +517,10 @@ class IconQueryEngine:
         if reg is None:
             raise IconAmdError("no regressor bound: pass regressor= or call set_regressor()")
         sd = regressor_state_dict(reg)
-        k = tuple((n, ) + (_key(t)[0] if isinstance(t, torch.Tensor) else (id(t),)) for n, t in sd.items())
+        last_op = regressor_last_op(reg) if not isinstance(reg, dict) else self.last_op
+        k = tuple((n, ) + (_key(t)[0] if isinstance(t, torch.Tensor) else (id(t),)) for n, t in sd.items()) + (last_op,)
         if k != self._mlp_key:
-            self._mlp = MlpHandle(sd, self.res_layers)
+            self._mlp = MlpHandle(sd, self.res_layers, last_op=last_op)
             self._mlp_key, self._mlp_src = k, list(sd.values())
         self._resolve_precision()
         return self._mlp

@@ -128,6 +128,11 @@ int icon_mlp_create(int n_layers, const int *cin, const int *cout, const int *is
                     const float *const *h_bn_mean, const float *const *h_bn_var,
                     float bn_eps, void *stream, icon_mlp_t **out);
 int icon_mlp_destroy(icon_mlp_t *mlp);
+/* MLP.last_op (lib/net/MLP.py:68-70): HGPIFuNet builds the regressor with last_op = nn.Sigmoid() unless cfg.test_mode
+ * (lib/net/HGPIFuNet.py:133; every configs/ *.yaml sets test_mode: True, training / validation runs do not).  Applied to the
+ * network output before the in_cube mask, in every precision. */
+enum { ICON_LASTOP_NONE = 0, ICON_LASTOP_SIGMOID = 1 };
+int icon_mlp_set_last_op(icon_mlp_t *mlp, int last_op);
 /* MLP.forward on point-major input rows: d_x [N,16] f32 (channels cin[0]..15 ignored),
  * d_out [N].  precision: ICON_PRECISION_*. */
 int icon_mlp_forward(const icon_mlp_t *mlp, const float *d_x, int64_t N, float *d_out,

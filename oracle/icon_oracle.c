@@ -426,7 +426,7 @@ void orc_trilinear(const float *vol, int C, int D, int H, int W, float x, float 
 /* ------------------------------------------------------------------------------------------
  * S8  MLP.forward (lib/net/MLP.py:49-72): Conv1d(k=1) -> BatchNorm1d(eval, eps 1e-5) ->
  *     LeakyReLU(0.01); raw input re-concatenated (after the activations) before res layers;
- *     no last_op in test mode (HGPIFuNet.py:133).  Weights arrive un-folded, exactly as the
+ *     last_op: none in test mode, Sigmoid otherwise (HGPIFuNet.py:133).  Weights arrive un-folded, exactly as the
  *     reference state_dict holds them.  accumulate_f64 != 0 gives the high-precision variant.
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
@@ -440,6 +440,7 @@ typedef struct {
     const float *const *bn_b;  /* beta                                        */
     const float *const *bn_m;  /* running_mean                                */
     const float *const *bn_v;  /* running_var                                 */
+    int last_op;               /* 0: none (cfg.test_mode); 1: Sigmoid (MLP.py:68-70, HGPIFuNet.py:133) */
 } orc_mlp;
 
 #define ORC_MAXC 1024
@@ -480,6 +481,10 @@ static void mlp_point(const orc_mlp *m, const float *x, int c0, float *out, int 
         }
         memcpy(cur, nxt, sizeof(float) * (size_t)co);
         n_cur = co;
+    }
+    if (m->last_op == 1) {                                       /* self.last_op(y), MLP.py:68-70 */
+        for (int o = 0; o < n_cur; ++o)
+            cur[o] = accumulate_f64 ? (float)(1.0 / (1.0 + exp(-(double)cur[o]))) : 1.0f / (1.0f + expf(-cur[o]));
     }
     memcpy(out, cur, sizeof(float) * (size_t)n_cur);
 }

@@ -155,13 +155,14 @@ def cal_sdf(verts, faces, cmap, vis, pts):
 class _OrcMlp(C.Structure):
     _fields_ = [("n_layers", C.c_int), ("cin", C.c_void_p), ("cout", C.c_void_p), ("is_res", C.c_void_p),
                 ("W", C.c_void_p), ("b", C.c_void_p), ("bn_g", C.c_void_p), ("bn_b", C.c_void_p),
-                ("bn_m", C.c_void_p), ("bn_v", C.c_void_p)]
+                ("bn_m", C.c_void_p), ("bn_v", C.c_void_p), ("last_op", C.c_int)]
 
 
 class Mlp:
     """Holds a reference-layout state_dict (numpy) as the orc_mlp struct."""
 
-    def __init__(self, state_dict: dict, res_layers=(2, 3, 4)):
+    def __init__(self, state_dict: dict, res_layers=(2, 3, 4), last_op=None):
+        """last_op: None (cfg.test_mode) or "sigmoid" (lib/net/HGPIFuNet.py:133)"""
         n = 0
         while f"filters.{n}.weight" in state_dict:
             n += 1
@@ -189,7 +190,7 @@ class Mlp:
         self._keep += [cin, cout, is_res, W, b, bn]
         self.struct = _OrcMlp(n, cin.ctypes.data, cout.ctypes.data, is_res.ctypes.data,
                               ptr_array(W), ptr_array(b), ptr_array(bn["weight"]), ptr_array(bn["bias"]),
-                              ptr_array(bn["running_mean"]), ptr_array(bn["running_var"]))
+                              ptr_array(bn["running_mean"]), ptr_array(bn["running_var"]), 1 if last_op == "sigmoid" else 0)
 
     def forward(self, x, f64: bool = False):
         """x [N, c0] point-major -> [N, c_last]"""

@@ -450,3 +450,45 @@ def test_per_axis_resolutions(body):
                                resolutions=[(33, 33, 33)], align_corners=True).to(dev())
     fast = recon_c(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
     assert torch.equal(fast, eng.eval_slab(T(body.features), 33, 0, 33))
+
+
+# ---------------------------------------------------------------------------------------------
+# last_op = Sigmoid (cfg.test_mode False, lib/net/HGPIFuNet.py:133; lib/net/MLP.py:68-70)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "f32", "mx6"])
+def test_sigmoid_last_op_vs_oracle(body, precision):
+    """a regressor built with last_op = nn.Sigmoid(): sigmoid(MLP) then the in_cube mask, every precision, explicit points,
+    lattice and the standalone MLP.forward; the module's own last_op is picked up by attach-style binding"""
+    import warnings
+    from icon_amd.engine import MlpHandle
+    from oracle.query_torch import TorchMLP
+    reg = TorchMLP().eval()
+    reg.norm, reg.last_op = "batch", torch.nn.Sigmoid()
+    reg.load_state_dict({k: torch.from_numpy(v) for k, v in body.state_dict.items()}, strict=False)
+    eng = make_engine(body, precision=precision)
+    eng.set_regressor(reg.to(dev()))
+    omlp = orc.Mlp(body.state_dict, last_op="sigmoid")
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=21)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1], [0.3, -1.0, 0.0], [1.2, 0.0, 0.0]], np.float32)])   # on / outside the cube
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        occ = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+        vol = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
+    ref, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp, pts,
+                            sdf_clip=body.sdf_clip)
+    tol = OCC_TOL if (precision != "mx6" or eng._effective_precision != "mx6") else 3e-4
+    assert np.abs(occ - ref).max() <= tol
+    assert (occ[-3:] == 0).all() and occ[:-3].min() > 0.0 and occ.max() < 1.0           # in_cube * sigmoid(.)
+    ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
+                              synth.lattice_points(33), sdf_clip=body.sdf_clip)
+    assert np.abs(vol - ref33).max() <= tol
+    if precision != "mx6":
+        x = np.random.RandomState(1).normal(0, 1, (777, 13)).astype(np.float32)
+        from common import rows16
+        h = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()}, last_op="sigmoid")
+        got = h.forward(T(rows16(x)), precision).cpu().numpy()
+        assert np.abs(got - omlp.forward(x)[:, 0]).max() <= OCC_TOL
+    # the same weights without last_op differ (the flag is part of the handle key)
+    reg.last_op = None
+    plain = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
+    assert np.abs(plain - vol).max() > 0.1

@@ -170,9 +170,9 @@ def test_synthetic_assets_are_deterministic():
 
 
 def test_unsupported_regressors_are_refused():
-    """lib/net/MLP.py builds GroupNorm / InstanceNorm / weight_norm variants and a Sigmoid last_op
-    (cfg.test_mode False): folding only equals eval-mode BatchNorm1d without last_op, everything else
-    must raise instead of silently mis-evaluating."""
+    """lib/net/MLP.py builds GroupNorm / InstanceNorm / weight_norm variants: folding only equals eval-mode
+    BatchNorm1d, everything else must raise instead of silently mis-evaluating.  last_op: None and
+    nn.Sigmoid (cfg.test_mode False) are evaluated, anything else is refused."""
     import torch.nn as nn
     from icon_amd.engine import check_regressor
     from icon_amd._lib import IconAmdError
@@ -182,7 +182,12 @@ def test_unsupported_regressors_are_refused():
     ok.norm, ok.last_op = "batch", None
     check_regressor(ok)
     check_regressor({k: v for k, v in ok.state_dict().items()})
-    for attr, val in (("norm", "group"), ("norm", "instance"), ("norm", "weight"), ("last_op", nn.Sigmoid())):
+    sig = TorchMLP().eval()
+    sig.norm, sig.last_op = "batch", nn.Sigmoid()
+    check_regressor(sig)
+    from icon_amd.engine import regressor_last_op
+    assert regressor_last_op(sig) == "sigmoid" and regressor_last_op(ok) is None
+    for attr, val in (("norm", "group"), ("norm", "instance"), ("norm", "weight"), ("last_op", nn.Tanh())):
         m = TorchMLP().eval()
         m.norm, m.last_op = "batch", None
         setattr(m, attr, val)

@@ -188,8 +188,20 @@ def test_attach_reads_the_reference_network(ref):
         check_regressor(mlp_group)
     with pytest.raises(IconAmdError, match="running statistics"):
         check_regressor(dict(mlp_group.state_dict()))
-    mlp_sig = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="batch", last_op=torch.nn.Sigmoid()).eval()  # cfg.test_mode False
+    # cfg.test_mode False: last_op = nn.Sigmoid() (HGPIFuNet.py:133) is evaluated - the oracle's restatement against the reference's
+    # own MLP module with that last_op, on the synthetic checkpoint
+    from icon_amd.engine import regressor_last_op
+    mlp_sig = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="batch", last_op=torch.nn.Sigmoid()).eval()
+    mlp_sig.load_state_dict({k: torch.from_numpy(v) for k, v in a.state_dict.items()}, strict=False)
+    check_regressor(mlp_sig)
+    assert regressor_last_op(mlp_sig) == "sigmoid"
+    x = np.random.RandomState(4).normal(0, 1, (3000, 13)).astype(np.float32)
+    with torch.no_grad():
+        want = mlp_sig(T(x.T.copy())[None])[0, 0].numpy()
+    got = orc.Mlp(a.state_dict, last_op="sigmoid").forward(x)[:, 0]
+    assert np.abs(got - want).max() <= 2e-6 and want.min() > 0.0 and want.max() < 1.0
     with pytest.raises(IconAmdError, match="last_op"):
+        mlp_sig.last_op = torch.nn.Tanh()
         check_regressor(mlp_sig)
     # subsets of smpl_feats are refused at attach time (HGPIFuNet.py:301-309)
     netG.smpl_feats = ["sdf", "norm"]
