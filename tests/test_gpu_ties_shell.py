@@ -478,7 +478,9 @@ def test_sigmoid_last_op_vs_oracle(body, precision):
                             sdf_clip=body.sdf_clip)
     tol = OCC_TOL if (precision != "mx6" or eng._effective_precision != "mx6") else 3e-4
     assert np.abs(occ - ref).max() <= tol
-    assert (occ[-3:] == 0).all() and occ[:-3].min() > 0.0 and occ.max() < 1.0           # in_cube * sigmoid(.)
+    assert (occ[-3:] == 0).all() and occ.min() >= 0.0 and occ.max() <= 1.0                # in_cube * sigmoid(.)
+    inside = (np.abs(pts) < 1.0).all(1)
+    assert ((occ[inside] > 0.0) & (occ[inside] < 1.0)).all() and (occ[~inside] == 0).all()
     ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
                               synth.lattice_points(33), sdf_clip=body.sdf_clip)
     assert np.abs(vol - ref33).max() <= tol
