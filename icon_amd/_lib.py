@@ -25,7 +25,7 @@ SYMBOLS = [
     "icon_last_error", "icon_version", "icon_device_count",
     "icon_mesh_create", "icon_mesh_destroy", "icon_mesh_vertex_normals", "icon_mesh_stats",
     "icon_sdf_query",
-    "icon_feat_create", "icon_feat_destroy",
+    "icon_feat_create", "icon_feat_destroy", "icon_feat_set_smpl_feats",
     "icon_mlp_create", "icon_mlp_destroy", "icon_mlp_forward", "icon_mlp_set_last_op",
     "icon_work_create", "icon_work_destroy", "icon_work_profile", "icon_work_stage_ms",
     "icon_query_points", "icon_query_points_dcalib",

@@ -115,7 +115,11 @@ struct FeatDev {
     const float *vol;      // [D][H][W][vpad] or null
     int32_t C, H, W, n_select, csel, cpad;
     int32_t Cv, Dv, Hv, Wv, vpad;
+    // icon prior: which SMPL features follow the sdf in the MLP input (cfg.net.smpl_feats, lib/net/HGPIFuNet.py:301-309):
+    // bit 0 = cmap (3 channels), bit 1 = norm (3 channels); 'sdf' is always there, 'vis' only selects the feature half
+    int32_t smpl_mask;
 };
+constexpr int kSmplCmap = 1, kSmplNorm = 2;
 
 // affine calibration (rot | trans), row-major [3][4]; when `d` is set the 12 floats are read from
 // device memory by the kernel itself (wave-uniform scalar loads), so a caller holding the calibration

@@ -191,7 +191,7 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
     if (code & kCodeOutlier) {                      // HGPIFuNet.py:298-305
         s = (float)((int)((code >> kCodeSignShift) & 3u) - 1);
         if (G.cmap_local) cmv = mk3(s, s, s);
-        else if (K > 0) {
+        else if (K > 0 && (G.f.smpl_mask & kSmplCmap)) {
             // rank among the call's outliers: scan over 256-point blocks + ballots of the 64-point groups
             const int64_t blk = i >> 8;
             const int g = (int)(i >> 6) & 3;
@@ -213,10 +213,10 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
         }
     }
     gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
-    const int hh = G.f.csel;
-    xrow[hh] = s;
-    xrow[hh + 1] = cmv.x; xrow[hh + 2] = cmv.y; xrow[hh + 3] = cmv.z;
-    xrow[hh + 4] = o.nrm.x; xrow[hh + 5] = o.nrm.y; xrow[hh + 6] = o.nrm.z;
+    int hh = G.f.csel;                                  // [img | sdf | cmap (if) | norm (if)], HGPIFuNet.py:301-311
+    xrow[hh++] = s;
+    if (G.f.smpl_mask & kSmplCmap) { xrow[hh] = cmv.x; xrow[hh + 1] = cmv.y; xrow[hh + 2] = cmv.z; hh += 3; }
+    if (G.f.smpl_mask & kSmplNorm) { xrow[hh] = o.nrm.x; xrow[hh + 1] = o.nrm.y; xrow[hh + 2] = o.nrm.z; }
     xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
 }
 

@@ -210,9 +210,10 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
         gather_planes_dyn(f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, g);   // feat_select: vis==1 -> front half
         const int h = f.csel;
         for (int k = 0; k < h; ++k) row[k] = g[k];
-        row[h] = s;
-        row[h + 1] = cmv.x; row[h + 2] = cmv.y; row[h + 3] = cmv.z;
-        row[h + 4] = o.nrm.x; row[h + 5] = o.nrm.y; row[h + 6] = o.nrm.z;
+        int hh = h;                                       // [img | sdf | cmap (if) | norm (if)], HGPIFuNet.py:301-311
+        row[hh++] = s;
+        if (f.smpl_mask & kSmplCmap) { row[hh] = cmv.x; row[hh + 1] = cmv.y; row[hh + 2] = cmv.z; hh += 3; }
+        if (f.smpl_mask & kSmplNorm) { row[hh] = o.nrm.x; row[hh + 1] = o.nrm.y; row[hh + 2] = o.nrm.z; }
     } else {
         float g[16];
         gather_planes_dyn(f, 0, p.x, p.y, g);
@@ -541,6 +542,7 @@ extern "C" int icon_feat_create(const float *d_planes, int C, int H, int W, int 
     hipLaunchKernelGGL(k_pack_planes, dim3(1024), dim3(256), 0, st, d_planes, C, H, W, n_select, csel, cpad, f->d_planes);
     FeatDev &d = f->dev;
     d.planes = f->d_planes; d.C = C; d.H = H; d.W = W; d.n_select = n_select; d.csel = csel; d.cpad = cpad;
+    d.smpl_mask = kSmplCmap | kSmplNorm;
     d.vol = nullptr; d.Cv = 0; d.Dv = d.Hv = d.Wv = 0; d.vpad = 0;
     if (d_vol) {
         const int vpad = (Cv + 3) & ~3;
@@ -554,6 +556,13 @@ extern "C" int icon_feat_create(const float *d_planes, int C, int H, int W, int 
     e = hipGetLastError();
     if (e != hipSuccess) { icon_feat_destroy(f); return fail(ICON_ERR_HIP, std::string("pack planes: ") + hipGetErrorString(e)); }
     *out = f;
+    return ICON_OK;
+}
+
+extern "C" int icon_feat_set_smpl_feats(icon_feat_t *f, int has_cmap, int has_norm)
+{
+    ICON_ARG(f != nullptr, "icon_feat_set_smpl_feats: feat is null");
+    f->dev.smpl_mask = (has_cmap ? kSmplCmap : 0) | (has_norm ? kSmplNorm : 0);
     return ICON_OK;
 }
 
@@ -680,7 +689,7 @@ int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int
     if (prior == ICON_PRIOR_ICON) {
         ICON_ARG(mesh != nullptr, "icon prior needs a mesh handle");
         ICON_ARG(f.n_select == 2, "icon prior needs feature planes created with n_select = 2");
-        *c0 = f.csel + 7;
+        *c0 = f.csel + 1 + ((f.smpl_mask & kSmplCmap) ? 3 : 0) + ((f.smpl_mask & kSmplNorm) ? 3 : 0);
     } else if (prior == ICON_PRIOR_PAMIR) {
         ICON_ARG(f.n_select == 1 && f.vol != nullptr, "pamir prior needs n_select = 1 and a volume");
         *c0 = f.csel + f.Cv;
@@ -812,7 +821,7 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
     work->q_mesh = mesh; work->q_feat = feat; work->q_prior = prior; work->q_sdf_clip = sdf_clip; work->q_cmap_mode = cmap_mode;
     work->q_cal = cal; work->q_L = L; work->q_points = d_points; work->q_N = N; work->q_search = search; work->q_lattice = LATTICE;
     work->q_rows_ready = false; work->slab_patched = false;
-    work->slab_needs_patch = (prior == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE);
+    work->slab_needs_patch = (prior == ICON_PRIOR_ICON && cmap_mode == ICON_CMAP_REFERENCE && (feat->dev.smpl_mask & kSmplCmap));
     work->slab_cmap_slot = feat->dev.csel + 1;
     if (prior != ICON_PRIOR_ICON) return ICON_OK;
     if (search == ICON_SEARCH_BRUTE) {

@@ -146,7 +146,8 @@ class FeatHandle(_Handle):
     encoder output ([1,Cv,D,H,W]); icon_feat_create."""
     _destroy = "icon_feat_destroy"
 
-    def __init__(self, planes: torch.Tensor, n_select: int, vol: Optional[torch.Tensor] = None):
+    def __init__(self, planes: torch.Tensor, n_select: int, vol: Optional[torch.Tensor] = None,
+                 smpl_feats: Sequence[str] = ("sdf", "norm", "vis", "cmap")):
         super().__init__()
         _lib.require_device()
         p = _dev_f32(planes, "features")
@@ -169,6 +170,9 @@ class FeatHandle(_Handle):
             check(_lib.lib().icon_feat_create(ptr(p), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_int(n_select), vp,
                                               C.c_int(Cv), C.c_int(Dv), C.c_int(Hv), C.c_int(Wv), _stream(),
                                               C.byref(self.h)), "icon_feat_create")
+        if n_select == 2 and set(smpl_feats) != {"sdf", "norm", "vis", "cmap"}:
+            check(_lib.lib().icon_feat_set_smpl_feats(self.h, C.c_int(int("cmap" in smpl_feats)), C.c_int(int("norm" in smpl_feats))),
+                  "icon_feat_set_smpl_feats")
         # no synchronisation: the repack kernel is enqueued on the current stream, and the caching allocator
         # recycles the (possibly temporary) source tensors in stream order
 
@@ -358,9 +362,14 @@ class IconQueryEngine:
                  res_layers: Sequence[int] = (2, 3, 4), voxelizer: str = "auto"):
         if prior_type not in _lib.PRIOR:
             raise IconAmdError(f"unknown prior_type {prior_type!r}")
-        if prior_type == "icon" and set(smpl_feats) != {"sdf", "norm", "vis", "cmap"}:
-            raise IconAmdError("the icon kernels are built for smpl_feats = [sdf, norm, vis, cmap] "
-                               "(configs/icon-filter.yaml:16); other subsets are not supported")
+        if prior_type == "icon":
+            unknown = set(smpl_feats) - {"sdf", "norm", "vis", "cmap"}
+            if unknown or "vis" not in smpl_feats:
+                # lib/net/HGPIFuNet.py:334-346: without 'vis' the reference feeds BOTH feature halves (12 + smpl_dim input
+                # channels) - more than the 15 the MLP kernels carry
+                raise IconAmdError(f"smpl_feats = {list(smpl_feats)}: 'vis' must be among them (configs/icon-filter.yaml:17) and only "
+                                   "sdf / norm / vis / cmap exist; subsets that keep 'vis' are supported")
+        self.smpl_feats = tuple(smpl_feats)
         self.prior_type, self.sdf_clip = prior_type, float(sdf_clip)
         self.cmap_mode, self.search, self.precision = cmap_mode, search, precision
         self.res_layers = tuple(res_layers)
@@ -451,7 +460,7 @@ class IconQueryEngine:
         vol = self._pamir_volume() if self.prior_type == "pamir" else None
         k = _key(im_feat) + (_key(vol) if vol is not None else ())
         if k != self._feat_key:
-            self._feat = FeatHandle(im_feat, 2 if self.prior_type == "icon" else 1, vol)
+            self._feat = FeatHandle(im_feat, 2 if self.prior_type == "icon" else 1, vol, smpl_feats=self.smpl_feats)
             self._feat_key, self._feat_src = k, (im_feat, vol)
         return self._feat
 

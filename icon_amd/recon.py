@@ -256,7 +256,8 @@ class DenseReconEngine(nn.Module):
         # message of the sign exchange: [int64 count][2 bits per outlier sign, padded to the largest slab], 8-byte aligned
         stride = 8 + ((per * res * res + 3) // 4 + 7) // 8 * 8
         slab, msg = self._shard_buffers((res, world, rank, str(dev), per), per, res, stride, dev)
-        need_exchange = getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
+        need_exchange = (getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
+                         and "cmap" in getattr(be, "smpl_feats", ("cmap",)))   # the tiled cmap rule is what couples the ranks
         pieces = hasattr(be, "slab_finish_gathered")
         # the volume is gathered in two halves of every rank's (padded) slab: the first half travels over xGMI while
         # the second half is still in the MLP kernel

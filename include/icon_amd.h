@@ -111,6 +111,10 @@ int icon_feat_create(const float *d_planes, int C, int H, int W, int n_select,
                      const float *d_vol, int Cv, int Dv, int Hv, int Wv,
                      void *stream, icon_feat_t **out);
 int icon_feat_destroy(icon_feat_t *feat);
+/* icon prior: cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-309).  The MLP input is [img | sdf | cmap if has_cmap | norm if
+ * has_norm]; 'sdf' is always present, 'vis' must be (it selects the feature half, :334-336 - without it the reference
+ * concatenates both halves, more input channels than these kernels carry).  Default: both (every configs/ *.yaml). */
+int icon_feat_set_smpl_feats(icon_feat_t *feat, int has_cmap, int has_norm);
 
 /* ---------------------------------------------------------------------------------------------
  * MLP (lib/net/MLP.py:8-72 as built by lib/net/HGPIFuNet.py:128-133): Conv1d(k=1) stack with

@@ -529,6 +529,12 @@ void orc_mask_in_cube(const float *xyz, int64_t N, float *occ)
  *     out_x (optional): [N,C/2+7] MLP input in reference channel order
  *                       [img0..5, sdf, cmap r g b, norm x y z] (HGPIFuNet.py:301-311,343,359).
  * ---------------------------------------------------------------------------------------- */
+/* cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-309): bit 0 = 'cmap', bit 1 = 'norm' follow the sdf; 'sdf' is always there and
+ * 'vis' is required (it selects the feature half, :334-336).  Default: both, as every configs/ *.yaml. */
+static int g_smpl_mask = 3;
+void orc_set_smpl_feats(int has_cmap, int has_norm) { g_smpl_mask = (has_cmap ? 1 : 0) | (has_norm ? 2 : 0); }
+int orc_icon_c0(int C) { return C / 2 + 1 + ((g_smpl_mask & 1) ? 3 : 0) + ((g_smpl_mask & 2) ? 3 : 0); }
+
 void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t F,
                     const float *cmaps, const float *vis,
                     const float *feat, int C, int H, int W,
@@ -537,7 +543,7 @@ void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t
                     int cmap_local)
 {
     const int half = C / 2;
-    const int c0 = half + 7;
+    const int c0 = orc_icon_c0(C);
     float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)N);
     orc_project(calib, pts, N, xyz);
     float *sdf = (float *)malloc(sizeof(float) * (size_t)N);
@@ -579,9 +585,10 @@ void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t
         const int off = (vs[i] != 0.0f) ? 0 : half;         /* feat_select, mesh_util.py:272-275 */
         float *x = X + (size_t)c0 * i;
         for (int k = 0; k < half; ++k) x[k] = fall[off + k];
-        x[half] = s;
-        x[half + 1] = c3[0]; x[half + 2] = c3[1]; x[half + 3] = c3[2];
-        x[half + 4] = nrm[3 * i]; x[half + 5] = nrm[3 * i + 1]; x[half + 6] = nrm[3 * i + 2];
+        int o = half;
+        x[o++] = s;
+        if (g_smpl_mask & 1) { x[o] = c3[0]; x[o + 1] = c3[1]; x[o + 2] = c3[2]; o += 3; }
+        if (g_smpl_mask & 2) { x[o] = nrm[3 * i]; x[o + 1] = nrm[3 * i + 1]; x[o + 2] = nrm[3 * i + 2]; }
     }
     orc_mlp_forward(mlp, X, N, c0, out_occ, accumulate_f64);
     orc_mask_in_cube(xyz, N, out_occ);
@@ -602,7 +609,7 @@ void orc_query_icon_subset(const float *verts, int64_t V, const int64_t *faces, 
                            float *out_occ, float *out_x, int accumulate_f64, int cmap_local)
 {
     const int half = C / 2;
-    const int c0 = half + 7;
+    const int c0 = orc_icon_c0(C);
     float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)N);
     orc_project(calib, pts, N, xyz);
     float *sdf = (float *)malloc(sizeof(float) * (size_t)N);
@@ -637,9 +644,10 @@ void orc_query_icon_subset(const float *verts, int64_t V, const int64_t *faces, 
         const int off = (vs[i] != 0.0f) ? 0 : half;
         float *x = X + (size_t)c0 * m;
         for (int k = 0; k < half; ++k) x[k] = fall[off + k];
-        x[half] = s;
-        x[half + 1] = c3[0]; x[half + 2] = c3[1]; x[half + 3] = c3[2];
-        x[half + 4] = nrm[3 * i]; x[half + 5] = nrm[3 * i + 1]; x[half + 6] = nrm[3 * i + 2];
+        int o = half;
+        x[o++] = s;
+        if (g_smpl_mask & 1) { x[o] = c3[0]; x[o + 1] = c3[1]; x[o + 2] = c3[2]; o += 3; }
+        if (g_smpl_mask & 2) { x[o] = nrm[3 * i]; x[o + 1] = nrm[3 * i + 1]; x[o + 2] = nrm[3 * i + 2]; }
         sxyz[3 * m] = xyz[3 * i]; sxyz[3 * m + 1] = xyz[3 * i + 1]; sxyz[3 * m + 2] = xyz[3 * i + 2];
     }
     orc_mlp_forward(mlp, X, M, c0, out_occ, accumulate_f64);

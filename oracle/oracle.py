@@ -40,6 +40,7 @@ def lib():
         _lib.orc_ray_hit.restype = C.c_int
         _lib.orc_get_accel.restype = C.c_int
         _lib.orc_accel_build.restype = C.c_void_p
+        _lib.orc_icon_c0.restype = C.c_int
     return _lib
 
 
@@ -124,6 +125,11 @@ class Accel:
         d2, idx, idx2, ulps = np.empty(n, np.float32), np.empty(n, np.int64), np.empty(n, np.int64), np.empty(n, np.uint8)
         lib().orc_accel_nearest_ties(self.h, _p(pts), C.c_int64(n), _p(d2), _p(idx), _p(idx2), _p(ulps))
         return d2, idx, idx2, ulps
+
+
+def set_smpl_feats(has_cmap: bool = True, has_norm: bool = True) -> None:
+    """cfg.net.smpl_feats for query_icon (lib/net/HGPIFuNet.py:301-309): which of cmap / norm follow the sdf in the MLP input"""
+    lib().orc_set_smpl_feats(C.c_int(int(has_cmap)), C.c_int(int(has_norm)))
 
 
 def set_tie_rule(rule: int = 0, ulps: int = 0) -> None:
@@ -223,7 +229,7 @@ def query_icon(verts, faces, cmap, vis, feat, mlp: Mlp, pts, sdf_clip=0.05, cali
     Cc, H, W = feat.shape
     n = len(pts)
     occ = np.empty(n, np.float32)
-    X = np.empty((n, Cc // 2 + 7), np.float32)
+    X = np.empty((n, int(lib().orc_icon_c0(C.c_int(Cc)))), np.float32)
     cal = _calib12(calib)
     lib().orc_query_icon(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(cmap), _p(vis),
                          _p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), C.byref(mlp.struct),
@@ -243,7 +249,7 @@ def query_icon_subset(verts, faces, cmap, vis, feat, mlp: Mlp, pts, subset, sdf_
     feat = feat.reshape(feat.shape[-3:])
     Cc, H, W = feat.shape
     occ = np.empty(len(subset), np.float32)
-    X = np.empty((len(subset), Cc // 2 + 7), np.float32)
+    X = np.empty((len(subset), int(lib().orc_icon_c0(C.c_int(Cc)))), np.float32)
     cal = _calib12(calib)
     lib().orc_query_icon_subset(_p(verts), C.c_int64(len(verts)), _p(faces), C.c_int64(len(faces)), _p(cmap), _p(vis),
                                 _p(feat), C.c_int(Cc), C.c_int(H), C.c_int(W), C.byref(mlp.struct),

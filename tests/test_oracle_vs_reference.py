@@ -148,6 +148,38 @@ def test_reference_voxelization_wrapper_around_the_leaf(ref, monkeypatch):
     assert mine.any()
 
 
+@pytest.fixture(scope="module")
+def body_net(ref):
+    """the reference HGPIFuNet on the synthetic body (372 M parameters: built once per module)"""
+    return ref_loader.build_netG(assets("body"))
+
+
+@pytest.mark.parametrize("feats", [["sdf", "vis"], ["sdf", "norm", "vis"], ["sdf", "cmap", "vis"], ["vis", "cmap", "norm", "sdf"]])
+def test_smpl_feats_subsets_against_the_reference(ref, body_net, feats):
+    """cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-311): the reference's own query() with a subset of the SMPL features and
+    a regressor of the matching input width vs the oracle's restatement of the same layout [img | sdf | cmap? | norm?]"""
+    a = assets("body")
+    netG, cfg = body_net
+    c0 = 6 + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
+    sd = synth.make_mlp_state_dict(synth.SEED + 5, dims=(c0, 512, 256, 128, 1)) if c0 != 13 else a.state_dict
+    saved = (netG.smpl_feats, netG.if_regressor)
+    try:
+        netG.smpl_feats = feats
+        netG.if_regressor = ref.MLP(filter_channels=[c0, 512, 256, 128, 1], name="if", res_layers=[2, 3, 4], norm="batch", last_op=None).eval()
+        netG.if_regressor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 2500, seed=31)
+        with torch.no_grad():
+            want = ref.query_func(cfg, netG, [T(a.features)], T(pts)[None])[0, 0].numpy()
+        orc.set_smpl_feats("cmap" in feats, "norm" in feats)
+        got, X = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, orc.Mlp(sd), pts,
+                                sdf_clip=a.sdf_clip)
+        assert X.shape[1] == c0
+        assert np.abs(got - want).max() <= 2e-6
+    finally:
+        orc.set_smpl_feats(True, True)
+        netG.smpl_feats, netG.if_regressor = saved
+
+
 def test_attach_reads_the_reference_network(ref):
     """IconQueryEngine.attach() on the reference's REAL HGPIFuNet (no device needed up to the first kernel launch):
     every attribute the engine reads exists with the meaning it assumes, the regressor check accepts the shipped
