@@ -347,7 +347,7 @@ def main():
                 traffic_note = "profiles/traffic.json holds the 257^3 icon step only"
             else:
                 traffic = tj.get(KERNEL[args.precision] + "_bytes_per_launch")
-                traffic_note = ("PMC FETCH_SIZE (x 1.1: calibrated on the known slot / code arrays, tools/rocprof_summary.py) + WRITE_SIZE "
+                traffic_note = ("PMC FETCH_SIZE (x 1.0: calibrated on the known slot / code arrays, tools/rocprof_summary.py) + WRITE_SIZE "
                                 "per launch (profiles/traffic.json, same kernel sources)")
                 if traffic is not None and my_points != n_points:
                     traffic = traffic * my_points / n_points          # the PMC passes were taken on whole-volume launches

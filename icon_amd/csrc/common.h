@@ -154,6 +154,11 @@ __device__ __forceinline__ float apply_last_op(float y, int last_op)
     return last_op == ICON_LASTOP_SIGMOID ? 1.0f / (1.0f + expf(-y)) : y;
 }
 
+// Hand-over of the nearest-triangle search to k_sign / the feature phase, structure of arrays: 16 bits per point - the low 15
+// bits of the triangle slot and, in bit 15, "outside the clip band" - plus, only for meshes with more than 32,768 slots (SMPL:
+// 17 k, SMPL-X: 26 k), a byte with the higher slot bits, plus d^2 for the points inside the band (geom_device.h: store_near).
+struct NearRef { uint16_t *lo; uint8_t *hi; float *d2; };
+
 // where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)
 enum { kSignNone = 0, kSignSelf = 1, kSignGlobal = 2, kSignSeg = 3 };
 struct FusedSigns {
@@ -241,7 +246,10 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
 struct icon_work {
     float *d_x = nullptr;                 // [cap_x][16] MLP input rows (materialising paths only: f32 / mx6 / brute force)
     int64_t cap_x = 0;
-    void *d_near = nullptr;               // nearest-triangle result: int32 slot [cap_points] followed by float d^2 [cap_points]
+    uint16_t *d_near16 = nullptr;         // nearest-triangle result (NearRef): low slot bits + far flag [cap_points]
+    uint8_t *d_near_hi = nullptr;         //   higher slot bits [cap_points_hi], allocated for meshes with > 32,768 slots only
+    float *d_near_d2 = nullptr;           //   d^2 [cap_points], written inside the clip band only
+    int64_t cap_points_hi = 0;
     uint8_t *d_code8 = nullptr;           // [cap_points] byte copy of each row's code word
     int64_t cap_points = 0;
     uint64_t *d_grp_mask = nullptr;       // [4 * cap_blocks] outlier ballot of every 64-point group (k_sign): rank of a point = block offset + popcounts
@@ -286,6 +294,12 @@ struct icon_work {
 };
 
 namespace icon {
-inline int32_t *work_near_slot(const icon_work *w) { return reinterpret_cast<int32_t *>(w->d_near); }
-inline float *work_near_d2(const icon_work *w) { return reinterpret_cast<float *>(w->d_near) + w->cap_points; }
+constexpr int kNearLoSlots = 32768;      // slots addressable by the 15 low bits
+inline NearRef work_near(const icon_work *w, const icon_mesh *mesh)
+{
+    NearRef r;
+    r.lo = w->d_near16; r.d2 = w->d_near_d2;
+    r.hi = (mesh && mesh->dev.n_tris > kNearLoSlots) ? w->d_near_hi : nullptr;
+    return r;
+}
 }  // namespace icon

@@ -69,8 +69,7 @@ struct FusedGeom {
     int64_t N;                   // work items of this launch
     float sdf_clip;
     int cmap_local;
-    const int32_t *near_slot;    // icon prior: slot of the nearest triangle (k_nearest / k_nearest_coop)
-    const float *near_d2;        //             its squared distance - valid for the points inside the clip band only
+    NearRef near;                // icon prior: slot of the nearest triangle (k_nearest / k_nearest_coop), far flag, d^2 inside the clip band
     const uint8_t *code8;        // icon prior: outlier / sign / inside / in_cube (k_nearest<.., SIGN> or k_sign)
     const int64_t *block_offsets;        // exclusive scan of the outlier counts per 256 points of the linear order
     const unsigned long long *grp_mask;  // outlier ballot of every 64-point group of the linear order (4 per block)
@@ -87,7 +86,7 @@ static_assert(kScanBlock == 256, "k_sign's 256-point blocks are the blocks of th
 template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                              const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2, uint8_t *__restrict__ code8,
+                                              NearRef near, uint8_t *__restrict__ code8,
                                               int32_t *__restrict__ block_counts, unsigned long long *__restrict__ grp_mask, float far_box2)
 {
     __shared__ int wsum[4];
@@ -108,8 +107,8 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
     // outside the clip band (~94 % of a lattice): the code needs the inside test only.  Nine points in ten are
     // farther from the body's bounding box than the band is wide - they are known to be outside it without
     // reading anything; for the rest the search left a flag in the slot word
-    const bool far = box_dist2(m.box_lo[0], m.box_lo[1], m.box_lo[2], m.box_hi[0], m.box_hi[1], m.box_hi[2], p) > far_box2 || near_slot[i] < 0;
-    code = far ? sign_code_far(p, ins) : sign_code(p, near_d2[i], ins, sdf_clip);
+    const bool far = box_dist2(m.box_lo[0], m.box_lo[1], m.box_lo[2], m.box_hi[0], m.box_hi[1], m.box_hi[2], p) > far_box2 || near_is_far(near, i);
+    code = far ? sign_code_far(p, ins) : sign_code(p, near.d2[i], ins, sdf_clip);
     code8[i] = (uint8_t)code;
     }
     // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
@@ -183,8 +182,8 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
 {
     const uint32_t code = G.code8[i];
     Nearest nr;
-    nr.slot = (int)((uint32_t)G.near_slot[i] & ~kNearFar); nr.face = 0;
-    nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near_d2[i];    // an outlier's sdf is its sign
+    nr.slot = near_slot_of(G.near, i); nr.face = 0;
+    nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near.d2[i];    // an outlier's sdf is its sign
     const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
     float s = o.sdf;
     f3 cmv = o.cm;
@@ -379,10 +378,10 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
     ICON_ARG(nb > 0 && nb < (1ll << 31), "too many workgroups for one launch");
     const float far_box2 = far_box_dist2(sdf_clip);
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                                    work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts,
+                                    work->d_row_count, work->d_row_slots, work_near(work, mesh), work->d_code8, work->d_block_counts,
                                     (unsigned long long *)work->d_grp_mask, far_box2);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
-                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near_slot(work), work_near_d2(work), work->d_code8, work->d_block_counts,
+                            (const int32_t *)nullptr, (const int32_t *)nullptr, work_near(work, mesh), work->d_code8, work->d_block_counts,
                             (unsigned long long *)work->d_grp_mask, far_box2);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
@@ -443,7 +442,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     if (N <= 0) { ICON_HIP(hipGetLastError()); return ICON_OK; }
     ICON_ARG(N < (1ll << 31), "fused: more than 2^31 points in one call");
     G.N = N;
-    G.near_slot = work_near_slot(work); G.near_d2 = work_near_d2(work); G.code8 = work->d_code8;
+    G.near = work_near(work, mesh); G.code8 = work->d_code8;
     G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;

@@ -822,13 +822,21 @@ __device__ __forceinline__ uint32_t sign_code(f3 p, float d2, bool ins, float sd
 // the inside test, so the kernel that holds d^2 in a register decides "outside the clip band" (exactly the comparison
 // sign_code makes) and flags it in the slot word; d^2 itself is only stored for the ~6 % of points inside the band,
 // the only ones whose consumers read it: ~90 MB less HBM traffic per 257^3 step.
-constexpr uint32_t kNearFar = 0x80000000u;
-__device__ __forceinline__ void store_near(int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int64_t i, const Nearest &nr, float sdf_clip)
+constexpr uint32_t kNearFar = 0x8000u;
+__device__ __forceinline__ void store_near(const NearRef &r, int64_t i, const Nearest &nr, float sdf_clip)
 {
     const float dist = sqrtf(nr.d2) / sqrtf(3.0f);
     const bool far = dist >= sdf_clip && dist > 0.0f;       // dist == 0 (sign 0) stays on the general path
-    near_slot[i] = (int32_t)((uint32_t)nr.slot | (far ? kNearFar : 0u));
-    if (!far) near_d2[i] = nr.d2;
+    r.lo[i] = (uint16_t)(((uint32_t)nr.slot & 0x7fffu) | (far ? kNearFar : 0u));
+    if (r.hi) r.hi[i] = (uint8_t)((uint32_t)nr.slot >> 15);   // wave-uniform: meshes with more than 32,768 slots only
+    if (!far) r.d2[i] = nr.d2;
+}
+__device__ __forceinline__ bool near_is_far(const NearRef &r, int64_t i) { return (r.lo[i] & kNearFar) != 0; }
+__device__ __forceinline__ int near_slot_of(const NearRef &r, int64_t i)
+{
+    uint32_t s = (uint32_t)r.lo[i] & 0x7fffu;
+    if (r.hi) s |= (uint32_t)r.hi[i] << 15;
+    return (int)s;
 }
 // code byte of a point flagged kNearFar: what sign_code returns for |s| >= sdf_clip, s = +-dist, dist > 0
 __device__ __forceinline__ uint32_t sign_code_far(f3 p, bool ins)

@@ -50,14 +50,14 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
 
 // point mode, one wavefront per point (see nearest_coop)
 __global__ __launch_bounds__(kCoopWaves * 64) void k_nearest_coop(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N,
-                                                                 int32_t *__restrict__ near_slot, float *__restrict__ near_d2, int cap, float sdf_clip)
+                                                                 NearRef near, int cap, float sdf_clip)
 {
     extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
     const f3 p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
-    if ((threadIdx.x & 63) == 0) store_near(near_slot, near_d2, i, nr, sdf_clip);
+    if ((threadIdx.x & 63) == 0) store_near(near, i, nr, sdf_clip);
 }
 
 __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, const float *__restrict__ pts, int64_t N,
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
 // the unpinned tie behaviour of the kaolin leaf (lib/dataset/mesh_util.py:374-390).
 template <bool LATTICE, bool ALT = false>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
-                                                    int32_t *__restrict__ near_slot, float *__restrict__ near_d2, const int32_t *__restrict__ perm,
+                                                    NearRef near, const int32_t *__restrict__ perm,
                                                     float sdf_clip, int tie_ulps)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
     if (ALT) nr = nearest_packet_alt(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, (uint32_t)__float_as_int(nr.d2), (uint32_t)tie_ulps);
     // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
     //  writes but the block-wide barrier costs 0.14 ms; not kept)
-    if (live) store_near(near_slot, near_d2, i, nr, sdf_clip);
+    if (live) store_near(near, i, nr, sdf_clip);
 }
 
 // Diagnostics (icon_sdf_query_ties): winner, runner-up and the ulp gap between their squared distances
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
                                                      const float *__restrict__ pts, int64_t N,
                                                      float sdf_clip, int cmap_local,
                                                      const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
-                                                     const int32_t *__restrict__ near_slot, const float *__restrict__ near_d2,
+                                                     NearRef near,
                                                      float *__restrict__ X, uint8_t *__restrict__ code8, int skip_shell)
 {
     __shared__ int lds[(PRIOR == ICON_PRIOR_ICON && BRUTE) ? kBruteTile * 24 : 1];
@@ -195,8 +195,8 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
             // the geometry pre-pass ran on the same stream just before: slot of the nearest triangle, the code byte
             // (outlier / sign / inside / in_cube) and, for points inside the clip band only, d^2
             code = code8[i];
-            nr.slot = (int)((uint32_t)near_slot[i] & ~kNearFar); nr.face = 0;
-            nr.d2 = (code & kCodeOutlier) ? 0.0f : near_d2[i];
+            nr.slot = near_slot_of(near, i); nr.face = 0;
+            nr.d2 = (code & kCodeOutlier) ? 0.0f : near.d2[i];
             ins = (code & kCodeInside) != 0;
             o = sdf_attrs(m, p, nr, ins);
         }
@@ -585,7 +585,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_grp_mask); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near); (void)hipFree(w->d_code8);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
@@ -649,8 +649,9 @@ inline void mark(icon_work *w, int k, hipStream_t st)
 int ensure_work(icon_work *w, int64_t n_points, bool need_x)
 {
     if (n_points > w->cap_points) {
-        (void)hipFree(w->d_near); w->d_near = nullptr; w->cap_points = 0;
-        ICON_HIP(hipMalloc((void **)&w->d_near, (size_t)n_points * 8));
+        (void)hipFree(w->d_near16); (void)hipFree(w->d_near_d2); w->d_near16 = nullptr; w->d_near_d2 = nullptr; w->cap_points = 0;
+        ICON_HIP(hipMalloc((void **)&w->d_near16, (size_t)n_points * sizeof(uint16_t)));
+        ICON_HIP(hipMalloc((void **)&w->d_near_d2, (size_t)n_points * sizeof(float)));
         (void)hipFree(w->d_code8); w->d_code8 = nullptr;
         ICON_HIP(hipMalloc((void **)&w->d_code8, (size_t)n_points));
         w->cap_points = n_points;
@@ -723,8 +724,12 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb >= 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    int32_t *near_slot = work_near_slot(work);
-    float *near_d2 = work_near_d2(work);
+    if (mesh->dev.n_tris > kNearLoSlots && work->cap_points_hi < work->cap_points) {      // big meshes: the byte of higher slot bits
+        (void)hipFree(work->d_near_hi); work->d_near_hi = nullptr; work->cap_points_hi = 0;
+        ICON_HIP(hipMalloc((void **)&work->d_near_hi, (size_t)work->cap_points));
+        work->cap_points_hi = work->cap_points;
+    }
+    const NearRef near = work_near(work, mesh);
     // point mode: sparse batches walk the tree one wavefront per point; a batch dense enough for a wave's 64
     // Morton neighbours to be close together goes through the packet kernel
     const int32_t *perm = nullptr;
@@ -733,14 +738,14 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     if (!LATTICE && !alt && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
         const int cap = coop_cap((int)mesh->stats[1]);
         hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
-                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near_slot, near_d2, cap, sdf_clip);
+                           kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near, cap, sdf_clip);
     } else if (nb > 0) {                         // nb == 0: a slab that is all shell (nothing to search)
         if (!LATTICE) {
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip, work->tie_ulps);
-        else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near_slot, near_d2, perm, sdf_clip, 0);
+        if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps);
+        else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0);
     }
     ICON_HIP(hipGetLastError());
     return launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
@@ -766,7 +771,7 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     const MeshDev md = mesh ? mesh->dev : MeshDev{};
     const int local = (cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
     const bool brute = (search == ICON_SEARCH_BRUTE);
-#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, Lf, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, work_near_slot(work), work_near_d2(work), work->d_x, work->d_code8, skip_shell)
+#define ICON_LAUNCH(P, B) hipLaunchKernelGGL((k_features<P, LATTICE, B>), grid, block, 0, st, md, feat->dev, cal, Lf, d_points, N, sdf_clip, local, work->d_row_count, work->d_row_slots, work_near(work, mesh), work->d_x, work->d_code8, skip_shell)
     if (prior == ICON_PRIOR_ICON) { if (brute) ICON_LAUNCH(ICON_PRIOR_ICON, true); else ICON_LAUNCH(ICON_PRIOR_ICON, false); }
     else if (prior == ICON_PRIOR_PAMIR) ICON_LAUNCH(ICON_PRIOR_PAMIR, false);
     else ICON_LAUNCH(ICON_PRIOR_PIFU, false);

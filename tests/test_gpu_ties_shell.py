@@ -535,3 +535,35 @@ def test_smpl_feats_subsets_vs_oracle(body, feats, precision):
     eng.set_regressor({k: torch.from_numpy(v) for k, v in body.state_dict.items()})          # 13 inputs
     with pytest.raises(IconAmdError, match="input width"):
         eng.query([feat], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])
+
+
+# ---------------------------------------------------------------------------------------------
+# meshes with more than 32,768 triangle slots (the 16-bit slot hand-over carries a byte of higher bits for them)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_mesh_with_more_slots_than_15_bits(body, precision):
+    """81,920 faces: every consumer of the nearest-triangle hand-over (k_sign, the fused feature phase, k_features) must
+    see the full slot index; lattice and explicit points against the oracle"""
+    import copy
+    from icon_amd.engine import MeshHandle
+    v, f = synth.icosphere(6, radius=0.62, center=(0.03, -0.05, 0.02))
+    v = (v * np.array([0.7, 1.25, 0.45])).astype(np.float32)              # an ellipsoid: not every face equidistant from anything
+    f = f.astype(np.int64)
+    vis, cm = synth.make_vis_cmap(v, f)
+    a = copy.copy(body)
+    a.smpl_verts, a.smpl_faces = v[None], f[None]
+    a.smpl_cmap = np.asarray(cm, np.float32).reshape(1, -1, 3)
+    a.smpl_vis = np.asarray(vis, np.float32).reshape(1, -1, 1)
+    h = MeshHandle(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+    assert h.stats()["slots"] > 32768
+    eng = make_engine(a, precision=precision)
+    res = 33
+    occ = eng.eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
+    ref, _ = oracle_query(a, synth.lattice_points(res))
+    assert np.abs(occ - ref).max() <= OCC_TOL
+    pts = synth.stratified_points(v, f, 5000, seed=8)
+    q = eng.query([T(a.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    refq, _ = oracle_query(a, pts)
+    assert np.abs(q - refq).max() <= OCC_TOL
+    faces_hit = h.sdf_query(T(pts))["face"].cpu().numpy()
+    assert faces_hit.max() > 40000          # the sample does reach triangles stored beyond slot 32,768

@@ -5,8 +5,9 @@ FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  MI355X_MICROARCH.md (HBM secti
 half of the bytes of a wide (16 B/lane) coalesced streaming read; other access widths and WRITE_SIZE are
 uncalibrated - "calibrate on a known byte count in your own access pattern".  Calibrations of this repo (known array
 sizes against the counter, one MI355X):
-  k_fused_f16x3   : icon minus pamir launch (the difference is the slot / code / d^2 / sign arrays, 89 MB at 257^3): 80.7 MB raw
-                    -> factor 1.1 (sparse 4 B/lane and 1 B/lane loads of 256 threads per tile are NOT halved)
+  k_fused_f16x3   : icon minus pamir launch (the difference is the slot / code / d^2 / sign arrays): with 4-byte slots 89 MB known,
+                    80.7 MB raw (1.10); with 2-byte slots 58 MB known, 63.7 MB raw (0.92) -> factor 1.0: the sparse 2-4 B/lane and
+                    1 B/lane loads of 256 threads per tile are NOT halved
   k_outlier_compact: streams the 17.0 MB code array (1 B/lane): 12.7 MB raw -> factor 1.33
   k_sign (round 2, when it still streamed 68 MB of d^2 at 4 B/lane): 35-39 MB raw -> factor 2 (the guide's case)
 Every kernel gets its raw value, the x2 upper bound and - where calibrated - the calibrated fetch; totals and the
@@ -34,7 +35,7 @@ def kernel_sources_sha() -> str:
 
 
 # FETCH_SIZE calibration factors (true bytes / reported bytes) measured on known array sizes - see the module docstring
-FETCH_CALIBRATION = {"k_fused_f16x3": 1.1, "k_outlier_compact": 1.33}
+FETCH_CALIBRATION = {"k_fused_f16x3": 1.0, "k_outlier_compact": 1.33}
 
 
 def short(name):
