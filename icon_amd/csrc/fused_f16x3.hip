@@ -341,8 +341,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
             const f32x16 wv = ld16(w3 + m2 * 16);
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) {
-                const float x = acc2[m2][tt] * w.inv2;
-                part = fmaf(wv[tt], fmaxf(x, 0.01f * x), part);
+                part = fmaf(wv[tt], leaky_scaled(acc2[m2][tt], w.inv2), part);
             }
         }
 #pragma unroll

@@ -98,8 +98,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
         const f32x16 wv = ld16(w3 + m2 * 16);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            const float x = acc2[m2][t] * w.inv2;
-            part = fmaf(wv[t], fmaxf(x, 0.01f * x), part);
+            part = fmaf(wv[t], leaky_scaled(acc2[m2][t], w.inv2), part);
         }
     }
 #pragma unroll

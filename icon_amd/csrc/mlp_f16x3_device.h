@@ -82,12 +82,31 @@ __device__ __forceinline__ void split8(const float *v, half8 &hi, half8 &lo)
     }
 }
 
+// LeakyReLU(0.01) of an accumulator value with the weight scale divided out, in TWO VALU operations:
+//   max(x, 0.01 x) = 0.505 x + 0.495 |x|,  x = a * inv   ->   fma(|a|, 0.495 inv, (0.505 inv) * a)
+// instead of three (a * inv, 0.01 * x, max).  0.505f + 0.495f == 1 exactly; the negative slope comes out as 0.00999999 instead of
+// 0.00999999978 (1e-8 of |x| - a twentieth of the 2^-22 the split product carries) and the positive branch takes one more
+// rounding.  Round 3: the activation work hides in the MFMA shadow but not its energy - 14.04-14.18 vs 14.14-14.26 ms standalone.
+// ICON_ACT_EXACT=1 builds the three-operation form.
+#ifndef ICON_ACT_EXACT
+#define ICON_ACT_EXACT 0
+#endif
+__device__ __forceinline__ float leaky_scaled(float a, float inv)
+{
+#if ICON_ACT_EXACT
+    const float x = a * inv;
+    return fmaxf(x, 0.01f * x);
+#else
+    return fmaf(fabsf(a), 0.495f * inv, (0.505f * inv) * a);
+#endif
+}
+
 // activation step of a finished tile: undo the weight scale, LeakyReLU(0.01), split for the next GEMM
 __device__ __forceinline__ void activate_split(const f32x16 &acc, float inv, half8 hi[2], half8 lo[2])
 {
     float v[16];
 #pragma unroll
-    for (int t = 0; t < 16; ++t) { const float x = acc[t] * inv; v[t] = fmaxf(x, 0.01f * x); }
+    for (int t = 0; t < 16; ++t) v[t] = leaky_scaled(acc[t], inv);
     split8(v, hi[0], lo[0]);
     split8(v + 8, hi[1], lo[1]);
 }
@@ -175,15 +194,7 @@ __device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, ha
     }
 #endif
 
-#if defined(ICON_EXP_ACT7)
-    // LeakyReLU(0.01) with the weight scale folded in: max(x, 0.01 x) = 0.505 x + 0.495 |x| -> v = fma(|a|, c2, c1 a),
-    // c1 = 0.505 inv, c2 = 0.495 inv: 2 VALU per value instead of 3 (7 instead of 9 per pair)
-    const float c1 = 0.505f * inv, c2 = 0.495f * inv;
-    const float v0 = fmaf(fabsf(acc[2 * k]), c2, c1 * acc[2 * k]), v1 = fmaf(fabsf(acc[2 * k + 1]), c2, c1 * acc[2 * k + 1]);
-#else
-    const float x0 = acc[2 * k] * inv, x1 = acc[2 * k + 1] * inv;
-    const float v0 = fmaxf(x0, 0.01f * x0), v1 = fmaxf(x1, 0.01f * x1);
-#endif
+    const float v0 = leaky_scaled(acc[2 * k], inv), v1 = leaky_scaled(acc[2 * k + 1], inv);      // 7 VALU per pair with the split below
     fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     fp16x2 ll = residual_pair(hh, v0, v1);
 #if defined(ICON_EXP_ACT2X)

@@ -6,7 +6,7 @@
 set -e
 cd "$(dirname "$0")/.."
 C=icon_amd/csrc
-VARIANTS="${ICON_EXP_VARIANTS:-base:: act7:-DICON_EXP_ACT7 act2x:-DICON_EXP_ACT2X prio:-DICON_EXP_PRIO act7_prio:-DICON_EXP_ACT7__-DICON_EXP_PRIO}"
+VARIANTS="${ICON_EXP_VARIANTS:-base:: act2x:-DICON_EXP_ACT2X prio:-DICON_EXP_PRIO}"
 if [ "$1" = build ]; then
   make -s -C $C
   mkdir -p icon_amd/exp
