@@ -314,24 +314,24 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
 #pragma unroll
         for (int m = 0; m < 8; ++m) acc1[m] = ld16(sb1 + (m * 2 + h) * 16);
         half8 bh[2], bl[2];
-        activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
+        activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), LeakyK{w.inv0, w.p0, w.q0}, bh, bl);
         f32x16 acc2[4];
         const bool more = tile + 1 < tile_end;                  // the first chunks of the next tile ride on the last ones
         for (int c = 0; c < 16; ++c) {
             l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
-                      w.inv0, h, lane, wave, bh, bl);
+                      LeakyK{w.inv0, w.p0, w.q0}, h, lane, wave, bh, bl);
             ICON_CHUNK_BARRIER();
         }
 #pragma unroll
         for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
-        activate_split(acc1[0], w.inv1, bh, bl);
-        l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        activate_split(acc1[0], LeakyK{w.inv1, w.p1, w.q1}, bh, bl);
+        l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
         ICON_CHUNK_BARRIER();
-        l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
         ICON_CHUNK_BARRIER();
-        l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+        l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
         ICON_CHUNK_BARRIER();
-        l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl, more ? 0 : -1);
+        l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl, more ? 0 : -1);
 
         // ---- layer 3 on the VALU (f32) ---------------------------------------------------------------------
         const float *w3 = sw3 + h * 72;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
             const f32x16 wv = ld16(w3 + m2 * 16);
 #pragma unroll
             for (int tt = 0; tt < 16; ++tt) {
-                part = fmaf(wv[tt], leaky_scaled(acc2[m2][tt], w.inv2), part);
+                part = fmaf(wv[tt], leaky_scaled(acc2[m2][tt], LeakyK{w.inv2, w.p2, w.q2}), part);
             }
         }
 #pragma unroll
@@ -454,6 +454,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     w.image = mlp->d_f16;
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
+    w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
 
     int n_cu = 0;
     const int rc = device_cu_count(&n_cu);

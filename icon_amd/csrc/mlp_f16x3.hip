@@ -70,10 +70,10 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
 
     // ---- layers 0 + 1: one chunk = 32 hidden channels ------------------------------------------
     half8 bh[2], bl[2];
-    activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), w.inv0, bh, bl);
+    activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), LeakyK{w.inv0, w.p0, w.q0}, bh, bl);
     for (int c = 0; c < 16; ++c) {
         l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
-                  w.inv0, h, lane, wave, bh, bl);
+                  LeakyK{w.inv0, w.p0, w.q0}, h, lane, wave, bh, bl);
         ICON_CHUNK_BARRIER();   // all waves done with this buffer AND the next chunk has landed
     }
 
@@ -81,14 +81,14 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     f32x16 acc2[4];
 #pragma unroll
     for (int m2 = 0; m2 < 4; ++m2) acc2[m2] = ld16(sb2 + (m2 * 2 + h) * 16);
-    activate_split(acc1[0], w.inv1, bh, bl);
-    l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+    activate_split(acc1[0], LeakyK{w.inv1, w.p1, w.q1}, bh, bl);
+    l2_chunk<0>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
     ICON_CHUNK_BARRIER();
-    l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+    l2_chunk<1>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
     ICON_CHUNK_BARRIER();
-    l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+    l2_chunk<2>(smem, smem + kBufBytes, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
     ICON_CHUNK_BARRIER();
-    l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, w.inv1, lane, wave, bh, bl);
+    l2_chunk<3>(smem + kBufBytes, smem, w.image, acc1, acc2, xhi, xlo, LeakyK{w.inv1, w.p1, w.q1}, lane, wave, bh, bl);
 
     // ---- layer 3 on the VALU (f32) ----------------------------------------------------------------
     const float *w3 = sw3 + h * 72;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
         const f32x16 wv = ld16(w3 + m2 * 16);
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
-            part = fmaf(wv[t], leaky_scaled(acc2[m2][t], w.inv2), part);
+            part = fmaf(wv[t], leaky_scaled(acc2[m2][t], LeakyK{w.inv2, w.p2, w.q2}), part);
         }
     }
 #pragma unroll
@@ -224,6 +224,7 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
     w.image = mlp->d_f16;
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
+    w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
     const int64_t nb = (N + kF16Pts - 1) / kF16Pts;
     ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
     if (first_use_on_device(6)) {          // per device: a process may drive several (common.h)

@@ -42,6 +42,9 @@ struct MlpF16Dev {
     const float *side;          // f32: b0 [16][2][16] | b1 [8][2][16] | b2 [4][2][16] (bias * weight scale) | w3 [2][72]
     float b3;
     float inv0, inv1, inv2;     // 1 / weight scale of layers 0..2
+    // LeakyReLU constants 0.505 / scale and 0.495 / scale per layer, from the host: wave-uniform kernel arguments stay in SGPRs
+    // (computed in the kernel they took five vector registers of a body that has none to spare: 20 B/lane of scratch)
+    float p0, q0, p1, q1, p2, q2;
     int c0;
     int last_op;                // ICON_LASTOP_*
 };
@@ -91,18 +94,19 @@ __device__ __forceinline__ void split8(const float *v, half8 &hi, half8 &lo)
 #ifndef ICON_ACT_EXACT
 #define ICON_ACT_EXACT 0
 #endif
-__device__ __forceinline__ float leaky_scaled(float a, float inv)
+struct LeakyK { float inv, p, q; };          // 1 / scale, 0.505 / scale, 0.495 / scale
+__device__ __forceinline__ float leaky_scaled(float a, const LeakyK &k)
 {
 #if ICON_ACT_EXACT
-    const float x = a * inv;
+    const float x = a * k.inv;
     return fmaxf(x, 0.01f * x);
 #else
-    return fmaf(fabsf(a), 0.495f * inv, (0.505f * inv) * a);
+    return fmaf(fabsf(a), k.q, k.p * a);
 #endif
 }
 
 // activation step of a finished tile: undo the weight scale, LeakyReLU(0.01), split for the next GEMM
-__device__ __forceinline__ void activate_split(const f32x16 &acc, float inv, half8 hi[2], half8 lo[2])
+__device__ __forceinline__ void activate_split(const f32x16 &acc, const LeakyK &inv, half8 hi[2], half8 lo[2])
 {
     float v[16];
 #pragma unroll
@@ -182,12 +186,12 @@ __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const flo
 
 // one eighth of the activation step of a finished layer-0 tile: values 2k, 2k+1 -> LeakyReLU ->
 // hi/lo halves -> pair (k&3) of the next B operand (u = k>>2)
-__device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, half8 (&nh)[2], half8 (&nl)[2])
+__device__ __forceinline__ void act_part(const f32x16 &acc, int k, const LeakyK &inv, half8 (&nh)[2], half8 (&nl)[2])
 {
 #if defined(ICON_EXP_NO_ACT)
     {   // keep the data dependence on the accumulator (one v_mov-class op per pair), drop the arithmetic
         const int u = k >> 2, q = k & 3;
-        const fp16x2 raw = __builtin_bit_cast(fp16x2, __float_as_int(acc[2 * k]) ^ __float_as_int(inv));
+        const fp16x2 raw = __builtin_bit_cast(fp16x2, __float_as_int(acc[2 * k]) ^ __float_as_int(inv.inv));
         nh[u][2 * q] = (_Float16)raw[0]; nh[u][2 * q + 1] = (_Float16)raw[1];
         nl[u][2 * q] = (_Float16)raw[1]; nl[u][2 * q + 1] = (_Float16)raw[0];
         return;
@@ -201,7 +205,7 @@ __device__ __forceinline__ void act_part(const f32x16 &acc, int k, float inv, ha
     {   // the same 9 VALU once more on the same data, results discarded: what does a VALU instruction cost on real data?
         float y0 = acc[2 * k], y1 = acc[2 * k + 1];
         asm volatile("" : "+v"(y0), "+v"(y1));
-        const float z0 = y0 * inv, z1 = y1 * inv;
+        const float z0 = y0 * inv.inv, z1 = y1 * inv.inv;
         const float u0 = fmaxf(z0, 0.01f * z0), u1 = fmaxf(z1, 0.01f * z1);
         fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(u0, u1);
         fp16x2 l2 = residual_pair(h2, u0, u1);
@@ -234,7 +238,7 @@ __device__ __forceinline__ void load_group(const char *__restrict__ L, int g, in
 // pins that interleave so the matrix pipe and the VALU run side by side instead of alternating.
 __device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__restrict__ nxt, const char *__restrict__ W0,
                                           const float *__restrict__ sb0, const char *image, int c, f32x16 (&acc1)[8],
-                                          half8 xhi, half8 xlo, float inv0, int h, int lane, int wave,
+                                          half8 xhi, half8 xlo, const LeakyK &inv0, int h, int lane, int wave,
                                           half8 (&bh)[2], half8 (&bl)[2])
 {
     issue_chunk(image, nxt, c + 1, wave, lane);
@@ -265,7 +269,7 @@ __device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__re
 // tile m+1 (the next B operand) is slotted between the four 6-MFMA groups, two parts per group.
 template <int Q>
 __device__ __forceinline__ void l2_chunk(const char *__restrict__ L, char *__restrict__ nxt, const char *image,
-                                         f32x16 (&acc1)[8], f32x16 (&acc2)[4], half8 xhi, half8 xlo, float inv1,
+                                         f32x16 (&acc1)[8], f32x16 (&acc2)[4], half8 xhi, half8 xlo, const LeakyK &inv1,
                                          int lane, int wave, half8 (&bh)[2], half8 (&bl)[2], int next_chunk = (Q < 3) ? 17 + Q : -1)
 {
     // next_chunk: the chunk DMA'd into `nxt` while this one is multiplied; the persistent kernel passes 0 for

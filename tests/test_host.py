@@ -233,3 +233,46 @@ def test_bench_launches_its_own_ranks():
     else:
         assert p.returncode != 0
         assert "needs a HIP device" in p.stderr and "launch multi-GPU runs with" not in p.stderr
+
+
+def test_hot_kernels_do_not_spill():
+    """the register budget of the MFMA body is used to the last register (250 of 256): any change that makes hipcc spill shows
+    up as scratch traffic on HBM (20 B/lane = 21 MB per 257^3 launch were once introduced by two scalar constants computed in
+    the kernel).  Compile the two hot translation units with the resource remarks and require 0 bytes of scratch for the
+    icon instantiations of the fused kernel, the standalone f16x3 MLP and the lattice search, at 8 waves / SIMD for the latter."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    csrc = os.path.join(ROOT, "icon_amd", "csrc")
+
+    def remarks(src, exact):
+        with tempfile.TemporaryDirectory() as d:
+            cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + (["-ffp-contract=off"] if exact else []) + \
+                  ["-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(csrc, src), "-o", os.path.join(d, "x.o")]
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+            assert p.returncode == 0, p.stdout[-2000:]
+            out, name = {}, None
+            for line in p.stdout.splitlines():
+                m = re.search(r"Function Name: (\S+)", line)
+                if m:
+                    name = m.group(1); out[name] = {}
+                for key in ("ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "VGPRs"):
+                    m = re.search(re.escape(key) + r": (\d+)", line)
+                    if m and name:
+                        out[name][key] = int(m.group(1))
+            return out
+    with ThreadPoolExecutor(3) as ex:
+        fused, mlp, query = ex.map(lambda a: remarks(*a), [("fused_f16x3.hip", True), ("mlp_f16x3.hip", False), ("query_kernels.hip", True)])
+    icon_fused = {k: v for k, v in fused.items() if "k_fused_f16x3ILi0E" in k}
+    assert len(icon_fused) == 2, list(fused)
+    for k, v in {**icon_fused, **{k: v for k, v in mlp.items() if "k_mlp_f16x3" in k}}.items():
+        assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    near = {k: v for k, v in query.items() if "k_nearestILb1ELb0" in k}
+    assert len(near) == 1
+    for k, v in near.items():
+        assert v["ScratchSize [bytes/lane]"] == 0 and v["Occupancy [waves/SIMD]"] == 8, (k, v)
