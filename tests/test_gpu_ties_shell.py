@@ -567,3 +567,53 @@ def test_mesh_with_more_slots_than_15_bits(body, precision):
     assert np.abs(q - refq).max() <= OCC_TOL
     faces_hit = h.sdf_query(T(pts))["face"].cpu().numpy()
     assert faces_hit.max() > 40000          # the sample does reach triangles stored beyond slot 32,768
+
+
+# ---------------------------------------------------------------------------------------------
+# the sharded path on the REAL collective backend (RCCL), world size 1
+# ---------------------------------------------------------------------------------------------
+_NCCL_WORLD1 = r'''
+import os, sys
+sys.path.insert(0, os.environ["ICON_ROOT"]); sys.path.insert(0, os.path.join(os.environ["ICON_ROOT"], "tests"))
+import numpy as np, torch, torch.distributed as dist
+from types import SimpleNamespace
+from icon_amd import synth
+from icon_amd.engine import IconQueryEngine, query_func
+from icon_amd.recon import DenseReconEngine
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+a = synth.make_assets("body")
+T = lambda x: torch.from_numpy(x).to(dev)
+out = {}
+for cmap_mode in ("reference", "local"):
+    for overlap in (True, False):
+        eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, cmap_mode=cmap_mode)
+        eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
+        eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
+        rec = DenseReconEngine(query_func=query_func, resolutions=[17, 65], align_corners=True, engine=eng, overlap_gather=overlap).to(dev)
+        want = eng.eval_slab(T(a.features), 65, 0, 65)
+        got = rec._forward_sharded(eng, T(a.features), 65, dist, 1, 0)          # the N > 1 code path, one rank: RCCL broadcast / all_gather / async handles
+        assert torch.equal(got, want), (cmap_mode, overlap)
+        assert rec.last_stats["slabs"] == [(0, 65)]
+dist.barrier(); dist.destroy_process_group()
+print("NCCL-WORLD1-OK")
+'''
+
+
+def test_sharded_path_on_rccl_world_size_one():
+    """every collective call of the Z-slab path (cut broadcast, int8 message all_gather, the two asynchronous volume gathers
+    and their handles) issued on the real backend - "nccl" = RCCL - with one rank: API and dtype compatibility that the gloo
+    tests cannot vouch for; the volume must equal the unsharded one bit for bit"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from common import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    env = dict(os.environ, ICON_ROOT=ROOT, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", _NCCL_WORLD1], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and "NCCL-WORLD1-OK" in p.stdout, p.stdout[-3000:]
