@@ -16,9 +16,11 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_stats -- pyth
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${T}_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${T}_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $R/gpurun_out/${T}_pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_pmc.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD -d $R/gpurun_out/${T}_lds -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_lds.log 2>&1
 cd $R
 python tools/rocprof_summary.py stats $(find gpurun_out/${T}_stats -name "*.db" | head -1) > gpurun_out/${T}_kernel_stats.csv; head -9 gpurun_out/${T}_kernel_stats.csv
 python tools/rocprof_summary.py traffic $(find gpurun_out/${T}_fetch -name "*.db" | head -1) $(find gpurun_out/${T}_write -name "*.db" | head -1) > gpurun_out/${T}_traffic.json
 python tools/pmc_extract.py $(find gpurun_out/${T}_pmc -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc.txt
+python tools/pmc_extract.py $(find gpurun_out/${T}_lds -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc_lds.txt
 python tools/mlp_power_probe.py f16x3 5 > gpurun_out/${T}_power_probe.txt; cat gpurun_out/${T}_power_probe.txt
 find gpurun_out -name "*.db" -delete
