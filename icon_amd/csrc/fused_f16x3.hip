@@ -211,7 +211,7 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
             cmv = mk3(c3[0], c3[1], c3[2]);
         }
     }
-    gather_planes_dyn(G.f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, xrow);   // feat_select: vis==1 -> front half
+    gather_planes_dyn(G.f, (G.f.n_select == 2 && o.vis == 0.0f) ? 1 : 0, p.x, p.y, xrow);   // feat_select: vis==1 -> front half; no 'vis' in smpl_feats: all channels
     int hh = G.f.csel;                                  // [img | sdf | cmap (if) | norm (if)], HGPIFuNet.py:301-311
     xrow[hh++] = s;
     if (G.f.smpl_mask & kSmplCmap) { xrow[hh] = cmv.x; xrow[hh + 1] = cmv.y; xrow[hh + 2] = cmv.z; hh += 3; }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
             if (cmap_local) cmv = mk3(s, s, s);   // reference mode: patched later from the sign list
         }
         float g[16];
-        gather_planes_dyn(f, (o.vis != 0.0f) ? 0 : 1, p.x, p.y, g);   // feat_select: vis==1 -> front half
+        gather_planes_dyn(f, (f.n_select == 2 && o.vis == 0.0f) ? 1 : 0, p.x, p.y, g);   // feat_select: vis==1 -> front half; no 'vis': all channels
         const int h = f.csel;
         for (int k = 0; k < h; ++k) row[k] = g[k];
         int hh = h;                                       // [img | sdf | cmap (if) | norm (if)], HGPIFuNet.py:301-311
@@ -689,7 +689,7 @@ int check_prior(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, int
     const FeatDev &f = feat->dev;
     if (prior == ICON_PRIOR_ICON) {
         ICON_ARG(mesh != nullptr, "icon prior needs a mesh handle");
-        ICON_ARG(f.n_select == 2, "icon prior needs feature planes created with n_select = 2");
+        // n_select = 2: smpl_vis picks the front or back half (HGPIFuNet.py:334-336); 1: smpl_feats without 'vis', every channel is an input (:345-346)
         *c0 = f.csel + 1 + ((f.smpl_mask & kSmplCmap) ? 3 : 0) + ((f.smpl_mask & kSmplNorm) ? 3 : 0);
     } else if (prior == ICON_PRIOR_PAMIR) {
         ICON_ARG(f.n_select == 1 && f.vol != nullptr, "pamir prior needs n_select = 1 and a volume");

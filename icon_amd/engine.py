@@ -170,7 +170,7 @@ class FeatHandle(_Handle):
             check(_lib.lib().icon_feat_create(ptr(p), C.c_int(Cc), C.c_int(H), C.c_int(W), C.c_int(n_select), vp,
                                               C.c_int(Cv), C.c_int(Dv), C.c_int(Hv), C.c_int(Wv), _stream(),
                                               C.byref(self.h)), "icon_feat_create")
-        if n_select == 2 and set(smpl_feats) != {"sdf", "norm", "vis", "cmap"}:
+        if set(smpl_feats) | {"vis"} != {"sdf", "norm", "vis", "cmap"}:
             check(_lib.lib().icon_feat_set_smpl_feats(self.h, C.c_int(int("cmap" in smpl_feats)), C.c_int(int("norm" in smpl_feats))),
                   "icon_feat_set_smpl_feats")
         # no synchronisation: the repack kernel is enqueued on the current stream, and the caching allocator
@@ -364,11 +364,11 @@ class IconQueryEngine:
             raise IconAmdError(f"unknown prior_type {prior_type!r}")
         if prior_type == "icon":
             unknown = set(smpl_feats) - {"sdf", "norm", "vis", "cmap"}
-            if unknown or "vis" not in smpl_feats:
-                # lib/net/HGPIFuNet.py:334-346: without 'vis' the reference feeds BOTH feature halves (12 + smpl_dim input
-                # channels) - more than the 15 the MLP kernels carry
-                raise IconAmdError(f"smpl_feats = {list(smpl_feats)}: 'vis' must be among them (configs/icon-filter.yaml:17) and only "
-                                   "sdf / norm / vis / cmap exist; subsets that keep 'vis' are supported")
+            if unknown:
+                raise IconAmdError(f"smpl_feats = {list(smpl_feats)}: only sdf / norm / vis / cmap exist")
+            # the sdf is the first smpl feature whether or not it is listed (lib/net/HGPIFuNet.py:300)
+            # without 'vis' (configs/train/icon-mvp.yaml:40) the reference feeds EVERY feature channel, not the half smpl_vis
+            # selects (lib/net/HGPIFuNet.py:345-346); the kernels carry at most 15 input channels in all and refuse more
         self.smpl_feats = tuple(smpl_feats)
         self.prior_type, self.sdf_clip = prior_type, float(sdf_clip)
         self.cmap_mode, self.search, self.precision = cmap_mode, search, precision
@@ -460,7 +460,8 @@ class IconQueryEngine:
         vol = self._pamir_volume() if self.prior_type == "pamir" else None
         k = _key(im_feat) + (_key(vol) if vol is not None else ())
         if k != self._feat_key:
-            self._feat = FeatHandle(im_feat, 2 if self.prior_type == "icon" else 1, vol, smpl_feats=self.smpl_feats)
+            select = 2 if (self.prior_type == "icon" and "vis" in self.smpl_feats) else 1
+            self._feat = FeatHandle(im_feat, select, vol, smpl_feats=self.smpl_feats)
             self._feat_key, self._feat_src = k, (im_feat, vol)
         return self._feat
 

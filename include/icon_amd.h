@@ -104,16 +104,18 @@ int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, int64_t N,
  *   d_planes [C,H,W] f32 - features[-1][0] from HGPIFuNet.filter (lib/net/HGPIFuNet.py:204-266);
  *   d_vol [Cv,D,H,W] f32 or NULL - VolumeEncoder output (PaMIR, lib/net/HGPIFuNet.py:321-325).
  * n_select = 2 for the icon prior (front/back halves chosen by feat_select,
- * lib/dataset/mesh_util.py:266-277), 1 otherwise.  Repacks to channel-last so one bilinear tap
- * is one or two 16-byte loads.
+ * lib/dataset/mesh_util.py:266-277), 1 otherwise - including the icon prior with smpl_feats that lack 'vis'
+ * (configs/train/icon-mvp.yaml:40): every channel is then an MLP input (lib/net/HGPIFuNet.py:345-346).  Repacks to
+ * channel-last so one bilinear tap is one to four 16-byte loads.
  * ------------------------------------------------------------------------------------------- */
 int icon_feat_create(const float *d_planes, int C, int H, int W, int n_select,
                      const float *d_vol, int Cv, int Dv, int Hv, int Wv,
                      void *stream, icon_feat_t **out);
 int icon_feat_destroy(icon_feat_t *feat);
 /* icon prior: cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-309).  The MLP input is [img | sdf | cmap if has_cmap | norm if
- * has_norm]; 'sdf' is always present, 'vis' must be (it selects the feature half, :334-336 - without it the reference
- * concatenates both halves, more input channels than these kernels carry).  Default: both (every configs/ *.yaml). */
+ * has_norm]; 'sdf' is always present; 'vis' (it selects the feature half, :334-336) is n_select = 2 above, its absence
+ * n_select = 1.  At most 15 input channels in all, or the query entry points return ICON_ERR_UNSUPPORTED.
+ * Default: both (every configs/ *.yaml). */
 int icon_feat_set_smpl_feats(icon_feat_t *feat, int has_cmap, int has_norm);
 
 /* ---------------------------------------------------------------------------------------------

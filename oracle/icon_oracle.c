@@ -529,11 +529,13 @@ void orc_mask_in_cube(const float *xyz, int64_t N, float *occ)
  *     out_x (optional): [N,C/2+7] MLP input in reference channel order
  *                       [img0..5, sdf, cmap r g b, norm x y z] (HGPIFuNet.py:301-311,343,359).
  * ---------------------------------------------------------------------------------------- */
-/* cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-309): bit 0 = 'cmap', bit 1 = 'norm' follow the sdf; 'sdf' is always there and
- * 'vis' is required (it selects the feature half, :334-336).  Default: both, as every configs/ *.yaml. */
-static int g_smpl_mask = 3;
-void orc_set_smpl_feats(int has_cmap, int has_norm) { g_smpl_mask = (has_cmap ? 1 : 0) | (has_norm ? 2 : 0); }
-int orc_icon_c0(int C) { return C / 2 + 1 + ((g_smpl_mask & 1) ? 3 : 0) + ((g_smpl_mask & 2) ? 3 : 0); }
+/* cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-309): bit 0 = 'cmap', bit 1 = 'norm' follow the sdf ('sdf' is always there);
+ * bit 2 = 'vis': smpl_vis selects the feature half (:334-336) - without it every feature channel is an input (:345-346,
+ * configs/train/icon-mvp.yaml:40).  Default: all, as every configs/ *.yaml. */
+static int g_smpl_mask = 7;
+void orc_set_smpl_feats(int has_cmap, int has_norm, int has_vis) { g_smpl_mask = (has_cmap ? 1 : 0) | (has_norm ? 2 : 0) | (has_vis ? 4 : 0); }
+static int icon_img_width(int C) { return (g_smpl_mask & 4) ? C / 2 : C; }
+int orc_icon_c0(int C) { return icon_img_width(C) + 1 + ((g_smpl_mask & 1) ? 3 : 0) + ((g_smpl_mask & 2) ? 3 : 0); }
 
 void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t F,
                     const float *cmaps, const float *vis,
@@ -542,7 +544,7 @@ void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t
                     const float *pts, int64_t N, float *out_occ, float *out_x, int accumulate_f64,
                     int cmap_local)
 {
-    const int half = C / 2;
+    const int half = icon_img_width(C);
     const int c0 = orc_icon_c0(C);
     float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)N);
     orc_project(calib, pts, N, xyz);
@@ -582,7 +584,7 @@ void orc_query_icon(const float *verts, int64_t V, const int64_t *faces, int64_t
         }
         float fall[64];
         orc_bilinear(feat, C, H, W, xyz[3 * i], xyz[3 * i + 1], fall);
-        const int off = (vs[i] != 0.0f) ? 0 : half;         /* feat_select, mesh_util.py:272-275 */
+        const int off = ((g_smpl_mask & 4) && vs[i] == 0.0f) ? half : 0;   /* feat_select, mesh_util.py:272-275 */
         float *x = X + (size_t)c0 * i;
         for (int k = 0; k < half; ++k) x[k] = fall[off + k];
         int o = half;
@@ -608,7 +610,7 @@ void orc_query_icon_subset(const float *verts, int64_t V, const int64_t *faces, 
                            const float *pts, int64_t N, const int64_t *subset, int64_t M,
                            float *out_occ, float *out_x, int accumulate_f64, int cmap_local)
 {
-    const int half = C / 2;
+    const int half = icon_img_width(C);
     const int c0 = orc_icon_c0(C);
     float *xyz = (float *)malloc(sizeof(float) * 3 * (size_t)N);
     orc_project(calib, pts, N, xyz);
@@ -641,7 +643,7 @@ void orc_query_icon_subset(const float *verts, int64_t V, const int64_t *faces, 
         }
         float fall[64];
         orc_bilinear(feat, C, H, W, xyz[3 * i], xyz[3 * i + 1], fall);
-        const int off = (vs[i] != 0.0f) ? 0 : half;
+        const int off = ((g_smpl_mask & 4) && vs[i] == 0.0f) ? half : 0;
         float *x = X + (size_t)c0 * m;
         for (int k = 0; k < half; ++k) x[k] = fall[off + k];
         int o = half;

@@ -127,9 +127,10 @@ class Accel:
         return d2, idx, idx2, ulps
 
 
-def set_smpl_feats(has_cmap: bool = True, has_norm: bool = True) -> None:
-    """cfg.net.smpl_feats for query_icon (lib/net/HGPIFuNet.py:301-309): which of cmap / norm follow the sdf in the MLP input"""
-    lib().orc_set_smpl_feats(C.c_int(int(has_cmap)), C.c_int(int(has_norm)))
+def set_smpl_feats(has_cmap: bool = True, has_norm: bool = True, has_vis: bool = True) -> None:
+    """cfg.net.smpl_feats for query_icon (lib/net/HGPIFuNet.py:301-309, :334-346): which of cmap / norm follow the sdf in the MLP
+    input, and whether smpl_vis selects the feature half (without 'vis' every feature channel is an input)"""
+    lib().orc_set_smpl_feats(C.c_int(int(has_cmap)), C.c_int(int(has_norm)), C.c_int(int(has_vis)))
 
 
 def set_tie_rule(rule: int = 0, ulps: int = 0) -> None:

@@ -397,7 +397,7 @@ def test_errors(body):
     with pytest.raises(IconAmdError):
         eng.query([T(body.features)], torch.zeros(2, 3, 5, device=dev()), torch.eye(4, device=dev())[None])
     with pytest.raises(IconAmdError):
-        IconQueryEngine(prior_type="icon", smpl_feats=("sdf", "cmap"))
+        IconQueryEngine(prior_type="icon", smpl_feats=("sdf", "colour"))   # no such SMPL feature
     e2 = IconQueryEngine()
     with pytest.raises(IconAmdError):
         e2.query([T(body.features)], torch.zeros(1, 3, 5, device=dev()), torch.eye(4, device=dev())[None])

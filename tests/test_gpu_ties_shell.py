@@ -500,41 +500,54 @@ def test_sigmoid_last_op_vs_oracle(body, precision):
 # cfg.net.smpl_feats subsets (lib/net/HGPIFuNet.py:301-311)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
-@pytest.mark.parametrize("feats", [["sdf", "vis"], ["sdf", "norm", "vis"], ["sdf", "cmap", "vis"]])
-def test_smpl_feats_subsets_vs_oracle(body, feats, precision):
-    """the MLP input [img | sdf | cmap? | norm?] for the subsets that keep 'vis' (the oracle's layout is pinned against the
-    reference's query() in tests/test_oracle_vs_reference.py); without 'vis' the reference needs 12 + smpl_dim input channels:
-    refused"""
+@pytest.mark.parametrize("feats,planes", [(["sdf", "vis"], 12), (["sdf", "norm", "vis"], 12), (["sdf", "cmap", "vis"], 12),
+                                          (["sdf"], 6), (["sdf"], 12), (["sdf", "norm", "cmap"], 6), (["sdf", "cmap"], 6)])
+def test_smpl_feats_subsets_vs_oracle(body, feats, planes, precision):
+    """the MLP input [img | sdf | cmap? | norm?] for subsets of cfg.net.smpl_feats (the oracle's layout is pinned against the
+    reference's query() in tests/test_oracle_vs_reference.py); without 'vis' (configs/train/icon-mvp.yaml:40) img is EVERY
+    feature channel (HGPIFuNet.py:345-346), with it the half smpl_vis selects"""
     from icon_amd.engine import IconQueryEngine, IconAmdError
-    c0 = 6 + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
+    img = planes // 2 if "vis" in feats else planes
+    c0 = img + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
     sd = synth.make_mlp_state_dict(synth.SEED + 5, dims=(c0, 512, 256, 128, 1))
     omlp = orc.Mlp(sd)
     pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=31)
-    feat = T(body.features)
+    features = np.ascontiguousarray(body.features[:, :planes])
+    feat = T(features)
     try:
-        orc.set_smpl_feats("cmap" in feats, "norm" in feats)
+        orc.set_smpl_feats("cmap" in feats, "norm" in feats, "vis" in feats)
         for cmap_mode in ("reference", "local"):
             eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, smpl_feats=feats, cmap_mode=cmap_mode, precision=precision)
             eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
             eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
             occ = eng.query([feat], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
-            ref, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp, pts,
+            ref, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], features, omlp, pts,
                                     sdf_clip=body.sdf_clip, cmap_local=(cmap_mode == "local"))
             assert np.abs(occ - ref).max() <= OCC_TOL, (feats, cmap_mode)
             vol = eng.eval_slab(feat, 33, 0, 33).cpu().numpy().ravel()
-            ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
+            ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], features, omlp,
                                       synth.lattice_points(33), sdf_clip=body.sdf_clip, cmap_local=(cmap_mode == "local"))
             assert np.abs(vol - ref33).max() <= OCC_TOL, (feats, cmap_mode)
     finally:
-        orc.set_smpl_feats(True, True)
-    with pytest.raises(IconAmdError, match="vis"):
-        IconQueryEngine(prior_type="icon", smpl_feats=["sdf", "norm", "cmap"])
+        orc.set_smpl_feats(True, True, True)
     # a regressor whose input width does not match the selected features is refused by the library
     eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, smpl_feats=feats)
     eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
-    eng.set_regressor({k: torch.from_numpy(v) for k, v in body.state_dict.items()})          # 13 inputs
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in synth.make_mlp_state_dict(synth.SEED + 6, dims=(c0 + 1, 512, 256, 128, 1)).items()})
     with pytest.raises(IconAmdError, match="input width"):
         eng.query([feat], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])
+
+
+def test_smpl_feats_wider_than_the_kernels_is_refused(body):
+    """twelve feature planes without 'vis' plus cmap: 12 + 1 + 3 = 16 input channels, one more than the kernels carry"""
+    from icon_amd.engine import IconQueryEngine, IconAmdError
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, smpl_feats=["sdf", "cmap"])
+    eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
+    with pytest.raises(IconAmdError, match="15 MLP input channels"):
+        eng.query([T(body.features)], torch.zeros(1, 3, 8, device=dev()), torch.eye(4, device=dev())[None])
+    with pytest.raises(IconAmdError, match="15 MLP input channels"):
+        eng.eval_slab(T(body.features), 17, 0, 17)
 
 
 # ---------------------------------------------------------------------------------------------

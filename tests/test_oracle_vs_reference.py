@@ -154,14 +154,19 @@ def body_net(ref):
     return ref_loader.build_netG(assets("body"))
 
 
-@pytest.mark.parametrize("feats", [["sdf", "vis"], ["sdf", "norm", "vis"], ["sdf", "cmap", "vis"], ["vis", "cmap", "norm", "sdf"]])
-def test_smpl_feats_subsets_against_the_reference(ref, body_net, feats):
-    """cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-311): the reference's own query() with a subset of the SMPL features and
-    a regressor of the matching input width vs the oracle's restatement of the same layout [img | sdf | cmap? | norm?]"""
+@pytest.mark.parametrize("feats,planes", [(["sdf", "vis"], 12), (["sdf", "norm", "vis"], 12), (["sdf", "cmap", "vis"], 12),
+                                          (["vis", "cmap", "norm", "sdf"], 12),
+                                          (["sdf"], 6), (["sdf"], 12), (["sdf", "norm", "cmap"], 6), (["cmap"], 6)])
+def test_smpl_feats_subsets_against_the_reference(ref, body_net, feats, planes):
+    """cfg.net.smpl_feats (lib/net/HGPIFuNet.py:301-311, :334-346): the reference's own query() with a subset of the SMPL
+    features and a regressor of the matching input width vs the oracle's restatement of the same layout
+    [img | sdf | cmap? | norm?]; without 'vis' (configs/train/icon-mvp.yaml:40) img is every feature channel, not the selected half"""
     a = assets("body")
     netG, cfg = body_net
-    c0 = 6 + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
-    sd = synth.make_mlp_state_dict(synth.SEED + 5, dims=(c0, 512, 256, 128, 1)) if c0 != 13 else a.state_dict
+    img = planes // 2 if "vis" in feats else planes
+    c0 = img + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
+    sd = synth.make_mlp_state_dict(synth.SEED + 5, dims=(c0, 512, 256, 128, 1)) if (c0, planes, len(feats)) != (13, 12, 4) else a.state_dict
+    features = np.ascontiguousarray(a.features[:, :planes])
     saved = (netG.smpl_feats, netG.if_regressor)
     try:
         netG.smpl_feats = feats
@@ -169,14 +174,14 @@ def test_smpl_feats_subsets_against_the_reference(ref, body_net, feats):
         netG.if_regressor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
         pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 2500, seed=31)
         with torch.no_grad():
-            want = ref.query_func(cfg, netG, [T(a.features)], T(pts)[None])[0, 0].numpy()
-        orc.set_smpl_feats("cmap" in feats, "norm" in feats)
-        got, X = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, orc.Mlp(sd), pts,
+            want = ref.query_func(cfg, netG, [T(features)], T(pts)[None])[0, 0].numpy()
+        orc.set_smpl_feats("cmap" in feats, "norm" in feats, "vis" in feats)
+        got, X = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], features, orc.Mlp(sd), pts,
                                 sdf_clip=a.sdf_clip)
         assert X.shape[1] == c0
         assert np.abs(got - want).max() <= 2e-6
     finally:
-        orc.set_smpl_feats(True, True)
+        orc.set_smpl_feats(True, True, True)
         netG.smpl_feats, netG.if_regressor = saved
 
 
@@ -235,8 +240,8 @@ def test_attach_reads_the_reference_network(ref):
     with pytest.raises(IconAmdError, match="last_op"):
         mlp_sig.last_op = torch.nn.Tanh()
         check_regressor(mlp_sig)
-    # subsets of smpl_feats are refused at attach time (HGPIFuNet.py:301-309)
-    netG.smpl_feats = ["sdf", "norm"]
+    # SMPL features the reference does not have are refused at attach time (HGPIFuNet.py:301-309)
+    netG.smpl_feats = ["sdf", "colour"]
     with pytest.raises(IconAmdError, match="smpl_feats"):
         IconQueryEngine.attach(netG)
     netG.smpl_feats = ["sdf", "norm", "vis", "cmap"]
