@@ -183,6 +183,21 @@ def _np32(t) -> np.ndarray:
     return np.ascontiguousarray(t, dtype=np.float32)
 
 
+def effective_filters(state_dict: dict) -> dict:
+    """``norm_mlp: 'weight'`` (lib/net/MLP.py:42-45): ``nn.utils.weight_norm`` keeps ``filters.l.weight_g`` / ``weight_v`` and
+    applies ``v * (g / ||v||)`` (norm over all but the output dimension) - returned as ``filters.l.weight``.  Other
+    state_dicts pass through."""
+    if not any(k.endswith("weight_g") for k in state_dict):
+        return state_dict
+    out = {k: v for k, v in state_dict.items() if not (k.endswith("weight_g") or k.endswith("weight_v"))}
+    for k, g in state_dict.items():
+        if k.endswith("weight_g"):
+            v = state_dict[k[:-1] + "v"]
+            g, v = (torch.as_tensor(t).detach().float().cpu() for t in (g, v))
+            out[k[:-2]] = torch._weight_norm(v, g, 0)
+    return out
+
+
 class MlpHandle(_Handle):
     """``if_regressor`` weights in reference state_dict layout (``filters.{l}.weight [Cout,Cin,1]``,
     ``filters.{l}.bias``, ``norms.{l}.{weight,bias,running_mean,running_var}``; lib/net/MLP.py:26-45);
@@ -194,6 +209,7 @@ class MlpHandle(_Handle):
         if last_op not in (None, "sigmoid"):
             raise IconAmdError(f"unsupported last_op {last_op!r} (None or 'sigmoid')")
         _lib.require_device()
+        state_dict = effective_filters(state_dict)
         n = 0
         while f"filters.{n}.weight" in state_dict:
             n += 1
@@ -286,24 +302,21 @@ class Workspace(_Handle):
 
 
 def check_regressor(regressor) -> None:
-    """Refuse every ``MLP`` configuration the kernels do not evaluate (lib/net/MLP.py:8-72): the folded
-    operands are only equal to the module for eval-mode BatchNorm1d (``norm_mlp: 'batch'`` in every
-    configs/*.yaml; the config default 'group', lib/common/config.py:80, and 'instance' normalise over the
-    points of the call); ``last_op`` may be None (``test_mode: True``) or ``nn.Sigmoid`` (lib/net/HGPIFuNet.py:128-133)."""
+    """Refuse every ``MLP`` configuration the kernels do not evaluate (lib/net/MLP.py:8-72): eval-mode BatchNorm1d
+    (``norm_mlp: 'batch'`` in every configs/*.yaml) folds into the weights, ``'weight'`` (weight_norm, no norm layers) and any
+    other string (no norm at all, MLP.py:64-65) are plain layers; the config default 'group', lib/common/config.py:80, and
+    'instance' normalise over the points of the call - refused.  ``last_op`` may be None (``test_mode: True``) or ``nn.Sigmoid``
+    (lib/net/HGPIFuNet.py:128-133)."""
     if isinstance(regressor, dict):
         if any(k.startswith("norms.") for k in regressor) and "norms.0.running_mean" not in regressor:
             raise IconAmdError("regressor state_dict has norms.* without running statistics (GroupNorm / InstanceNorm): "
                                "only norm_mlp='batch' (eval-mode BatchNorm1d) can be folded into the weights")
-        if any(k.endswith("weight_g") or k.endswith("weight_v") for k in regressor):
-            raise IconAmdError("regressor uses weight_norm (norm_mlp='weight'): not supported")
         return
     norm = getattr(regressor, "norm", "batch")
     has_norm_layers = len(getattr(regressor, "norms", ())) > 0
     if has_norm_layers and norm != "batch":
         raise IconAmdError(f"if_regressor.norm = {norm!r}: only norm_mlp='batch' (eval-mode BatchNorm1d) is supported - "
                            "group / instance statistics depend on the points of the call and cannot be folded")
-    if norm == "weight":
-        raise IconAmdError("if_regressor.norm = 'weight' (weight_norm) is not supported")
     lo = getattr(regressor, "last_op", None)
     if lo is not None and not isinstance(lo, nn.Sigmoid):
         raise IconAmdError(f"if_regressor.last_op = {type(lo).__name__}: only None (cfg.test_mode) and nn.Sigmoid "

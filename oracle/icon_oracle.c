@@ -424,7 +424,7 @@ void orc_trilinear(const float *vol, int C, int D, int H, int W, float x, float 
 }
 
 /* ------------------------------------------------------------------------------------------
- * S8  MLP.forward (lib/net/MLP.py:49-72): Conv1d(k=1) -> BatchNorm1d(eval, eps 1e-5) ->
+ * S8  MLP.forward (lib/net/MLP.py:49-72): Conv1d(k=1) -> BatchNorm1d(eval, eps 1e-5; none for norm_mlp = 'weight') ->
  *     LeakyReLU(0.01); raw input re-concatenated (after the activations) before res layers;
  *     last_op: none in test mode, Sigmoid otherwise (HGPIFuNet.py:133).  Weights arrive un-folded, exactly as the
  *     reference state_dict holds them.  accumulate_f64 != 0 gives the high-precision variant.
@@ -462,8 +462,9 @@ static void mlp_point(const orc_mlp *m, const float *x, int c0, float *out, int 
                 for (int k = 0; k < n_cur; ++k) acc += (double)w[k] * (double)cur[k];
                 acc += (double)m->b[l][o];
                 if (l != m->n_layers - 1) {
-                    acc = (acc - (double)m->bn_m[l][o]) / sqrt((double)m->bn_v[l][o] + 1e-5) * (double)m->bn_g[l][o]
-                          + (double)m->bn_b[l][o];
+                    if (m->bn_m)   /* NULL: norm_mlp = 'weight' or none - activation only, MLP.py:64-65 */
+                        acc = (acc - (double)m->bn_m[l][o]) / sqrt((double)m->bn_v[l][o] + 1e-5) * (double)m->bn_g[l][o]
+                              + (double)m->bn_b[l][o];
                     if (acc < 0.0) acc *= 0.01;
                 }
                 y = (float)acc;
@@ -472,7 +473,7 @@ static void mlp_point(const orc_mlp *m, const float *x, int c0, float *out, int 
                 for (int k = 0; k < n_cur; ++k) acc += w[k] * cur[k];
                 acc += m->b[l][o];
                 if (l != m->n_layers - 1) {
-                    acc = (acc - m->bn_m[l][o]) / sqrtf(m->bn_v[l][o] + 1e-5f) * m->bn_g[l][o] + m->bn_b[l][o];
+                    if (m->bn_m) acc = (acc - m->bn_m[l][o]) / sqrtf(m->bn_v[l][o] + 1e-5f) * m->bn_g[l][o] + m->bn_b[l][o];
                     if (acc < 0.0f) acc *= 0.01f;
                 }
                 y = acc;

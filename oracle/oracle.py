@@ -165,11 +165,27 @@ class _OrcMlp(C.Structure):
                 ("bn_m", C.c_void_p), ("bn_v", C.c_void_p), ("last_op", C.c_int)]
 
 
+def effective_filters(state_dict: dict) -> dict:
+    """nn.utils.weight_norm (norm_mlp = 'weight', lib/net/MLP.py:42-45) stores filters.l.weight_g [Cout,1,1] and weight_v
+    [Cout,Cin,1]; the weight the layer applies is v * (g / ||v||), the norm over everything but the output dimension"""
+    if not any(k.endswith("weight_g") for k in state_dict):
+        return state_dict
+    out = {k: v for k, v in state_dict.items() if not (k.endswith("weight_g") or k.endswith("weight_v"))}
+    for k in state_dict:
+        if k.endswith("weight_g"):
+            g = np.asarray(state_dict[k], np.float32)
+            v = np.asarray(state_dict[k[:-1] + "v"], np.float32)
+            nrm = np.sqrt((v.reshape(len(v), -1) ** 2).sum(1, dtype=np.float32)).reshape(g.shape)
+            out[k[:-2]] = v * (g / nrm)
+    return out
+
+
 class Mlp:
     """Holds a reference-layout state_dict (numpy) as the orc_mlp struct."""
 
     def __init__(self, state_dict: dict, res_layers=(2, 3, 4), last_op=None):
         """last_op: None (cfg.test_mode) or "sigmoid" (lib/net/HGPIFuNet.py:133)"""
+        state_dict = effective_filters(state_dict)
         n = 0
         while f"filters.{n}.weight" in state_dict:
             n += 1
@@ -192,12 +208,15 @@ class Mlp:
             self._keep.append((arrs, arr))
             return C.cast(arr, C.c_void_p)
 
-        bn = {k: [_f32(state_dict[f"norms.{l}.{k}"]) for l in range(n - 1)]
-              for k in ("weight", "bias", "running_mean", "running_var")}
+        if "norms.0.running_mean" in state_dict:
+            bn = {k: [_f32(state_dict[f"norms.{l}.{k}"]) for l in range(n - 1)]
+                  for k in ("weight", "bias", "running_mean", "running_var")}
+            bn_ptrs = [ptr_array(bn[k]) for k in ("weight", "bias", "running_mean", "running_var")]
+        else:                                       # norm_mlp = 'weight' (or none): no norm layers, MLP.py:42-45,64-65
+            bn, bn_ptrs = None, [C.c_void_p(0)] * 4
         self._keep += [cin, cout, is_res, W, b, bn]
         self.struct = _OrcMlp(n, cin.ctypes.data, cout.ctypes.data, is_res.ctypes.data,
-                              ptr_array(W), ptr_array(b), ptr_array(bn["weight"]), ptr_array(bn["bias"]),
-                              ptr_array(bn["running_mean"]), ptr_array(bn["running_var"]), 1 if last_op == "sigmoid" else 0)
+                              ptr_array(W), ptr_array(b), *bn_ptrs, 1 if last_op == "sigmoid" else 0)
 
     def forward(self, x, f64: bool = False):
         """x [N, c0] point-major -> [N, c_last]"""

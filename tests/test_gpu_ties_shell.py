@@ -497,6 +497,46 @@ def test_sigmoid_last_op_vs_oracle(body, precision):
 
 
 # ---------------------------------------------------------------------------------------------
+# norm_mlp: 'weight' (lib/net/MLP.py:42-45): weight_norm layers, no norm layers
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_weight_norm_regressor_vs_oracle(body, precision):
+    """a state_dict with filters.l.weight_g / weight_v and no norms.*: the library receives v * (g / ||v||) and runs the layers
+    without normalisation (the oracle's reading of the same dict is pinned against the reference's MLP(norm='weight') in
+    tests/test_oracle_vs_reference.py)"""
+    from icon_amd.engine import MlpHandle
+    from common import rows16
+    rs = np.random.RandomState(11)
+    sd = {}
+    for k, v in body.state_dict.items():
+        if k.startswith("norms."):
+            continue
+        if k.endswith(".weight") and not k.startswith("filters.3."):
+            nrm = np.sqrt((v.reshape(len(v), -1) ** 2).sum(1)).reshape(-1, 1, 1).astype(np.float32)
+            sd[k + "_v"] = (v * rs.uniform(0.5, 2.0, (len(v), 1, 1))).astype(np.float32)       # any positive rescaling of v ...
+            sd[k + "_g"] = (nrm * rs.uniform(0.9, 1.1, nrm.shape)).astype(np.float32)          # ... is undone by g / ||v||
+        else:
+            sd[k] = v
+    omlp = orc.Mlp(sd)
+    x = rs.normal(0, 1, (2000, 13)).astype(np.float32)
+    h = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()})
+    got = h.forward(T(rows16(x)), precision).cpu().numpy()
+    want = omlp.forward(x, f64=True)[:, 0]
+    assert np.abs(got - want).max() <= OCC_TOL * max(1.0, np.abs(want).max())
+    eng = make_engine(body, precision=precision)
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=22)
+    occ = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    ref, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp, pts,
+                            sdf_clip=body.sdf_clip)
+    assert np.abs(occ - ref).max() <= OCC_TOL * max(1.0, np.abs(ref).max())
+    vol = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
+    ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
+                              synth.lattice_points(33), sdf_clip=body.sdf_clip)
+    assert np.abs(vol - ref33).max() <= OCC_TOL * max(1.0, np.abs(ref33).max())
+
+
+# ---------------------------------------------------------------------------------------------
 # cfg.net.smpl_feats subsets (lib/net/HGPIFuNet.py:301-311)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])

@@ -185,6 +185,34 @@ def test_smpl_feats_subsets_against_the_reference(ref, body_net, feats, planes):
         netG.smpl_feats, netG.if_regressor = saved
 
 
+def test_weight_norm_regressor_against_the_reference(ref):
+    """norm_mlp: 'weight' (lib/net/MLP.py:42-45,64-65): nn.utils.weight_norm on all but the last layer, no norm layers.  The
+    reference's own MLP with random g / v vs the oracle on the same state_dict, and the weights the engine hands to the
+    library (engine.effective_filters) vs the ones the module applies"""
+    from icon_amd.engine import check_regressor, regressor_state_dict, effective_filters
+    torch.manual_seed(7)
+    dims = [13, 512, 256, 128, 1]
+    mlp = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="weight", last_op=None).eval()
+    with torch.no_grad():
+        for l in range(3):
+            mlp.filters[l].weight_g.mul_(torch.empty_like(mlp.filters[l].weight_g).uniform_(0.5, 2.0))
+        mlp.filters[3].weight.mul_(0.3)
+    assert len(mlp.norms) == 0
+    check_regressor(mlp)
+    sd = regressor_state_dict(mlp)
+    assert "filters.0.weight_g" in sd and "filters.0.weight_v" in sd and "filters.3.weight" in sd and "filters.0.weight" not in sd
+    x = np.random.RandomState(5).normal(0, 1, (3000, 13)).astype(np.float32)
+    with torch.no_grad():
+        want = mlp(T(x.T.copy())[None])[0, 0].numpy()
+    got = orc.Mlp({k: v.numpy() for k, v in sd.items()}).forward(x)[:, 0]
+    assert np.abs(got - want).max() <= 2e-6 * max(1.0, np.abs(want).max())
+    eff = effective_filters(sd)
+    assert not any(k.endswith("weight_g") or k.endswith("weight_v") for k in eff)
+    for l in range(3):
+        assert torch.equal(eff[f"filters.{l}.weight"], mlp.filters[l].weight.detach())      # what the forward pre-hook computed
+    assert torch.equal(eff["filters.3.weight"], sd["filters.3.weight"])
+
+
 def test_attach_reads_the_reference_network(ref):
     """IconQueryEngine.attach() on the reference's REAL HGPIFuNet (no device needed up to the first kernel launch):
     every attribute the engine reads exists with the meaning it assumes, the regressor check accepts the shipped
