@@ -843,25 +843,13 @@ int phase1(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior, float sd
     return ICON_OK;
 }
 
-// Phase 2: the MLP input of every point and the MLP itself, given where the call's outlier signs are.
-// Lattice calls evaluate the planes [za, zb) of the prepared slab into the SLAB's buffer d_occ (several calls may
-// cover a slab piece by piece: the multi-GPU driver gathers the first half while the second is computed).
-int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precision, icon_work *work, hipStream_t st, int za = 0, int zb = 0)
+// The MLP input rows of the prepared call in work->d_x ([N, kXRow], reference channel order, slot kCodeSlot = code word),
+// the reference-mode outlier cmap patched in from wherever the call's sign list is.  Idempotent per prepared call.
+int materialise_rows(icon_work *work, const FusedSigns &fs, hipStream_t st)
 {
     int rc;
     const int prior = work->q_prior;
     const int64_t N = work->q_N;
-    const bool fused = want_fused(precision, work->q_search);
-    const int local = (work->q_cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
-    const LatticeMap &L = work->q_L;
-    const bool first = !work->q_lattice || za == L.z0;
-    if (fused) {
-        if (first) mark(work, 2, st);
-        rc = launch_fused_f16x3(work->q_mesh, work->q_feat, mlp, prior, work->q_cal, L, za, zb, work->q_points, N,
-                                work->q_sdf_clip, local, work, fs, d_occ, work->q_lattice, st);
-        mark(work, 3, st);
-        return rc;
-    }
     if (!work->q_rows_ready) {
         if ((rc = ensure_work(work, N, true))) return rc;
         rc = work->q_lattice ? launch_features<true>(work->q_mesh, work->q_feat, prior, work->q_sdf_clip, work->q_cmap_mode, work->q_cal, work->q_L,
@@ -886,6 +874,29 @@ int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precis
         ICON_HIP(hipGetLastError());
         work->slab_patched = true;
     }
+    return ICON_OK;
+}
+
+// Phase 2: the MLP input of every point and the MLP itself, given where the call's outlier signs are.
+// Lattice calls evaluate the planes [za, zb) of the prepared slab into the SLAB's buffer d_occ (several calls may
+// cover a slab piece by piece: the multi-GPU driver gathers the first half while the second is computed).
+int phase2(const icon_mlp_t *mlp, const FusedSigns &fs, float *d_occ, int precision, icon_work *work, hipStream_t st, int za = 0, int zb = 0)
+{
+    int rc;
+    const int prior = work->q_prior;
+    const int64_t N = work->q_N;
+    const bool fused = want_fused(precision, work->q_search);
+    const int local = (work->q_cmap_mode == ICON_CMAP_LOCAL) ? 1 : 0;
+    const LatticeMap &L = work->q_L;
+    const bool first = !work->q_lattice || za == L.z0;
+    if (fused) {
+        if (first) mark(work, 2, st);
+        rc = launch_fused_f16x3(work->q_mesh, work->q_feat, mlp, prior, work->q_cal, L, za, zb, work->q_points, N,
+                                work->q_sdf_clip, local, work, fs, d_occ, work->q_lattice, st);
+        mark(work, 3, st);
+        return rc;
+    }
+    if ((rc = materialise_rows(work, fs, st))) return rc;
     if (first) mark(work, 2, st);
     if (work->q_lattice) {
         const int64_t o = (int64_t)(za - L.z0) * L.res * L.res, n = (int64_t)(zb - za) * L.res * L.res;
@@ -1093,6 +1104,57 @@ extern "C" int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, in
     }
     // the slab stays prepared: its planes may be finished piece by piece (the next icon_grid_slab_features replaces it)
     return phase2(mlp, fs, d_occ, precision, work, (hipStream_t)stream, za, zb);
+}
+
+// ---- the MLP input rows of a call, handed out (regressors whose normalisation runs over the points of the call) ----
+static int copy_rows_out(icon_work *work, float *d_rows, hipStream_t st)
+{
+    int rc = materialise_rows(work, self_signs(work), st);
+    if (rc) return rc;
+    ICON_HIP(hipMemcpyAsync(d_rows, work->d_x, (size_t)work->q_N * kXRow * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return ICON_OK;
+}
+
+extern "C" int icon_query_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_type, float sdf_clip, int cmap_mode,
+                               const float *h_calib, const float *d_calib, const float *d_points, int64_t N, float *d_rows,
+                               int search, icon_work_t *work, void *stream)
+{
+    ICON_ARG(work && d_points && d_rows, "icon_query_rows: null argument");
+    ICON_ARG(N >= 0, "icon_query_rows: negative N");
+    int c0 = 0;
+    int rc = check_prior(mesh, feat, prior_type, &c0);
+    if (rc) return rc;
+    if (N == 0) return ICON_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if ((rc = ensure_work(work, N, false))) return rc;
+    Calib cal;
+    static const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    memcpy(cal.m, h_calib ? h_calib : ident, sizeof(cal.m));
+    cal.d = d_calib;
+    LatticeMap L{};
+    work->slab_ready = false;
+    if ((rc = phase1<false>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, d_points, N, search, nullptr, work, st))) return rc;
+    return copy_rows_out(work, d_rows, st);
+}
+
+extern "C" int icon_grid_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_type, float sdf_clip, int cmap_mode,
+                              int res, int z0, int z1, float *d_rows, int search, icon_work_t *work, void *stream)
+{
+    ICON_ARG(work && d_rows, "icon_grid_rows: null argument");
+    int c0 = 0;
+    int rc = check_prior(mesh, feat, prior_type, &c0);
+    if (rc) return rc;
+    LatticeMap L;
+    // no shell skip: the rows of the shell are inputs of the call's statistics like any other (HGPIFuNet.py:361-363 masks afterwards)
+    if ((rc = lattice_map(res, z0, z1, nullptr, sdf_clip, false, &L))) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t N = (int64_t)L.nz * res * res;
+    ICON_ARG(N < (1ll << 31), "icon_grid_rows: more than 2^31 points in one slab");
+    if ((rc = ensure_work(work, N, false))) return rc;
+    Calib cal{};
+    work->slab_ready = false;
+    if ((rc = phase1<true>(mesh, feat, prior_type, sdf_clip, cmap_mode, cal, L, nullptr, N, search, nullptr, work, st))) return rc;
+    return copy_rows_out(work, d_rows, st);
 }
 
 extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3])

@@ -301,27 +301,28 @@ class Workspace(_Handle):
         return float(out[0]), float(out[1]), float(out[2])
 
 
-def check_regressor(regressor) -> None:
+def check_regressor(regressor, norm_mlp: Optional[str] = None) -> None:
     """Refuse every ``MLP`` configuration the kernels do not evaluate (lib/net/MLP.py:8-72): eval-mode BatchNorm1d
     (``norm_mlp: 'batch'`` in every configs/*.yaml) folds into the weights, ``'weight'`` (weight_norm, no norm layers) and any
     other string (no norm at all, MLP.py:64-65) are plain layers; the config default 'group', lib/common/config.py:80, and
-    'instance' normalise over the points of the call - refused.  ``last_op`` may be None (``test_mode: True``) or ``nn.Sigmoid``
+    'instance' normalise over the points of the call and take the per-call path of icon_amd/callnorm.py (a state_dict cannot
+    say which it is: ``norm_mlp`` must).  ``last_op`` may be None (``test_mode: True``) or ``nn.Sigmoid``
     (lib/net/HGPIFuNet.py:128-133)."""
     if isinstance(regressor, dict):
-        if any(k.startswith("norms.") for k in regressor) and "norms.0.running_mean" not in regressor:
-            raise IconAmdError("regressor state_dict has norms.* without running statistics (GroupNorm / InstanceNorm): "
-                               "only norm_mlp='batch' (eval-mode BatchNorm1d) can be folded into the weights")
+        if any(k.startswith("norms.") for k in regressor) and "norms.0.running_mean" not in regressor and norm_mlp not in ("group", "instance"):
+            raise IconAmdError("regressor state_dict has norms.* without running statistics (GroupNorm / affine InstanceNorm): set "
+                               "engine.norm_mlp = 'group' or 'instance' - a state_dict does not say which")
         return
     norm = getattr(regressor, "norm", "batch")
     has_norm_layers = len(getattr(regressor, "norms", ())) > 0
-    if has_norm_layers and norm != "batch":
-        raise IconAmdError(f"if_regressor.norm = {norm!r}: only norm_mlp='batch' (eval-mode BatchNorm1d) is supported - "
-                           "group / instance statistics depend on the points of the call and cannot be folded")
+    if has_norm_layers and norm not in ("batch", "group", "instance"):
+        raise IconAmdError(f"if_regressor.norm = {norm!r} with norm layers: lib/net/MLP.py builds norm layers for 'batch', "
+                           "'group' and 'instance' only")
     lo = getattr(regressor, "last_op", None)
     if lo is not None and not isinstance(lo, nn.Sigmoid):
         raise IconAmdError(f"if_regressor.last_op = {type(lo).__name__}: only None (cfg.test_mode) and nn.Sigmoid "
                            "(lib/net/HGPIFuNet.py:133) are evaluated")
-    if getattr(regressor, "training", False):
+    if getattr(regressor, "training", False) and norm == "batch":
         raise IconAmdError("if_regressor is in training mode: BatchNorm batch statistics cannot be folded - call .eval()")
 
 
@@ -330,9 +331,9 @@ def regressor_last_op(regressor) -> Optional[str]:
     return "sigmoid" if isinstance(getattr(regressor, "last_op", None), nn.Sigmoid) else None
 
 
-def regressor_state_dict(regressor) -> dict:
+def regressor_state_dict(regressor, norm_mlp: Optional[str] = None) -> dict:
     """state_dict of an ``MLP`` module (lib/net/MLP.py) or a dict already in that layout."""
-    check_regressor(regressor)
+    check_regressor(regressor, norm_mlp)
     if isinstance(regressor, dict):
         return regressor
     return {k: v for k, v in regressor.state_dict().items() if "num_batches_tracked" not in k}
@@ -391,6 +392,7 @@ class IconQueryEngine:
         self.voxelizer = voxelizer       # pamir: which semantic voxeliser feeds netG.ve (see _pamir_volume)
         self.last_op = None              # for regressors given as a state_dict: None or "sigmoid" (modules carry their own last_op)
         self.tie_rule = None             # diagnostics: ("highest", ulps) - see Workspace.set_tie_rule / DESIGN.md section 2
+        self.norm_mlp = None             # for regressors given as a state_dict: "group" / "instance" (modules say it themselves)
         self._calibrated = None          # (mlp key, precision) the effective precision was derived for
         self._work_tie = None
         self.netG = None
@@ -533,12 +535,74 @@ class IconQueryEngine:
                 _WARNED_VOXELIZER = True
         return have
 
-    def _mlp_handle(self, regressor=None) -> MlpHandle:
+    def _bound_regressor(self, regressor=None):
         reg = regressor if regressor is not None else self._regressor
         if reg is None and self.netG is not None:
             reg = self.netG.if_regressor
         if reg is None:
             raise IconAmdError("no regressor bound: pass regressor= or call set_regressor()")
+        return reg
+
+    def _callnorm_spec(self, reg):
+        """CallNormSpec of a Group / InstanceNorm regressor (icon_amd/callnorm.py), None for everything that folds"""
+        from . import callnorm
+        if isinstance(reg, dict):
+            if self.norm_mlp not in ("group", "instance"):
+                return None
+            sd = effective_filters(reg)
+        else:
+            if getattr(reg, "norm", None) not in ("group", "instance") or len(getattr(reg, "norms", ())) == 0:
+                return None
+            sd = reg.state_dict()
+        n = 0
+        while f"filters.{n}.weight" in sd:
+            n += 1
+        return callnorm.spec_of(reg, self.norm_mlp, [int(sd[f"filters.{l}.weight"].shape[0]) for l in range(n - 1)])
+
+    def _callnorm_eval(self, reg, spec, rows: torch.Tensor) -> torch.Tensor:
+        """occupancy of the call whose MLP input rows are ``rows`` [N,16] under a Group / InstanceNorm regressor: the call's
+        statistics (callnorm.call_statistics), folded like BatchNorm, the MFMA MLP on the rows, the in_cube mask"""
+        from . import callnorm
+        sd = effective_filters(regressor_state_dict(reg, self.norm_mlp))
+        n = 0
+        while f"filters.{n}.weight" in sd:
+            n += 1
+        dev = rows.device
+        W = [torch.as_tensor(sd[f"filters.{l}.weight"]).detach().to(dev, torch.float32).reshape(sd[f"filters.{l}.weight"].shape[0], -1) for l in range(n)]
+        b = [torch.as_tensor(sd[f"filters.{l}.bias"]).detach().to(dev, torch.float32) for l in range(n)]
+        c0 = int(W[0].shape[1])
+        is_res = [l in self.res_layers for l in range(n)]
+        means, variances = callnorm.call_statistics(W, b, is_res, spec, rows, c0)
+        last_op = regressor_last_op(reg) if not isinstance(reg, dict) else self.last_op
+        handle = MlpHandle(callnorm.batchnorm_equivalent({k: torch.as_tensor(v).detach().cpu() for k, v in sd.items()}, spec, means, variances),
+                           self.res_layers, last_op=last_op)
+        occ = handle.forward(rows, "f32" if self.precision == "f32" else "f16x3")
+        return occ * callnorm.in_cube_mask(rows)
+
+    def _rows(self, im_feat, points=None, calib12=None, lattice=None) -> torch.Tensor:
+        """the MLP input rows [N,16] of a call (icon_query_rows / icon_grid_rows): explicit ``points`` [N,3] with ``calib12``, or
+        ``lattice = (res, z0, z1)``"""
+        mesh, feat = self._mesh_handle(), self._feat_handle(im_feat)
+        mh = mesh.h if mesh is not None else C.c_void_p(0)
+        common = (C.c_int(_lib.PRIOR[self.prior_type]), C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]))
+        if lattice is not None:
+            res, z0, z1 = lattice
+            rows = torch.empty(((z1 - z0) * res * res, 16), dtype=torch.float32, device=im_feat.device)
+            check(_lib.lib().icon_grid_rows(mh, feat.h, *common, C.c_int(res), C.c_int(z0), C.c_int(z1), ptr(rows),
+                                            C.c_int(_lib.SEARCH[self.search]), self._work().h, _stream()), "icon_grid_rows")
+            return rows
+        rows = torch.empty((points.shape[0], 16), dtype=torch.float32, device=points.device)
+        on_dev = isinstance(calib12, torch.Tensor)
+        check(_lib.lib().icon_query_rows(mh, feat.h, *common, C.c_void_p(0) if on_dev else ptr(calib12), ptr(calib12) if on_dev else C.c_void_p(0),
+                                         ptr(points), C.c_int64(points.shape[0]), ptr(rows), C.c_int(_lib.SEARCH[self.search]),
+                                         self._work().h, _stream()), "icon_query_rows")
+        return rows
+
+    def _mlp_handle(self, regressor=None) -> MlpHandle:
+        reg = self._bound_regressor(regressor)
+        if self._callnorm_spec(reg) is not None:
+            raise IconAmdError("this regressor normalises over the points of the call (norm_mlp 'group' / 'instance'): it is evaluated by "
+                               "query() and whole-lattice eval_slab() only, not through the split slab protocol (use shard=False)")
         sd = regressor_state_dict(reg)
         last_op = regressor_last_op(reg) if not isinstance(reg, dict) else self.last_op
         k = tuple((n, ) + (_key(t)[0] if isinstance(t, torch.Tensor) else (id(t),)) for n, t in sd.items()) + (last_op,)
@@ -598,6 +662,10 @@ class IconQueryEngine:
         else:
             calib12 = np.ascontiguousarray(calibs[0, :3, :4].detach().to(torch.float32).numpy())
             pts = points[0].t().to(torch.float32).contiguous()
+        reg = self._bound_regressor(regressor)
+        spec = self._callnorm_spec(reg)
+        if spec is not None:        # Group / InstanceNorm: the statistics of THIS call's points (icon_amd/callnorm.py)
+            return [self._callnorm_eval(reg, spec, self._rows(im_feat, points=pts, calib12=calib12)).view(1, 1, n) for im_feat in features]
         mesh = self._mesh_handle()
         mlp = self._mlp_handle(regressor)
         preds = []
@@ -617,6 +685,14 @@ class IconQueryEngine:
     # ---- dense lattice (one rank's share of reconEngine) ------------------------------------------------
     @_guarded
     def eval_slab(self, im_feat, res: int, z0: int, z1: int, regressor=None, out=None) -> torch.Tensor:
+        reg = self._bound_regressor(regressor)
+        spec = self._callnorm_spec(reg)
+        if spec is not None:        # Group / InstanceNorm: the planes [z0,z1) are ONE call, their points the statistics' population
+            occ = self._callnorm_eval(reg, spec, self._rows(im_feat, lattice=(res, z0, z1))).view(z1 - z0, res, res)
+            if out is not None:
+                out.copy_(occ)
+                return out
+            return occ
         mesh, mlp, feat = self._mesh_handle(), self._mlp_handle(regressor), self._feat_handle(im_feat)
         if out is None:
             out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=im_feat.device)

@@ -236,6 +236,20 @@ int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z
                                    const void *d_gathered, int64_t stride, int world, int rank,
                                    float *d_occ, int precision, icon_work_t *work, void *stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * The MLP input rows of a call, materialised: what HGPIFuNet.query concatenates into point_feat before the regressor
+ * (lib/net/HGPIFuNet.py:329-359), point-major d_rows [N,16] f32: slots [0,c0) in the reference's channel order, zeros,
+ * slot 15 = integer bits, value 8 set = in_cube (:274-275).  For regressors whose normalisation runs over the points of the call
+ * (norm_mlp 'group' / 'instance', lib/net/MLP.py:35-41: the host derives the call's statistics, folds them like
+ * BatchNorm and runs icon_mlp_forward on these rows) and for diagnostics.  Exactly one of h_calib / d_calib (or neither:
+ * identity); icon_grid_rows: the lattice planes [z0,z1) as one call, shell included.
+ * ------------------------------------------------------------------------------------------- */
+int icon_query_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_type, float sdf_clip, int cmap_mode,
+                    const float *h_calib, const float *d_calib, const float *d_points, int64_t N, float *d_rows,
+                    int search, icon_work_t *work, void *stream);
+int icon_grid_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_type, float sdf_clip, int cmap_mode,
+                   int res, int z0, int z1, float *d_rows, int search, icon_work_t *work, void *stream);
+
 /* Diagnostics: with precision F16X3 and the BVH search the query runs FUSED - the MLP input rows are
  * assembled in LDS by the MLP kernel itself and never reach HBM (icon_amd/csrc/fused_f16x3.hip).  on != 0
  * forces the materialising path (rows written by a feature kernel, patched, read back by the MLP kernel) that

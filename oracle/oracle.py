@@ -228,6 +228,59 @@ class Mlp:
         return out
 
 
+class CallNormMlp:
+    """MLP.forward (lib/net/MLP.py:49-72) with ``norm='group'`` (nn.GroupNorm(32, C), :35-36) or ``'instance'``
+    (nn.InstanceNorm1d(C), :39-41): after every hidden Conv1d the output [1,C,N] is normalised with the mean / biased variance
+    over (the channels of a group) x (all N points of the call) - InstanceNorm: one channel per group, no affine parameters
+    unless the state_dict carries them - then LeakyReLU(0.01).  The whole call at once, numpy; statistics in float64."""
+
+    def __init__(self, state_dict: dict, kind: str, res_layers=(2, 3, 4), last_op=None, groups: int = 32, eps: float = 1e-5):
+        assert kind in ("group", "instance")
+        sd = effective_filters(state_dict)
+        n = 0
+        while f"filters.{n}.weight" in sd:
+            n += 1
+        self.n, self.kind, self.groups, self.eps, self.res_layers, self.last_op = n, kind, groups, eps, tuple(res_layers), last_op
+        self.W = [_f32(np.asarray(sd[f"filters.{l}.weight"]).reshape(np.asarray(sd[f"filters.{l}.weight"]).shape[0], -1)) for l in range(n)]
+        self.b = [_f32(sd[f"filters.{l}.bias"]) for l in range(n)]
+        self.c0 = self.W[0].shape[1]
+        affine = "norms.0.weight" in sd
+        self.gamma = [_f32(sd[f"norms.{l}.weight"]) if affine else None for l in range(n - 1)]
+        self.beta = [_f32(sd[f"norms.{l}.bias"]) if affine else None for l in range(n - 1)]
+
+    def plain(self) -> "Mlp":
+        """the same filters without any norm (only good for asking the C oracle for the MLP input rows)"""
+        sd = {f"filters.{l}.weight": self.W[l][:, :, None] for l in range(self.n)}
+        sd.update({f"filters.{l}.bias": self.b[l] for l in range(self.n)})
+        return Mlp(sd, self.res_layers)
+
+    def forward(self, x) -> np.ndarray:
+        """x [N, c0] (the whole call) -> [N]"""
+        x = _f32(x)
+        assert x.ndim == 2 and x.shape[1] == self.c0 and len(x) > 0
+        N = len(x)
+        h = x
+        for l in range(self.n):
+            inp = np.concatenate([h, x], 1) if l in self.res_layers else h
+            y = inp @ self.W[l].T + self.b[l]
+            if l == self.n - 1:
+                h = y
+                break
+            C_ = y.shape[1]
+            G = self.groups if self.kind == "group" else C_
+            yg = y.reshape(N, G, C_ // G).astype(np.float64)
+            mu = yg.mean(axis=(0, 2))
+            var = yg.var(axis=(0, 2))                          # biased, as both torch norms use
+            y = ((yg - mu[None, :, None]) / np.sqrt(var + self.eps)[None, :, None]).reshape(N, C_).astype(np.float32)
+            if self.gamma[l] is not None:
+                y = y * self.gamma[l] + self.beta[l]
+            h = np.where(y < 0, np.float32(0.01) * y, y).astype(np.float32)
+        out = h[:, 0]
+        if self.last_op == "sigmoid":
+            out = (1.0 / (1.0 + np.exp(-out.astype(np.float64)))).astype(np.float32)
+        return out
+
+
 _IDENT = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0]], np.float32)
 
 
@@ -256,6 +309,18 @@ def query_icon(verts, faces, cmap, vis, feat, mlp: Mlp, pts, sdf_clip=0.05, cali
                          C.c_float(np.float32(sdf_clip)), _p(cal), _p(pts), C.c_int64(n), _p(occ), _p(X),
                          C.c_int(int(f64)), C.c_int(int(cmap_local)))
     return occ, X
+
+
+def query_icon_callnorm(verts, faces, cmap, vis, feat, mlp: "CallNormMlp", pts, sdf_clip=0.05, calib=None, cmap_local=False):
+    """HGPIFuNet.query (icon branch) with a Group / InstanceNorm regressor: the MLP input rows of the call from the C
+    restatement, the regressor over ALL of them at once (its statistics are the call's), then the in_cube mask
+    (lib/net/HGPIFuNet.py:274-275,361-363) -> (occ [N], X)"""
+    _, X = query_icon(verts, faces, cmap, vis, feat, mlp.plain(), pts, sdf_clip=sdf_clip, calib=calib, cmap_local=cmap_local)
+    pts = _f32(pts).reshape(-1, 3)
+    xyz = np.empty_like(pts)
+    lib().orc_project(_p(_calib12(calib)), _p(pts), C.c_int64(len(pts)), _p(xyz))
+    in_cube = ((xyz > -1.0) & (xyz < 1.0)).all(1).astype(np.float32)
+    return in_cube * mlp.forward(X), X
 
 
 def query_icon_subset(verts, faces, cmap, vis, feat, mlp: Mlp, pts, subset, sdf_clip=0.05, calib=None, f64=False,

@@ -537,6 +537,94 @@ def test_weight_norm_regressor_vs_oracle(body, precision):
 
 
 # ---------------------------------------------------------------------------------------------
+# norm_mlp 'group' / 'instance' (lib/net/MLP.py:35-41): statistics over the points of the call (icon_amd/callnorm.py)
+# ---------------------------------------------------------------------------------------------
+def _callnorm_state_dict(body, kind):
+    rs = np.random.RandomState(2)
+    sd = {k: v for k, v in body.state_dict.items() if k.startswith("filters.")}
+    if kind == "group":
+        for l, c in enumerate((512, 256, 128)):
+            sd[f"norms.{l}.weight"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+            sd[f"norms.{l}.bias"] = rs.normal(0, 0.1, c).astype(np.float32)
+    return sd
+
+
+class _CallNormMLP(torch.nn.Module):
+    """the attribute surface of lib/net/MLP.py for norm = 'group' / 'instance' (the reference class itself does not travel)"""
+
+    def __init__(self, sd, kind):
+        super().__init__()
+        dims = [13, 512, 256, 128, 1]
+        self.norm, self.last_op, self.res_layers = kind, None, [2, 3, 4]
+        self.filters = torch.nn.ModuleList([torch.nn.Conv1d(dims[l] + (13 if l in (2, 3) else 0), dims[l + 1], 1) for l in range(4)])
+        self.norms = torch.nn.ModuleList([torch.nn.GroupNorm(32, c) if kind == "group" else torch.nn.InstanceNorm1d(c) for c in dims[1:-1]])
+        self.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("kind", ["group", "instance"])
+def test_call_normalised_regressors_vs_oracle(body, kind, precision):
+    """Group / InstanceNorm regressors: explicit points (whole call and a half of it - different statistics), the 33^3 lattice
+    as one call (shell included in the statistics), module and state_dict binding; the oracle's restatement is pinned against
+    the reference's MLP(norm=...) through its own query() in tests/test_oracle_vs_reference.py"""
+    from icon_amd.engine import IconAmdError
+    sd = _callnorm_state_dict(body, kind)
+    omlp = orc.CallNormMlp(sd, kind)
+    args = (body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp)
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 4000, seed=23)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1], [1.2, 0.0, 0.0]], np.float32)])      # on / outside the cube: in the statistics, masked after
+    eye = torch.eye(4, device=dev())[None]
+    for cmap_mode in ("reference", "local"):
+        eng = make_engine(body, precision=precision, cmap_mode=cmap_mode)
+        eng.set_regressor(_CallNormMLP(sd, kind).eval().to(dev()))
+        occ = eng.query([T(body.features)], T(pts.T.copy())[None], eye)[0][0, 0].cpu().numpy()
+        ref, _ = orc.query_icon_callnorm(*args, pts, sdf_clip=body.sdf_clip, cmap_local=(cmap_mode == "local"))
+        scale = max(1.0, float(np.abs(ref).max()))
+        assert np.abs(occ - ref).max() <= OCC_TOL * scale, (kind, cmap_mode)
+        assert (occ[-2:] == 0).all()
+        half = eng.query([T(body.features)], T(pts[:2000].T.copy())[None], eye)[0][0, 0].cpu().numpy()
+        ref_half, _ = orc.query_icon_callnorm(*args, pts[:2000], sdf_clip=body.sdf_clip, cmap_local=(cmap_mode == "local"))
+        assert np.abs(half - ref_half).max() <= OCC_TOL * scale
+        assert np.abs(half - occ[:2000]).max() > 1e-3                    # the population of the call matters
+        vol = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
+        ref33, _ = orc.query_icon_callnorm(*args, synth.lattice_points(33), sdf_clip=body.sdf_clip, cmap_local=(cmap_mode == "local"))
+        assert np.abs(vol - ref33).max() <= OCC_TOL * max(1.0, float(np.abs(ref33).max())), (kind, cmap_mode)
+    # a state_dict does not say what its norms are
+    eng = make_engine(body, precision=precision)
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    if kind == "group":
+        with pytest.raises(IconAmdError, match="norm_mlp"):
+            eng.query([T(body.features)], T(pts.T.copy())[None], eye)
+    eng.norm_mlp = kind
+    occ = eng.query([T(body.features)], T(pts.T.copy())[None], eye)[0][0, 0].cpu().numpy()
+    ref, _ = orc.query_icon_callnorm(*args, pts, sdf_clip=body.sdf_clip)
+    assert np.abs(occ - ref).max() <= OCC_TOL * max(1.0, float(np.abs(ref).max()))
+    # the split slab protocol (the multi-GPU driver's) has no whole-call statistics: refused by name
+    with pytest.raises(IconAmdError, match="split slab protocol"):
+        eng.slab_finish_gathered(33, 0, 33, None, 0, 1, 0, device=dev())
+
+
+def test_rows_entry_points_vs_oracle(body):
+    """icon_query_rows / icon_grid_rows: the MLP input rows [N,16] of a call = the oracle's X (reference channel order),
+    slot 15 the in_cube bit; the lattice version includes the shell (no skip)"""
+    eng = make_engine(body)
+    omlp = orc.Mlp(body.state_dict)
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=24)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1]], np.float32)])
+    rows = eng._rows(T(body.features), points=T(pts), calib12=np.eye(4, dtype=np.float32)[:3].copy()).cpu().numpy()
+    _, X = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp, pts, sdf_clip=body.sdf_clip)
+    assert np.abs(rows[:, :13] - X).max() <= 2e-6 and (rows[:, 13:15] == 0).all()
+    code = rows[:, 15].view(np.int32)
+    assert ((code & 8) != 0).tolist() == ((np.abs(pts) < 1.0).all(1)).tolist()
+    rows33 = eng._rows(T(body.features), lattice=(33, 0, 33)).cpu().numpy()
+    _, X33 = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
+                            synth.lattice_points(33), sdf_clip=body.sdf_clip)
+    assert np.abs(rows33[:, :13] - X33).max() <= 2e-6
+    shell = ~(np.abs(synth.lattice_points(33)) < 1.0).all(1)
+    assert np.abs(rows33[shell, :13]).max() > 0.5 and ((rows33[:, 15].view(np.int32) & 8) != 0).tolist() == (~shell).tolist()
+
+
+# ---------------------------------------------------------------------------------------------
 # cfg.net.smpl_feats subsets (lib/net/HGPIFuNet.py:301-311)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])

@@ -170,9 +170,9 @@ def test_synthetic_assets_are_deterministic():
 
 
 def test_unsupported_regressors_are_refused():
-    """lib/net/MLP.py builds GroupNorm / InstanceNorm / weight_norm variants: folding only equals eval-mode
-    BatchNorm1d, everything else must raise instead of silently mis-evaluating.  last_op: None and
-    nn.Sigmoid (cfg.test_mode False) are evaluated, anything else is refused."""
+    """lib/net/MLP.py builds BatchNorm / GroupNorm / InstanceNorm / weight_norm variants: eval-mode BatchNorm1d folds,
+    weight_norm is a plain layer, Group / InstanceNorm take the per-call path; what is none of these must raise instead of
+    silently mis-evaluating.  last_op: None and nn.Sigmoid (cfg.test_mode False) are evaluated, anything else is refused."""
     import torch.nn as nn
     from icon_amd.engine import check_regressor
     from icon_amd._lib import IconAmdError
@@ -187,20 +187,61 @@ def test_unsupported_regressors_are_refused():
     check_regressor(sig)
     from icon_amd.engine import regressor_last_op
     assert regressor_last_op(sig) == "sigmoid" and regressor_last_op(ok) is None
-    for attr, val in (("norm", "group"), ("norm", "instance"), ("norm", "weight"), ("last_op", nn.Tanh())):
+    for attr, val in (("norm", "weight"), ("last_op", nn.Tanh())):      # 'weight' WITH norm layers is not something MLP.py builds
         m = TorchMLP().eval()
         m.norm, m.last_op = "batch", None
         setattr(m, attr, val)
         with pytest.raises(IconAmdError):
             check_regressor(m)
+    # 'group' / 'instance' take the per-call path (icon_amd/callnorm.py); a module whose norm layers are not what its `norm` says
+    from icon_amd.callnorm import spec_of
+    m = TorchMLP().eval()
+    m.norm, m.last_op = "group", None
+    check_regressor(m)
+    with pytest.raises(IconAmdError, match="BatchNorm1d"):
+        spec_of(m, None, [512, 256, 128])
     m = TorchMLP()
     m.norm, m.last_op = "batch", None
     m.train()
     with pytest.raises(IconAmdError):
         check_regressor(m)
     gn = {"filters.0.weight": torch.zeros(4, 3, 1), "norms.0.weight": torch.ones(4), "norms.0.bias": torch.zeros(4)}
-    with pytest.raises(IconAmdError):
+    with pytest.raises(IconAmdError, match="norm_mlp"):
         check_regressor(gn)
+    check_regressor(gn, "group")        # a state_dict cannot say what its norms are: the engine's norm_mlp does
+
+
+@pytest.mark.parametrize("kind", ["group", "instance"])
+def test_call_statistics_fold_like_batchnorm(kind):
+    """icon_amd/callnorm.py on CPU tensors: the statistics of a call (layer 0 from the rows' moments, the others from f32
+    GEMM passes) put into an eval-mode BatchNorm state_dict give the same MLP as Group / InstanceNorm over the call"""
+    from icon_amd import callnorm
+    from oracle import oracle as orc
+    a = synth.make_assets("ico")
+    rs = np.random.RandomState(2)
+    sd = {k: v for k, v in a.state_dict.items() if k.startswith("filters.")}
+    if kind == "group":
+        for l, c in enumerate((512, 256, 128)):
+            sd[f"norms.{l}.weight"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+            sd[f"norms.{l}.bias"] = rs.normal(0, 0.1, c).astype(np.float32)
+    x = rs.normal(0, 1, (5000, 13)).astype(np.float32)
+    x[:, 6] = np.sign(x[:, 6])                                  # a clipped sdf channel: far from Gaussian
+    rows = np.zeros((5000, 16), np.float32)
+    rows[:, :13] = x
+    spec = callnorm.spec_of({k: torch.from_numpy(v) for k, v in sd.items()}, kind, [512, 256, 128])
+    W = [torch.from_numpy(sd[f"filters.{l}.weight"][:, :, 0]) for l in range(4)]
+    b = [torch.from_numpy(sd[f"filters.{l}.bias"]) for l in range(4)]
+    means, variances = callnorm.call_statistics(W, b, [False, False, True, True], spec, torch.from_numpy(rows), 13, chunk=1024)
+    bn = callnorm.batchnorm_equivalent({k: torch.from_numpy(v) for k, v in sd.items()}, spec, means, variances)
+    got = orc.Mlp({k: v.numpy() for k, v in bn.items()}).forward(x)[:, 0]
+    want = orc.CallNormMlp(sd, kind).forward(x)
+    assert np.abs(got - want).max() <= 5e-6 * max(1.0, np.abs(want).max())
+    # the statistics themselves: layer 0 against a direct evaluation
+    y0 = x.astype(np.float64) @ sd["filters.0.weight"][:, :, 0].astype(np.float64).T + sd["filters.0.bias"]
+    g = 32 if kind == "group" else 512
+    mu = y0.reshape(5000, g, -1).mean(axis=(0, 2)).repeat(512 // g)
+    var = y0.reshape(5000, g, -1).var(axis=(0, 2)).repeat(512 // g)
+    assert np.allclose(means[0].numpy(), mu, rtol=1e-9, atol=1e-9) and np.allclose(variances[0].numpy(), var, rtol=1e-7, atol=1e-9)
 
 
 def test_handle_cache_keys_hold_their_tensors():

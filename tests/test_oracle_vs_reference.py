@@ -213,6 +213,51 @@ def test_weight_norm_regressor_against_the_reference(ref):
     assert torch.equal(eff["filters.3.weight"], sd["filters.3.weight"])
 
 
+@pytest.mark.parametrize("kind", ["group", "instance"])
+def test_call_normalised_regressors_against_the_reference(ref, body_net, kind):
+    """norm_mlp 'group' (lib/common/config.py:80 - the config default) / 'instance' (lib/net/MLP.py:35-41): the reference's own
+    query() with such a regressor vs the oracle's whole-call restatement (oracle.CallNormMlp); the statistics are the call's, so
+    the same points asked for in two halves give different values - pinned as well"""
+    from icon_amd.engine import check_regressor
+    from icon_amd.callnorm import spec_of
+    a = assets("body")
+    netG, cfg = body_net
+    torch.manual_seed(3)
+    dims = [13, 512, 256, 128, 1]
+    mlp = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm=kind, last_op=None).eval()
+    with torch.no_grad():
+        for l in range(4):
+            mlp.filters[l].weight.copy_(torch.from_numpy(a.state_dict[f"filters.{l}.weight"]))
+            mlp.filters[l].bias.copy_(torch.from_numpy(a.state_dict[f"filters.{l}.bias"]))
+        if kind == "group":
+            for m in mlp.norms:
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0.0, 0.1)
+    check_regressor(mlp)
+    spec = spec_of(mlp, None, dims[1:-1])
+    assert spec.kind == kind and spec.groups == ([32, 32, 32] if kind == "group" else [512, 256, 128]) and spec.eps == [1e-5] * 3
+    assert (spec.gamma[0] is None) == (kind == "instance")
+    sd = {k: v.numpy() for k, v in mlp.state_dict().items()}
+    assert ("norms.0.weight" in sd) == (kind == "group") and "norms.0.running_mean" not in sd
+    omlp = orc.CallNormMlp(sd, kind)
+    pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 3000, seed=33)
+    saved = netG.if_regressor
+    try:
+        netG.if_regressor = mlp
+        with torch.no_grad():
+            want = ref.query_func(cfg, netG, [T(a.features)], T(pts)[None])[0, 0].numpy()
+            half = ref.query_func(cfg, netG, [T(a.features)], T(pts[:1500])[None])[0, 0].numpy()
+    finally:
+        netG.if_regressor = saved
+    got, _ = orc.query_icon_callnorm(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, omlp, pts, sdf_clip=a.sdf_clip)
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(got - want).max() <= 5e-6 * scale
+    got_half, _ = orc.query_icon_callnorm(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features, omlp, pts[:1500],
+                                          sdf_clip=a.sdf_clip)
+    assert np.abs(got_half - half).max() <= 5e-6 * scale
+    assert np.abs(half - want[:1500]).max() > 1e-3          # the population of the call matters
+
+
 def test_attach_reads_the_reference_network(ref):
     """IconQueryEngine.attach() on the reference's REAL HGPIFuNet (no device needed up to the first kernel launch):
     every attribute the engine reads exists with the meaning it assumes, the regressor check accepts the shipped
@@ -245,14 +290,14 @@ def test_attach_reads_the_reference_network(ref):
     with pytest.raises(IconAmdError, match="training mode"):
         check_regressor(netG.if_regressor)
     netG.if_regressor.eval()
-    # the reference's own MLP class built the way HGPIFuNet.py:128-133 builds it, in the configurations that exist upstream
-    # but that the kernels do not evaluate (whole networks are 372 M parameters each - the regressor is what is checked)
+    # the reference's own MLP class built the way HGPIFuNet.py:128-133 builds it, in the other configurations that exist upstream
+    # (whole networks are 372 M parameters each - the regressor is what is checked)
     dims = [13, 512, 256, 128, 1]
     mlp_group = ref.MLP(filter_channels=dims, name="if", res_layers=[2, 3, 4], norm="group", last_op=None).eval()   # lib/common/config.py:80 - the config default
-    with pytest.raises(IconAmdError, match="norm"):
-        check_regressor(mlp_group)
-    with pytest.raises(IconAmdError, match="running statistics"):
+    check_regressor(mlp_group)                                    # evaluated per call since round 3 (icon_amd/callnorm.py)
+    with pytest.raises(IconAmdError, match="norm_mlp"):           # ... but a bare state_dict does not say what its norms are
         check_regressor(dict(mlp_group.state_dict()))
+    check_regressor(dict(mlp_group.state_dict()), "group")
     # cfg.test_mode False: last_op = nn.Sigmoid() (HGPIFuNet.py:133) is evaluated - the oracle's restatement against the reference's
     # own MLP module with that last_op, on the synthetic checkpoint
     from icon_amd.engine import regressor_last_op
