@@ -8,11 +8,12 @@ inside queries against the SMPL-size body (V=6,890 / F=13,776), barycentric attr
 clipping (reference cmap semantics), bilinear feature gather + front/back select, the fused
 13->512->256->128->1 MLP (f32-class arithmetic by default), the in_cube mask and the [D,H,W] volume
 write - plus, for N > 1, the RCCL exchange of the outlier sign lists and the all_gather of the
-Z-slabs.  Per-image constants (feature planes, packed mesh + BVH, folded weights) are resident in
+Z-slabs (--replicas: one image per GPU instead, whole volumes, no data-path collective, "weak" scaling -
+BASELINE.json configs[4] with --res 513).  Per-image constants (feature planes, packed mesh + BVH, folded weights) are resident in
 HBM before the timed region; their one-off preparation time is reported in config.prep_ms.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--res 257] [--prior icon|pamir]
-                    [--precision f16x3|f32|mx6] [--no-cpu-baseline] [--no-extras]
+                    [--precision f16x3|f32|mx6] [--replicas] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -221,6 +222,9 @@ def main():
     ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "mx6"])
+    ap.add_argument("--replicas", action="store_true",
+                    help="N > 1: one image per GPU, every rank evaluates a whole volume, no data-path collective (BASELINE.json "
+                         "configs[4]: 513^3 x 8 images); default: ONE image, Z-slabs sharded over the ranks (configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the post-timing legs (mx6 fast path, reference schedule, parity sample, mesh Chamfer): "
@@ -284,7 +288,7 @@ def main():
     feats = [T(a.features)]
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions=[33, 65, 129, res] if res == 257 else [res], align_corners=True,
-                             balance_value=0.5, faster=True, engine=eng).to(dev)
+                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas).to(dev)
     opt = SimpleNamespace(num_views=1)
 
     def step(r=recon, e=eng):
@@ -326,9 +330,10 @@ def main():
     assert occ is not None and occ.shape == (res, res, res)
 
     n_points = res ** 3
-    z0, z1 = recon.last_stats["slabs"][rank] if world > 1 else (0, res)      # the cut the engine actually used
+    z0, z1 = recon.last_stats["slabs"][rank] if (world > 1 and not args.replicas) else (0, res)      # the cut the engine actually used
     my_points = (z1 - z0) * res * res
-    value = n_points * args.steps / elapsed
+    images = world if args.replicas else 1
+    value = images * n_points * args.steps / elapsed
     mlp_s = stage[2] * 1e-3
     achieved = (MLP_FLOP_PER_POINT * my_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
     # HBM bytes of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs,
@@ -437,12 +442,12 @@ def main():
             "metric": "query-points/sec at 256^3 grid", "value": value, "unit": "points/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
+            "scaling": "weak" if args.replicas else "strong", "vs_baseline": None, "dtype": DTYPE[args.precision], "data": "synthetic",
             "config": {
-                "workload": f"{cfg_name}, {res}^3 lattice (mcube_res={res - 1}), 1 image: SMPL-size body "
+                "workload": f"{cfg_name}, {res}^3 lattice (mcube_res={res - 1}), {images} image{'s, one per GPU' if images > 1 else ''}: SMPL-size body "
                             f"V=6890/F=13776, planes [1,{a.features.shape[1]},128,128], MLP 13-512-256-128-1, "
                             f"cmap_mode={args.cmap_mode}, mlp={args.precision}",
-                "parallelism": f"zslab{world}", "points_per_step": n_points, "prep_ms": prep_ms,
+                "parallelism": f"replicas{world}" if args.replicas else f"zslab{world}", "points_per_step": images * n_points, "prep_ms": prep_ms,
                 "stage_ms": {"features": stage[0], "cmap_patch": stage[1], "mlp": stage[2]},
                 **extras,
             },

@@ -364,6 +364,14 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert out["n_gpus"] == 2 and len(out["config"]["rank_stage_ms"]) == 2 and out["config"]["parallelism"] == "zslab2"
     planes = [r["planes"] for r in out["config"]["rank_stage_ms"]]
     assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 65
+    # BASELINE.json configs[4]: one image per GPU, whole volumes, no data-path collective
+    p = subprocess.run(base + ["--replicas"], env=dict(env, ICON_AMD_DIST_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert rep["n_gpus"] == 2 and rep["scaling"] == "weak" and rep["config"]["parallelism"] == "replicas2"
+    assert rep["config"]["points_per_step"] == 2 * 65 ** 3 and [r["planes"] for r in rep["config"]["rank_stage_ms"]] == [[0, 65], [0, 65]]
+    assert abs(rep["value"] - 2 * 65 ** 3 / (rep["ms_per_step"] * 1e-3)) <= 1e-6 * rep["value"]
     if torch.cuda.device_count() < 2:
         p = subprocess.run(base, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
         assert p.returncode != 0 and "need 2 HIP devices" in p.stderr
