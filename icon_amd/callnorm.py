@@ -8,13 +8,13 @@ the statistics the norm is a per-channel affine map, i.e. an eval-mode BatchNorm
 them, which is what the MLP kernels fold into their weights.  So a call is
 
   1. the MLP input rows of the call, materialised (``icon_query_rows`` / ``icon_grid_rows``, HIP);
-  2. the statistics, layer by layer: layer 0 is linear in the input, its moments follow from the first and second moments
-     of the rows (float64); layers 1.. need the activations of the layers below - plain f32 library GEMMs (``F.linear``,
-     rocBLAS) over the rows in chunks, per-channel sums in float64;
+  2. the statistics, layer by layer: plain f32 library GEMMs (``F.linear``, rocBLAS) over the rows in chunks - the layers below
+     with their norms already folded in - per-channel sum and sum of squares of the layer's output accumulated in float64;
   3. ``icon_mlp_create`` with the statistics as BatchNorm operands and ``icon_mlp_forward`` on the rows (the f16x3 / f32 MFMA
      kernels), then the in_cube mask.
 
-Cost: the MLP kernel plus about 2.3x its FLOPs in f32 library GEMMs - this is the compatibility path of a configuration no
+Cost: the MLP kernel plus about its own FLOPs again in f32 library GEMMs (2.3x when the pre-norm outputs of a layer do not
+fit beside the rows and the layers below are recomputed) - this is the compatibility path of a configuration no
 ``configs/*.yaml`` ships (all use ``'batch'``), not the benchmarked one.
 """
 from __future__ import annotations
@@ -96,7 +96,7 @@ def _group_stats(mean_c: torch.Tensor, ey2_c: torch.Tensor, groups: int):
 
 @torch.no_grad()
 def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequence[bool], spec: CallNormSpec, rows: torch.Tensor,
-                    c0: int, chunk: int = 1 << 20):
+                    c0: int, chunk: int = 1 << 20, keep_bytes: int = 48 << 30):
     """mean / biased variance per channel (expanded from the groups) of every hidden layer's pre-norm output over the call:
     ``rows`` [N,16] device f32 (slots [0,c0) are the MLP input), ``W[l]`` [Cout,Cin] / ``b[l]`` device f32.  -> two lists of
     float64 device tensors."""
@@ -110,46 +110,53 @@ def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequen
     means, variances = [], []
     gam = [g.to(dev) if g is not None else None for g in spec.gamma]
     bet = [t.to(dev) if t is not None else None for t in spec.beta]
-    # layer 0: y = W0 x + b0 is linear in x - its moments from those of the rows
-    m = torch.zeros(c0, dtype=torch.float64, device=dev)
-    S = torch.zeros((c0, c0), dtype=torch.float64, device=dev)
-    for i in range(0, n_pts, chunk):
-        xc = rows[i:i + chunk, :c0].double()
-        m += xc.sum(0)
-        S += xc.t() @ xc
-    m /= n_pts
-    S /= n_pts
-    W0, b0 = W[0].double(), b[0].double()
-    wm = W0 @ m
-    mean_c = wm + b0
-    ey2_c = ((W0 @ S) * W0).sum(1) + 2.0 * b0 * wm + b0 * b0
-    mu, var = _group_stats(mean_c, ey2_c, spec.groups[0])
-    means.append(mu)
-    variances.append(var)
 
-    def hidden(l, y):
-        """norm_l (with the statistics found so far) + LeakyReLU, in f32 as the module computes it"""
-        rstd = torch.rsqrt(variances[l] + spec.eps[l]).float()
-        y = (y - means[l].float()) * rstd
-        if gam[l] is not None:
-            y = y * gam[l] + bet[l]
-        return F.leaky_relu(y, 0.01)
+    def affine(k):
+        """norm_k with the statistics found so far as y -> y * sc + sh (float64)"""
+        sc = torch.rsqrt(variances[k] + spec.eps[k])
+        if gam[k] is not None:
+            sc = sc * gam[k].double()
+        sh = -means[k] * sc
+        if bet[k] is not None:
+            sh = sh + bet[k].double()
+        return sc, sh
 
-    for l in range(1, n_hidden):
+    def folded(k):
+        """layer k with its norm folded in, as eval-mode BatchNorm folds: one GEMM + LeakyReLU per layer instead of five
+        elementwise passes over [chunk, C] (the fold moves the inputs of the next statistics by ~1e-7 relative)"""
+        sc, sh = affine(k)
+        return (W[k].double() * sc[:, None]).float(), (b[k].double() * sc + sh).float()
+
+    # One pass over the rows per hidden layer.  The pre-norm outputs of the layer whose statistics were taken last are kept
+    # for the next pass when they fit (257^3: 35 GB then 17 GB of the 288): the next layer is then one GEMM over them;
+    # otherwise (513^3) the layers below are recomputed with their norms folded in.
+    kept = None
+    for l in range(n_hidden):
         cl = W[l].shape[0]
         s1 = torch.zeros(cl, dtype=torch.float64, device=dev)
         s2 = torch.zeros(cl, dtype=torch.float64, device=dev)
+        below = [folded(k) for k in range(l)] if kept is None else None
+        if kept is not None:
+            kept_sc, kept_sh = (t.float() for t in affine(l - 1))
+        keep = torch.empty((n_pts, cl), dtype=torch.float32, device=dev) if (l + 1 < n_hidden and n_pts * cl * 4 <= keep_bytes) else None
         for i in range(0, n_pts, chunk):
             x = rows[i:i + chunk, :c0]
-            h = x
-            for k in range(l):
-                h = hidden(k, F.linear(torch.cat([h, x], 1) if is_res[k] else h, W[k], b[k]))
-            y = F.linear(torch.cat([h, x], 1) if is_res[l] else h, W[l], b[l]).double()
-            s1 += y.sum(0)
-            s2 += (y * y).sum(0)
+            if kept is not None:                       # y_{l-1} of this chunk is there: only its norm + activation remain
+                h = F.leaky_relu_(torch.addcmul(kept_sh, kept[i:i + chunk], kept_sc), 0.01)
+            else:
+                h = x
+                for k in range(l):
+                    Wf, bf = below[k]
+                    h = F.leaky_relu_(F.linear(torch.cat([h, x], 1) if is_res[k] else h, Wf, bf), 0.01)
+            y = F.linear(torch.cat([h, x], 1) if is_res[l] else h, W[l], b[l])
+            s1 += y.sum(0, dtype=torch.float64)
+            s2 += torch.linalg.vector_norm(y, dim=0, dtype=torch.float64) ** 2
+            if keep is not None:
+                keep[i:i + chunk] = y
         mu, var = _group_stats(s1 / n_pts, s2 / n_pts, spec.groups[l])
         means.append(mu)
         variances.append(var)
+        kept = keep
     return means, variances
 
 
