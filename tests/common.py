@@ -74,3 +74,58 @@ def chamfer(va, fa, vb, fb, n=20000, seed=0):
 ATTACH_NET_ATTRS = ("prior_type", "sdf_clip", "smpl_feats", "if_regressor", "smpl_feat_dict")
 ATTACH_REGRESSOR_ATTRS = ("norm", "last_op", "res_layers", "norms", "filters", "training")
 ATTACH_SMPL_KEYS = ("smpl_verts", "smpl_faces", "smpl_cmap", "smpl_vis")
+
+
+# ---------------------------------------------------------------------------------------------
+# the configurations outside configs/*.yaml that lib/net/MLP.py / HGPIFuNet.query also build: seeded constructions shared by
+# tools/make_golden.py (the reference run on them -> tests/golden/variants.npz) and the GPU tests
+# ---------------------------------------------------------------------------------------------
+def weight_norm_state_dict(sd, seed=11):
+    """norm_mlp 'weight' (lib/net/MLP.py:42-45): filters.l.weight_g / weight_v for all but the last layer, no norms.*"""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("norms."):
+            continue
+        if k.endswith(".weight") and not k.startswith("filters.3."):
+            nrm = np.sqrt((v.reshape(len(v), -1) ** 2).sum(1)).reshape(-1, 1, 1).astype(np.float32)
+            out[k + "_v"] = (v * rs.uniform(0.5, 2.0, (len(v), 1, 1))).astype(np.float32)      # any positive rescaling of v ...
+            out[k + "_g"] = (nrm * rs.uniform(0.9, 1.1, nrm.shape)).astype(np.float32)         # ... is undone by g / ||v||
+        else:
+            out[k] = v
+    return out
+
+
+def callnorm_state_dict(sd, kind, seed=2):
+    """norm_mlp 'group' (GroupNorm(32, C): affine) / 'instance' (InstanceNorm1d(C): no parameters), lib/net/MLP.py:35-41"""
+    rs = np.random.RandomState(seed)
+    out = {k: v for k, v in sd.items() if k.startswith("filters.")}
+    if kind == "group":
+        for l, c in enumerate((512, 256, 128)):
+            out[f"norms.{l}.weight"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
+            out[f"norms.{l}.bias"] = rs.normal(0, 0.1, c).astype(np.float32)
+    return out
+
+
+# name -> (feature planes used, smpl_feats, norm_mlp, last_op): what tests/golden/variants.npz holds the reference's answers for
+VARIANTS = {
+    "mvp_sdf": (6, ["sdf"], "batch", None),                            # configs/train/icon-mvp.yaml:40 (no 'vis': every plane is an input)
+    "novis_full": (6, ["sdf", "norm", "cmap"], "batch", None),
+    "vis_sdf": (12, ["sdf", "vis"], "batch", None),
+    "weight": (12, ["sdf", "norm", "vis", "cmap"], "weight", None),
+    "group": (12, ["sdf", "norm", "vis", "cmap"], "group", None),      # lib/common/config.py:80 - the config default
+    "instance": (12, ["sdf", "norm", "vis", "cmap"], "instance", None),
+    "sigmoid": (12, ["sdf", "norm", "vis", "cmap"], "batch", "sigmoid"),   # cfg.test_mode False (HGPIFuNet.py:133)
+}
+
+
+def variant_state_dict(name, a):
+    planes, feats, norm, _ = VARIANTS[name]
+    img = planes // 2 if "vis" in feats else planes
+    c0 = img + 1 + (3 if "cmap" in feats else 0) + (3 if "norm" in feats else 0)
+    sd = a.state_dict if c0 == 13 and len(feats) == 4 else synth.make_mlp_state_dict(synth.SEED + 5, dims=(c0, 512, 256, 128, 1))
+    if norm == "weight":
+        sd = weight_norm_state_dict(sd)
+    elif norm in ("group", "instance"):
+        sd = callnorm_state_dict(sd, norm)
+    return c0, sd

@@ -514,17 +514,9 @@ def test_weight_norm_regressor_vs_oracle(body, precision):
     tests/test_oracle_vs_reference.py)"""
     from icon_amd.engine import MlpHandle
     from common import rows16
-    rs = np.random.RandomState(11)
-    sd = {}
-    for k, v in body.state_dict.items():
-        if k.startswith("norms."):
-            continue
-        if k.endswith(".weight") and not k.startswith("filters.3."):
-            nrm = np.sqrt((v.reshape(len(v), -1) ** 2).sum(1)).reshape(-1, 1, 1).astype(np.float32)
-            sd[k + "_v"] = (v * rs.uniform(0.5, 2.0, (len(v), 1, 1))).astype(np.float32)       # any positive rescaling of v ...
-            sd[k + "_g"] = (nrm * rs.uniform(0.9, 1.1, nrm.shape)).astype(np.float32)          # ... is undone by g / ||v||
-        else:
-            sd[k] = v
+    from common import weight_norm_state_dict
+    rs = np.random.RandomState(12)
+    sd = weight_norm_state_dict(body.state_dict)
     omlp = orc.Mlp(sd)
     x = rs.normal(0, 1, (2000, 13)).astype(np.float32)
     h = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()})
@@ -548,13 +540,8 @@ def test_weight_norm_regressor_vs_oracle(body, precision):
 # norm_mlp 'group' / 'instance' (lib/net/MLP.py:35-41): statistics over the points of the call (icon_amd/callnorm.py)
 # ---------------------------------------------------------------------------------------------
 def _callnorm_state_dict(body, kind):
-    rs = np.random.RandomState(2)
-    sd = {k: v for k, v in body.state_dict.items() if k.startswith("filters.")}
-    if kind == "group":
-        for l, c in enumerate((512, 256, 128)):
-            sd[f"norms.{l}.weight"] = rs.uniform(0.5, 1.5, c).astype(np.float32)
-            sd[f"norms.{l}.bias"] = rs.normal(0, 0.1, c).astype(np.float32)
-    return sd
+    from common import callnorm_state_dict
+    return callnorm_state_dict(body.state_dict, kind)
 
 
 class _CallNormMLP(torch.nn.Module):
@@ -630,6 +617,31 @@ def test_rows_entry_points_vs_oracle(body):
     assert np.abs(rows33[:, :13] - X33).max() <= 2e-6
     shell = ~(np.abs(synth.lattice_points(33)) < 1.0).all(1)
     assert np.abs(rows33[shell, :13]).max() > 0.5 and ((rows33[:, 15].view(np.int32) & 8) != 0).tolist() == (~shell).tolist()
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's own answers for the configurations outside configs/*.yaml (tests/golden/variants.npz)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+@pytest.mark.parametrize("name", ["mvp_sdf", "novis_full", "vis_sdf", "weight", "group", "instance", "sigmoid"])
+def test_variants_golden_reference(body, name, precision):
+    """HIP path vs the fixture tools/make_golden.py (section i) wrote by running the reference's HGPIFuNet.query with its own MLP
+    class: smpl_feats with / without 'vis' (icon-mvp), norm_mlp 'weight' / 'group' / 'instance', last_op Sigmoid"""
+    from common import VARIANTS, variant_state_dict, golden
+    from icon_amd.engine import IconQueryEngine
+    g = golden("variants.npz")
+    planes, feats, norm, last_op = VARIANTS[name]
+    c0, sd = variant_state_dict(name, body)
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, smpl_feats=feats, precision=precision)
+    eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    eng.last_op = last_op
+    eng.norm_mlp = norm if norm in ("group", "instance") else None
+    pts = g["points"]
+    occ = eng.query([T(np.ascontiguousarray(body.features[:, :planes]))], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    want = g["occ_" + name]
+    assert np.abs(occ - want).max() <= OCC_TOL * max(1.0, float(np.abs(want).max())), name
+    assert (occ[-2:] == 0).all()
 
 
 # ---------------------------------------------------------------------------------------------

@@ -154,11 +154,44 @@ def section_h_adaptive_257():
     print("adaptive 257: queries per level", counts, "inside voxels", int((vol > 0.5).sum()))
 
 
+def section_i_variants():
+    """(i) the configurations outside configs/*.yaml that the reference's classes also build (tests/common.py VARIANTS): smpl_feats
+    subsets with and without 'vis', norm_mlp 'weight' / 'group' / 'instance', last_op Sigmoid - the reference's own
+    HGPIFuNet.query through query_func with its own MLP class, on 3000 seeded points of the synthetic subject"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from common import VARIANTS, variant_state_dict
+    ref = ref_loader.load()
+    a = synth.make_assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 3000, seed=41)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1], [1.2, 0.0, 0.0]], np.float32)])
+    out = {"points": pts}
+    saved = (netG.smpl_feats, netG.if_regressor)
+    for name, (planes, feats, norm, last_op) in VARIANTS.items():
+        c0, sd = variant_state_dict(name, a)
+        torch.manual_seed(0)
+        mlp = ref.MLP(filter_channels=[c0, 512, 256, 128, 1], name="if", res_layers=[2, 3, 4], norm=norm,
+                      last_op=torch.nn.Sigmoid() if last_op == "sigmoid" else None).eval()
+        missing, unexpected = mlp.load_state_dict({k: T(v) for k, v in sd.items()}, strict=False)
+        assert not unexpected and all("num_batches_tracked" in k for k in missing), (name, missing, unexpected)
+        try:
+            netG.smpl_feats, netG.if_regressor = feats, mlp
+            with torch.no_grad():
+                occ = ref.query_func(cfg, netG, [T(a.features[:, :planes])], T(pts)[None])[0, 0].numpy()
+        finally:
+            netG.smpl_feats, netG.if_regressor = saved
+        out["occ_" + name] = occ
+        print(f"variant {name}: c0 {c0}, occ range {occ.min():.4f} .. {occ.max():.4f}")
+    np.savez_compressed(os.path.join(OUT, "variants.npz"), **out)
+
+
 if __name__ == "__main__":
-    only = [s for s in ("--display", "--adaptive257") if s in sys.argv]
+    only = [s for s in ("--display", "--adaptive257", "--variants") if s in sys.argv]
     if not only:
         main()
     if not only or "--display" in only:
         section_g_display()
     if not only or "--adaptive257" in only:
         section_h_adaptive_257()
+    if not only or "--variants" in only:
+        section_i_variants()
