@@ -777,6 +777,19 @@ __device__ __forceinline__ f3 lattice_world(int res, int ix, int iy, int iz)
     return mk3(fx * 2.0f + (-1.0f), fy * (-2.0f) + 1.0f, fz * 2.0f + (-1.0f));
 }
 
+// NaN / Inf / astronomically large coordinates (bad caller data) are evaluated at +-kFarCoord: far outside the cube, so the
+// occupancy is 0 and the point is an "outside" entry of the call's outlier list like any other far point - instead of a
+// search that finds no triangle and then indexes with it (v_max/v_min return the finite operand for a NaN).  No-op for every
+// coordinate of magnitude <= 64: the body lives in [-1,1]^3.
+constexpr float kFarCoord = 64.0f;
+__device__ __forceinline__ f3 clamp_far(f3 r)
+{
+    r.x = fminf(fmaxf(r.x, -kFarCoord), kFarCoord);
+    r.y = fminf(fmaxf(r.y, -kFarCoord), kFarCoord);
+    r.z = fminf(fmaxf(r.z, -kFarCoord), kFarCoord);
+    return r;
+}
+
 __device__ __forceinline__ f3 project(const Calib &c, f3 p)
 {
     // orthogonal(): baddbmm(trans, rot, points), geometry.py:54-56
@@ -785,7 +798,7 @@ __device__ __forceinline__ f3 project(const Calib &c, f3 p)
     r.x = fmaf(c.m[2], p.z, fmaf(c.m[1], p.y, c.m[0] * p.x)) + c.m[3];
     r.y = fmaf(c.m[6], p.z, fmaf(c.m[5], p.y, c.m[4] * p.x)) + c.m[7];
     r.z = fmaf(c.m[10], p.z, fmaf(c.m[9], p.y, c.m[8] * p.x)) + c.m[11];
-    return r;
+    return clamp_far(r);
 }
 
 __device__ __forceinline__ Calib resolve_calib(Calib c)

@@ -310,6 +310,8 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     ICON_HIP(hipStreamSynchronize(st));
     for (int64_t i = 0; i < 3 * F; ++i)
         ICON_ARG(faces[i] >= 0 && faces[i] < V, "icon_mesh_create: face index out of range");
+    for (int64_t i = 0; i < 3 * V; ++i)     // a NaN breaks the strict weak ordering of the builder's partitions
+        ICON_ARG(std::isfinite(verts[i]) && std::fabs(verts[i]) <= 1e6f, "icon_mesh_create: non-finite (or absurdly large) vertex coordinate");
 
     const auto t1 = now();
     // S1: vertex normals = sum over incident faces (ascending face index) of (v1-v0)x(v2-v0),

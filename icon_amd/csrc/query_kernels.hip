@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     const bool live = i < N;
     if (live && perm) i = perm[i];           // Morton order (sort_points.hip): a wave's 64 points are neighbours
     const int64_t ic = live ? i : (N - 1);
-    const f3 p = mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]);
+    const f3 p = clamp_far(mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]));
     Nearest nr;
     bool ins;
     if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
     extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
-    const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const f3 p = clamp_far(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
     if ((threadIdx.x & 63) != 0) return;
     const bool ins = inside_bins(m, p);
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest_ties(MeshDev m, const float 
     const bool live = i < N;
     if (!live) i = N - 1;
     if (perm) i = perm[i];
-    const f3 p = mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]);
+    const f3 p = clamp_far(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     unsigned long long k2 = 0;
     const Nearest nr = nearest_packet<false, true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, nullptr, nullptr, INFINITY, &k2);
     if (!live) return;

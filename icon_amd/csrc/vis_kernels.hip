@@ -26,7 +26,7 @@ __device__ __forceinline__ float vmax(float a, float b) { return (a > b) ? a : b
 __device__ __forceinline__ float vmin(float a, float b) { return (b < a) ? b : a; }
 
 __global__ __launch_bounds__(64) void k_vis_raster(const float *__restrict__ xy, const float *__restrict__ z,
-                                                   const int64_t *__restrict__ faces, int64_t F, int S,
+                                                   const int64_t *__restrict__ faces, int64_t F, int64_t V, int S,
                                                    unsigned long long *__restrict__ zb)
 {
     const int64_t f = blockIdx.x;
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(64) void k_vis_raster(const float *__restrict__ xy,
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int64_t v = faces[3 * f + k];
+        if (v < 0 || v >= V) return;                                       // bad caller data: the face does not exist
         X[k] = (xy[2 * v] + 1.0f) / 2.0f; Y[k] = (xy[2 * v + 1] + 1.0f) / 2.0f; Z[k] = (-z[v] + 1.0f) / 2.0f;
     }
     const float eps = 1e-8f;
@@ -68,20 +69,23 @@ __global__ __launch_bounds__(64) void k_vis_raster(const float *__restrict__ xy,
     }
 }
 
-__global__ void k_vis_resolve(const unsigned long long *__restrict__ zb, int64_t npx, const int64_t *__restrict__ faces, int64_t F,
+__global__ void k_vis_resolve(const unsigned long long *__restrict__ zb, int64_t npx, const int64_t *__restrict__ faces, int64_t F, int64_t V,
                               float *__restrict__ vis)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && F > 0) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vis[faces[3 * (F - 1) + k]] = 1.0f;      // faces[-1]: the background index
+        for (int k = 0; k < 3; ++k) {                                        // faces[-1]: the background index
+            const int64_t v = faces[3 * (F - 1) + k];
+            if (v >= 0 && v < V) vis[v] = 1.0f;
+        }
     }
     if (i >= npx) return;
     const unsigned long long key = zb[i];
     if (key == ~0ull) return;
     const int64_t f = (int64_t)(key & 0xffffffffull);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) vis[faces[3 * f + k]] = 1.0f;
+    for (int k = 0; k < 3; ++k) vis[faces[3 * f + k]] = 1.0f;             // a face in the z-buffer passed k_vis_raster's index check
 }
 
 }  // namespace icon
@@ -102,8 +106,8 @@ extern "C" int icon_visibility(const float *d_xy, const float *d_z, int64_t V, c
     hipError_t e = hipMemsetAsync(zb, 0xff, npx * sizeof(unsigned long long), st);
     if (e == hipSuccess) e = hipMemsetAsync(d_vis, 0, (size_t)V * sizeof(float), st);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_vis_raster, dim3((unsigned)F), dim3(64), 0, st, d_xy, d_z, d_faces, F, image_size, zb);
-        hipLaunchKernelGGL(k_vis_resolve, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, zb, (int64_t)npx, d_faces, F, d_vis);
+        hipLaunchKernelGGL(k_vis_raster, dim3((unsigned)F), dim3(64), 0, st, d_xy, d_z, d_faces, F, V, image_size, zb);
+        hipLaunchKernelGGL(k_vis_resolve, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, zb, (int64_t)npx, d_faces, F, V, d_vis);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);       // the z-buffer is freed below

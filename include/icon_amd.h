@@ -56,6 +56,11 @@ enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1, ICON_PRECISION_MX6 = 2 
 /* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
 enum { ICON_SEARCH_BVH = 0, ICON_SEARCH_BRUTE = 1 };
 
+/* Bad data in device buffers never faults: query points whose (projected) coordinates are NaN / Inf / beyond +-64 are
+ * evaluated at +-64 - far outside the cube, occupancy 0 (the reference returns 0 * NaN there), an ordinary "outside" entry
+ * of the call's outlier list; faces / tetrahedra that name a vertex that does not exist are skipped (icon_visibility,
+ * icon_semantic_voxelize) or reported (icon_mesh_components, icon_mesh_create, which also refuses non-finite vertices). */
+
 typedef struct icon_mesh icon_mesh_t;   /* per-image SMPL body: triangles, normals, BVH, ray bins   */
 typedef struct icon_feat icon_feat_t;   /* per-image feature planes (and PaMIR volume), repacked    */
 typedef struct icon_mlp  icon_mlp_t;    /* if_regressor weights, BatchNorm folded, MFMA operand order */

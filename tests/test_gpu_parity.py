@@ -995,3 +995,40 @@ def test_unusual_clip_bands(clip):
     vol = eng.eval_slab(T(a.features), res, 0, res).cpu().numpy().ravel()
     ref_l, _ = oracle_query(a, synth.lattice_points(res))
     assert np.abs(vol - ref_l).max() <= OCC_TOL
+
+
+@pytest.mark.parametrize("n", [1000, 150_000])
+def test_non_finite_points_are_far_outside_not_a_fault(body, n):
+    """NaN / Inf / 1e30 coordinates (bad caller data; before round 3 a GPU memory fault: the search found no triangle and
+    indexed with it): evaluated as far outside the cube - occupancy 0 where the reference returns 0 * NaN - and, in the
+    per-point cmap mode, without touching any other point of the call; both search regimes (wave per point / Morton packets).
+    Non-finite mesh vertices are refused at mesh creation."""
+    from icon_amd.engine import IconQueryEngine, IconAmdError, MeshHandle
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], n, seed=5)
+    bad = pts.copy()
+    idx = np.arange(0, n, max(n // 50, 1))[:36]
+    vals = [np.nan, np.inf, -np.inf, 1e30, -1e30, 3e38]
+    for j, i in enumerate(idx):
+        bad[i, j % 3] = vals[j % len(vals)]
+    eye = torch.eye(4, device=dev())[None]
+    for cmap_mode in ("local", "reference"):
+        eng = make_engine(body, cmap_mode=cmap_mode)
+        clean = eng.query([T(body.features)], T(pts.T.copy())[None], eye)[0][0, 0].cpu().numpy()
+        occ = eng.query([T(body.features)], T(bad.T.copy())[None], eye)[0][0, 0].cpu().numpy()
+        torch.cuda.synchronize()
+        assert (occ[idx] == 0).all() and np.isfinite(occ).all()
+        keep = np.ones(n, bool)
+        keep[idx] = False
+        if cmap_mode == "local":
+            assert np.array_equal(occ[keep], clean[keep])
+    sdf = eng._mesh_handle().sdf_query(T(bad[idx]))
+    torch.cuda.synchronize()
+    assert np.isfinite(sdf["sdf"].cpu().numpy()).all() and (sdf["sdf"].cpu().numpy() < 0).all()
+    nan_calib = eye.clone()
+    nan_calib[0, 0, 0] = float("nan")
+    occ = eng.query([T(body.features)], T(pts.T.copy())[None], nan_calib)[0][0, 0].cpu().numpy()
+    assert (occ == 0).all()
+    v = body.smpl_verts.copy()
+    v[0, 17, 1] = np.nan
+    with pytest.raises(IconAmdError, match="non-finite"):
+        MeshHandle(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))

@@ -122,6 +122,18 @@ def test_gpu_visibility_reference_call_pattern_and_errors():
         get_visibility(xy, -z, torch.from_numpy(f + len(v)).cuda())
     with pytest.raises(IconAmdError):
         get_visibility(xy[:-1], -z, torch.from_numpy(f).cuda())
+    # the C entry point itself, with a face that names a vertex that does not exist (no Python check in the way): the face is
+    # skipped, no memory fault, every other vertex as without it
+    import ctypes as C
+    from icon_amd import _lib
+    from icon_amd.engine import _stream
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    fb = np.concatenate([f[:100], np.array([[0, 1, len(v) + 7]], np.int64), f[100:]])
+    xyc, zc, fc = xy.contiguous(), (-z).contiguous().reshape(-1), torch.from_numpy(fb).cuda()
+    vis = torch.empty(len(v), device="cuda")
+    rc = _lib.lib().icon_visibility(ptr(xyc), ptr(zc), C.c_int64(len(v)), ptr(fc), C.c_int64(len(fb)), C.c_int(4096), ptr(vis), _stream())
+    torch.cuda.synchronize()
+    assert rc == 0 and np.array_equal(vis.cpu().numpy()[:, None], orc.visibility(v[:, :2], -v[:, 2], f, 4096))
 
 
 @pytest.mark.gpu
