@@ -148,6 +148,15 @@ struct LatticeMap {
     int sz0, sz1;              // ... and planes [sz0, sz1) RELATIVE to the slab
 };
 
+// inf or NaN, as a test on the bits of an OPAQUE copy: in a translation unit compiled with -fno-honor-nans a NaN result is
+// poison to the optimiser, which may fold any test on it away - the empty asm hides where the value came from
+__device__ __forceinline__ bool not_finite(float y)
+{
+    uint32_t u = __float_as_uint(y);
+    asm volatile("" : "+v"(u));              // an opaque INTEGER: otherwise the mask-and-compare is matched back into |y| == inf
+    return (u & 0x7f800000u) == 0x7f800000u;
+}
+
 // MLP.last_op (lib/net/MLP.py:68-70; nn.Sigmoid() unless cfg.test_mode, lib/net/HGPIFuNet.py:133)
 __device__ __forceinline__ float apply_last_op(float y, int last_op)
 {
@@ -202,6 +211,8 @@ struct icon_mlp {
     size_t blob_bytes = 0;
     // offsets (in floats) into the blob
     size_t off_w0 = 0, off_b0 = 0, off_w1 = 0, off_b1 = 0, off_w2 = 0, off_w2x = 0, off_b2 = 0, off_w3 = 0;
+    size_t off_plain = 0;     // [Cout][Cin] f32 copies of the folded layers (mlp_plain_device.h) - the range safety net
+    size_t off_flag = 0;      // one int: "a split-precision kernel produced a non-finite in-cube result" (k_rescue_* recompute it)
     float b3 = 0.f;
     // 3xf16 split-precision path (mlp_f16x3.hip): chunked hi/lo operand image + f32 side arrays
     char *d_f16 = nullptr;
@@ -221,6 +232,10 @@ int morton_order(icon_work *w, const float *d_points, const float *calib12, cons
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
+// mlp_kernels.hip: after an f16x3 / mx6 launch over materialised rows - recompute the points the flag was raised for in plain f32
+int mlp_rescue_rows(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, hipStream_t st);
+int mlp_flag_reset(const icon_mlp *mlp, hipStream_t st);
+int rescue_always();
 // mlp_f16x3.hip
 int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
 int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);

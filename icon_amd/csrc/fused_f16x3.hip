@@ -37,6 +37,7 @@
 
 #include "geom_device.h"
 #include "mlp_f16x3_device.h"
+#include "mlp_plain_device.h"
 
 #include <algorithm>
 #include <mutex>
@@ -219,6 +220,49 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
     xrow[kCodeSlot] = __int_as_float((int)(code & kCodeInCube));
 }
 
+// The MLP input row of work item q of the launch (16 floats: reference channel order, zeros, slot kCodeSlot = the in_cube
+// bit): what the feature phase of k_fused_f16x3 writes into LDS - and what k_rescue_fused rebuilds for a point to redo.
+template <int PRIOR, bool LATTICE>
+__device__ __forceinline__ void build_row(const FusedGeom &G, int64_t q, float *xrow, int64_t K, int64_t rank0)
+{
+    // work item -> point: its world position p and its index i in the linear order of the call
+    f3 p;
+    int64_t i;
+    if (LATTICE) {
+        int ix, iy, iz;
+        i = lattice_item(G, q, ix, iy, iz);
+        p = lattice_world(G.res, ix, iy, iz);
+    } else {
+        i = q;
+        p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
+    }
+    if (PRIOR == ICON_PRIOR_ICON) {
+        icon_row(G, p, i, xrow, K, rank0);
+    } else {
+        gather_planes_dyn(G.f, 0, p.x, p.y, xrow);
+        const int hh = G.f.csel;
+        if (PRIOR == ICON_PRIOR_PAMIR) {
+            float v[8];
+            if (G.f.vpad == 8) gather_volume<2>(G.f, p.x, p.y, p.z, v); else gather_volume<1>(G.f, p.x, p.y, p.z, v);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) if (k < G.f.Cv) xrow[hh + k] = v[k];
+        } else {
+            xrow[hh] = p.z;
+        }
+        xrow[kCodeSlot] = __int_as_float((int)in_cube_bit(p));
+    }
+}
+
+// the sign-list geometry of the launch (reference cmap mode): K outliers in the call, rank0 = rank of this slab's first
+__device__ __forceinline__ void sign_list_extent(const FusedGeom &G, int64_t &K, int64_t &rank0)
+{
+    K = 0; rank0 = 0;
+    if (G.cmap_local) return;
+    if (G.sg.mode == kSignSelf) K = *G.sg.k_dev;
+    else if (G.sg.mode == kSignGlobal) { K = G.sg.k_host; rank0 = G.sg.rank_offset; }
+    else if (G.sg.mode == kSignSeg) { K = G.sg.seg[G.sg.world]; rank0 = G.sg.seg[G.sg.rank]; }
+}
+
 template <int PRIOR, bool LATTICE>
 __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float *__restrict__ out, MlpF16Dev w)
 {
@@ -232,11 +276,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     for (int i = threadIdx.x; i < kSideFloats; i += kF16Block) side[i] = w.side[i];
     const float *sb0 = side, *sb1 = side + 512, *sb2 = side + 768, *sw3 = side + 896;
     int64_t K = 0, rank0 = 0;
-    if (PRIOR == ICON_PRIOR_ICON && !G.cmap_local) {
-        if (G.sg.mode == kSignSelf) K = *G.sg.k_dev;
-        else if (G.sg.mode == kSignGlobal) { K = G.sg.k_host; rank0 = G.sg.rank_offset; }
-        else if (G.sg.mode == kSignSeg) { K = G.sg.seg[G.sg.world]; rank0 = G.sg.seg[G.sg.rank]; }
-    }
+    if (PRIOR == ICON_PRIOR_ICON) sign_list_extent(G, K, rank0);
     // wave-uniform 64-bit values that live across the whole MLP body: keep them in SGPRs, not in the
     // 250-register vector budget of the MFMA chain
     K = uniform64(K); rank0 = uniform64(rank0);
@@ -265,35 +305,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const bool worker = t < kTilePts;                       // wave-uniform
         int64_t q = tile * kTilePts + (worker ? t : 0);
         if (q >= G.N) q = G.N - 1;                               // padding lanes of the last tile recompute its last item
-        if (worker) {
-            // work item -> point: its world position p and its index i in the linear order of the call
-            f3 p;
-            int64_t i;
-            if (LATTICE) {
-                int ix, iy, iz;
-                i = lattice_item(G, q, ix, iy, iz);
-                p = lattice_world(G.res, ix, iy, iz);
-            } else {
-                i = q;
-                p = project(resolve_calib(G.cal), mk3(G.pts[3 * i], G.pts[3 * i + 1], G.pts[3 * i + 2]));
-            }
-            float *xrow = Xs + t * kXRow;
-            if (PRIOR == ICON_PRIOR_ICON) {
-                icon_row(G, p, i, xrow, K, rank0);
-            } else {
-                gather_planes_dyn(G.f, 0, p.x, p.y, xrow);
-                const int hh = G.f.csel;
-                if (PRIOR == ICON_PRIOR_PAMIR) {
-                    float v[8];
-                    if (G.f.vpad == 8) gather_volume<2>(G.f, p.x, p.y, p.z, v); else gather_volume<1>(G.f, p.x, p.y, p.z, v);
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) if (k < G.f.Cv) xrow[hh + k] = v[k];
-                } else {
-                    xrow[hh] = p.z;
-                }
-                xrow[kCodeSlot] = __int_as_float((int)in_cube_bit(p));
-            }
-        }
+        if (worker) build_row<PRIOR, LATTICE>(G, q, Xs + t * kXRow, K, rank0);
         __syncthreads();          // tile visible; chunk 0 (and, the first time, W0 + side arrays) landed
 
         // ---- MLP: one wave = 32 points, lane (j,h) holds input slots 8h..8h+7 of point j ------------------
@@ -353,7 +365,41 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const int64_t oq = tile * kTilePts + pt;
         if (h == 0 && oq < G.N) {
             int ix, iy, iz;
-            out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : oq] = maskf * y;
+            out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : oq] = masked_result(y, maskf != 0.0f, w.flag);
+        }
+    }
+}
+
+// The range safety net (mlp_plain_device.h): when the fused kernel raised the flag, find the work items whose result is not
+// finite, rebuild their input rows exactly as the feature phase did and redo them in plain f32.  One wave per 64 work items.
+template <int PRIOR, bool LATTICE>
+__global__ __launch_bounds__(64) void k_rescue_fused(FusedGeom G, float *__restrict__ out, MlpPlain P, const int *flag, int always)
+{
+    __shared__ float s[kPlainLds];
+    if (!always && *flag == 0) return;                        // the usual case: one word read per workgroup of a small grid
+    const int lane = threadIdx.x;
+    int64_t K = 0, rank0 = 0;
+    if (PRIOR == ICON_PRIOR_ICON) sign_list_extent(G, K, rank0);
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < G.N; base += (int64_t)gridDim.x * 64) {
+        const int64_t q = base + lane;
+        int ix, iy, iz;
+        const int64_t o = q < G.N ? (LATTICE ? lattice_item(G, q, ix, iy, iz) : q) : 0;
+        const float v = q < G.N ? out[o] : 0.0f;
+        unsigned long long todo = __ballot(not_finite(v));
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            if (lane == b) {
+                float row[kXRow];
+#pragma unroll
+                for (int k = 0; k < kXRow; ++k) row[k] = 0.0f;
+                build_row<PRIOR, LATTICE>(G, q, row, K, rank0);
+#pragma unroll
+                for (int k = 0; k < kXRow; ++k) s[k] = k < P.c0 ? row[k] : 0.0f;
+            }
+            const float y = mlp_plain_wave(P, s, lane);
+            if (lane == b) out[o] = y;       // only in-cube results are ever non-finite (masked_result): no mask to apply
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -455,10 +501,14 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
     w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
+    w.flag = reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
 
     int n_cu = 0;
-    const int rc = device_cu_count(&n_cu);
+    int rc = device_cu_count(&n_cu);
     if (rc) return rc;
+    if ((rc = mlp_flag_reset(mlp, st))) return rc;
+    const MlpPlain plain = mlp_plain_of(mlp);
+    const int64_t n_resc = std::min<int64_t>((N + 63) / 64, 2048);
     const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
 #define ICON_FUSED(P, L_, ID)                                                                                              \
@@ -467,6 +517,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
             ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),                               \
                                          hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));                          \
         hipLaunchKernelGGL((k_fused_f16x3<P, L_>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);               \
+        hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
     } while (0)
     if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }
     else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true, 2); else ICON_FUSED(ICON_PRIOR_PAMIR, false, 3); }

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
     const float other = __shfl_xor(part, 32);
     const float y = apply_last_op((part + other) + w.b3, w.last_op);
-    if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
+    if (h == 0 && base + j < N) out[base + j] = masked_result(y, MASK ? maskf != 0.0f : true, w.flag);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -224,6 +224,7 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
     w.image = mlp->d_f16;
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
+    w.flag = reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
     w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
     const int64_t nb = (N + kF16Pts - 1) / kF16Pts;
     ICON_ARG(nb < (1ll << 31), "mlp: N too large for one launch");
@@ -231,10 +232,12 @@ int mlp_launch_f16x3(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f16x3<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
         ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_f16x3<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes));
     }
+    int rc = mlp_flag_reset(mlp, st);
+    if (rc) return rc;
     if (mask) hipLaunchKernelGGL(k_mlp_f16x3<true>, dim3((unsigned)nb), dim3(kF16Block), kLdsBytes, st, d_x, N, d_out, w);
     else      hipLaunchKernelGGL(k_mlp_f16x3<false>, dim3((unsigned)nb), dim3(kF16Block), kLdsBytes, st, d_x, N, d_out, w);
     ICON_HIP(hipGetLastError());
-    return ICON_OK;
+    return mlp_rescue_rows(mlp, d_x, N, d_out, st);
 }
 
 }  // namespace icon

@@ -47,7 +47,15 @@ struct MlpF16Dev {
     float p0, q0, p1, q1, p2, q2;
     int c0;
     int last_op;                // ICON_LASTOP_*
+    int *flag;                  // raised when an in-cube result is not finite (operand beyond the f16 range): k_rescue_* redo the point in f32
 };
+
+// the in_cube mask as a SELECT (a masked point is 0 whatever the network said - 0 * NaN would not be), and the range flag
+__device__ __forceinline__ float masked_result(float y, bool in_cube, int *flag)
+{
+    if (in_cube && not_finite(y)) *flag = 1;
+    return in_cube ? y : 0.0f;
+}
 
 __device__ __forceinline__ f32x16 ld16(const float *p)
 {

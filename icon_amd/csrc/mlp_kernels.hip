@@ -23,7 +23,9 @@
 //    laid out [..][lane][4] so each wave-load is one contiguous KiB.
 //  * Layer 3 (141 -> 1) is 72 VALU fmas per lane plus one cross-half exchange.
 #include "common.h"
+#include "mlp_plain_device.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(kMlpBlock, 2) void k_mlp_f32(const float *__restric
     for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
     const float other = __shfl_xor(part, 32);
     const float y = apply_last_op((part + other) + w.b3, w.last_op);
-    if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
+    if (h == 0 && base + j < N) out[base + j] = (MASK ? maskf != 0.0f : true) ? y : 0.0f;     // select: a masked point is 0 whatever the network said
 }
 
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st)
@@ -251,6 +253,7 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
     auto take = [&](size_t n) { size_t o = off; off += (n + 3) & ~(size_t)3; return o; };
     m->off_w0 = take(kW0); m->off_b0 = take(kB0); m->off_w1 = take(kW1); m->off_b1 = take(kB1);
     m->off_w2 = take(kW2); m->off_w2x = take(kW2x); m->off_b2 = take(kB2); m->off_w3 = take(kW3);
+    m->off_plain = take(kPlainFloats); m->off_flag = take(4);
     std::vector<float> blob(off, 0.0f);
     auto rho = [](int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; };
 
@@ -307,6 +310,27 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
         }
     }
     m->b3 = B[3][0];
+    {   // plain [Cout][Cin] copies for the f32 safety net (mlp_plain_device.h): w0 [512][16] | b0 | w1 [256][512] | b1 | w2 [128][272] | b2 | w3 [144]
+        float *q = blob.data() + m->off_plain;
+        for (int o = 0; o < 512; ++o)
+            for (int k = 0; k < c0; ++k) q[o * 16 + k] = W[0][(size_t)o * c0 + k];
+        q += 512 * 16;
+        for (int o = 0; o < 512; ++o) q[o] = B[0][o];
+        q += 512;
+        for (size_t i = 0; i < (size_t)256 * 512; ++i) q[i] = W[1][i];
+        q += 256 * 512;
+        for (int o = 0; o < 256; ++o) q[o] = B[1][o];
+        q += 256;
+        for (int o = 0; o < 128; ++o) {
+            for (int k = 0; k < 256; ++k) q[o * 272 + k] = W[2][(size_t)o * ci2 + k];
+            for (int k = 0; k < c0; ++k) q[o * 272 + 256 + k] = W[2][(size_t)o * ci2 + 256 + k];
+        }
+        q += 128 * 272;
+        for (int o = 0; o < 128; ++o) q[o] = B[2][o];
+        q += 128;
+        for (int k = 0; k < 128; ++k) q[k] = W[3][k];
+        for (int k = 0; k < c0; ++k) q[128 + k] = W[3][128 + k];
+    }
     m->blob_bytes = blob.size() * sizeof(float);
     hipError_t e = hipMalloc((void **)&m->d_blob, m->blob_bytes);
     if (e != hipSuccess) { delete m; return fail(ICON_ERR_HIP, std::string("hipMalloc mlp: ") + hipGetErrorString(e)); }
@@ -320,6 +344,64 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
     *out = m;
     return ICON_OK;
 }
+
+// ---- the f32 safety net of the split-precision kernels over materialised rows (mlp_plain_device.h) ----------------
+namespace icon {
+
+MlpPlain mlp_plain_of(const icon_mlp *m)
+{
+    const float *q = m->d_blob + m->off_plain;
+    MlpPlain P;
+    P.w0 = q; q += 512 * 16; P.b0 = q; q += 512; P.w1 = q; q += 256 * 512; P.b1 = q; q += 256;
+    P.w2 = q; q += 128 * 272; P.b2 = q; q += 128; P.w3 = q;
+    P.b3 = m->b3; P.last_op = m->last_op; P.c0 = m->c0;
+    return P;
+}
+
+__global__ __launch_bounds__(64) void k_rescue_rows(const float *__restrict__ X, int64_t N, float *__restrict__ out, MlpPlain P, const int *flag, int always)
+{
+    __shared__ float s[kPlainLds];
+    if (!always && *flag == 0) return;                        // the usual case: one word read per workgroup of a small grid
+    const int lane = threadIdx.x;
+    for (int64_t base = (int64_t)blockIdx.x * 64; base < N; base += (int64_t)gridDim.x * 64) {
+        const int64_t i = base + lane;
+        const float v = i < N ? out[i] : 0.0f;
+        unsigned long long todo = __ballot(not_finite(v));
+        while (todo) {
+            const int b = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            const int64_t ib = base + b;
+            if (lane < 16) s[lane] = lane < P.c0 ? X[ib * kXRow + lane] : 0.0f;
+            const float y = mlp_plain_wave(P, s, lane);
+            if (lane == 0) out[ib] = y;
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// ICON_AMD_RESCUE_ALWAYS=1 (diagnostics): scan the results even when no kernel raised the flag
+int rescue_always()
+{
+    static const int v = (getenv("ICON_AMD_RESCUE_ALWAYS") && atoi(getenv("ICON_AMD_RESCUE_ALWAYS")) != 0) ? 1 : 0;
+    return v;
+}
+
+int mlp_flag_reset(const icon_mlp *mlp, hipStream_t st)
+{
+    ICON_HIP(hipMemsetAsync(mlp->d_blob + mlp->off_flag, 0, sizeof(int), st));
+    return ICON_OK;
+}
+
+int mlp_rescue_rows(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, hipStream_t st)
+{
+    const int64_t nb = (N + 63) / 64;
+    hipLaunchKernelGGL(k_rescue_rows, dim3((unsigned)std::min<int64_t>(nb, 2048)), dim3(64), 0, st, d_x, N, d_out, mlp_plain_of(mlp),
+                       reinterpret_cast<const int *>(mlp->d_blob + mlp->off_flag), rescue_always());
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+
+}  // namespace icon
 
 extern "C" int icon_mlp_destroy(icon_mlp_t *m)
 {

@@ -79,6 +79,7 @@ struct MlpMx6Dev {
     int c0;
     int last_op;
     unsigned long long *trace;     // debug (ICON_AMD_MX6_TRACE): s_memtime stamps of workgroup 0, second tile
+    int *flag;                     // raised when an in-cube result is not finite (operand beyond the f16 range): k_rescue_rows redoes the point in f32
 };
 
 __device__ __forceinline__ f32x16 mx_ld16(const float *p)
@@ -459,7 +460,11 @@ __global__ __launch_bounds__(kMxBlock, 2) void k_mlp_mx6(const float *__restrict
         for (int s = 0; s < 8; ++s) part = fmaf(w3[64 + s], xr[s], part);
         const float other = __shfl_xor(part, 32);
         const float y = apply_last_op((part + other) + w.b3, w.last_op);
-        if (h == 0 && base + j < N) out[base + j] = MASK ? maskf * y : y;
+        if (h == 0 && base + j < N) {
+            const bool in_cube = MASK ? maskf != 0.0f : true;          // select, not multiply: a masked point is 0 whatever the network said
+            if (in_cube && not_finite(y)) *w.flag = 1;
+            out[base + j] = in_cube ? y : 0.0f;
+        }
 
         mx_split8(xn, l0.xhi, l0.xlo);
         MX_STAMP(38)
@@ -607,6 +612,8 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
     w.image = mlp->d_mx6;
     w.side = reinterpret_cast<const float *>(mlp->d_mx6 + kMxImageBytes);
     w.b3 = mlp->b3; w.c0 = mlp->c0; w.last_op = mlp->last_op; w.trace = nullptr;
+    w.flag = reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
+    { const int rc = mlp_flag_reset(mlp, st); if (rc) return rc; }
     static const bool want_trace = getenv("ICON_AMD_MX6_TRACE") != nullptr;
     if (want_trace) { ICON_HIP(hipMalloc((void **)&w.trace, 8 * 64 * 8)); ICON_HIP(hipMemsetAsync(w.trace, 0, 8 * 64 * 8, st)); }
     const int64_t nt = (N + kMxPts - 1) / kMxPts;
@@ -636,7 +643,7 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
         }
     }
     ICON_HIP(hipGetLastError());
-    return ICON_OK;
+    return mlp_rescue_rows(mlp, d_x, N, d_out, st);
 }
 
 }  // namespace icon

@@ -46,6 +46,9 @@ enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
 /* MLP arithmetic.  F32: v_mfma_f32_32x32x2_f32, bit-for-bit an f32 fma chain.  F16X3 (the DEFAULT
  * of the host layer): every product as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16
  * with f32 accumulation (22-bit operands; ~1e-6 of the f32 result, 5x the rate) - f32-class.
+ * Its range is f16's: an input or hidden activation beyond 65504 (a thousand times anything a body mesh produces; a mesh
+ * squashed flat reaches it) would make the result NaN - the kernels flag such points and redo them in plain f32
+ * (k_rescue_*, mlp_plain_device.h), so F16X3 and MX6 return a number wherever F32 does.
  * MX6 (explicit opt-in, NOT f32-equivalent): a_hi*b_hi on the f16 MFMA and the two 2^-11 cross terms
  * on the block-scaled fp6 MFMA v_mfma_scale_f32_32x32x64_f8f6f4, i.e. ~15 significant bits per
  * product; its occupancy error scales with the hidden activations and the last layer's gain

@@ -1032,3 +1032,83 @@ def test_non_finite_points_are_far_outside_not_a_fault(body, n):
     v[0, 17, 1] = np.nan
     with pytest.raises(IconAmdError, match="non-finite"):
         MeshHandle(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+
+
+@pytest.mark.parametrize("case", ["clip0", "clip_tiny", "clip_huge", "scale3", "scale0.01", "shifted", "outside", "flat", "planes_2x2", "planes_64x96"])
+def test_extreme_inputs_vs_oracle(body, case):
+    """the corners of the input space: clip bands of 0 / 1e-6 / 100 (every point / no point an outlier), bodies three times
+    the cube, a hundredth of it, half outside it, wholly outside it, squashed flat, feature planes of 2x2 and of unequal
+    sides; 3^3 .. 33^3 lattices and 1 .. 4097 explicit points against the oracle"""
+    from icon_amd.engine import IconQueryEngine
+    rs = np.random.RandomState(0)
+    clip = {"clip0": 0.0, "clip_tiny": 1e-6, "clip_huge": 100.0}.get(case, body.sdf_clip)
+    sc, sh = {"scale3": (3.0, (0, 0, 0)), "scale0.01": (0.01, (0.3, -0.2, 0.1)), "shifted": (1.0, (0.9, 0.0, 0.0)),
+              "outside": (1.0, (3.0, 0.0, 0.0)), "flat": ((1.0, 1.0, 1e-4), (0, 0, 0))}.get(case, (1.0, (0, 0, 0)))
+    v = (body.smpl_verts * np.asarray(sc, np.float32) + np.asarray(sh, np.float32)).astype(np.float32)
+    planes = {"planes_2x2": rs.normal(0, 1, (1, 12, 2, 2)), "planes_64x96": rs.normal(0, 1, (1, 12, 64, 96))}.get(case, body.features)
+    planes = np.ascontiguousarray(planes, np.float32)
+    omlp = orc.Mlp(body.state_dict)
+    for cmap_mode in ("reference", "local"):
+        eng = IconQueryEngine(prior_type="icon", sdf_clip=clip, cmap_mode=cmap_mode)
+        eng.set_mesh(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+        eng.set_regressor({k: torch.from_numpy(x) for k, x in body.state_dict.items()})
+        args = (v[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], planes, omlp)
+        for res in (3, 5, 9, 33):
+            vol = eng.eval_slab(T(planes), res, 0, res).cpu().numpy().ravel()
+            ref, _ = orc.query_icon(*args, synth.lattice_points(res), sdf_clip=clip, cmap_local=(cmap_mode == "local"))
+            assert np.abs(vol - ref).max() <= OCC_TOL * max(1.0, np.abs(ref).max()), (case, cmap_mode, res)
+        for n in (1, 2, 63, 65, 4097):
+            pts = rs.uniform(-1.3, 1.3, (n, 3)).astype(np.float32)
+            occ = eng.query([T(planes)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+            ref, _ = orc.query_icon(*args, pts, sdf_clip=clip, cmap_local=(cmap_mode == "local"))
+            assert np.abs(occ - ref).max() <= OCC_TOL * max(1.0, np.abs(ref).max()), (case, cmap_mode, n)
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "mx6"])
+def test_operands_beyond_the_f16_range_are_redone_in_f32(body, precision):
+    """the split-precision kernels carry operands as f16 pieces: an input or activation beyond 65504 would be inf and the
+    occupancy NaN where the reference's f32 MLP returns a number.  They flag it and the flagged points are recomputed in plain
+    f32 (k_rescue_rows / k_rescue_fused): standalone MLP on rows, explicit points and lattices on a body squashed flat (its
+    sliver triangles extrapolate |norm| to 1e5), masked points exactly 0"""
+    import warnings
+    from icon_amd.engine import MlpHandle, IconQueryEngine
+    rs = np.random.RandomState(3)
+    omlp = orc.Mlp(body.state_dict)
+    x = rs.normal(0, 1, (3000, 13)).astype(np.float32)
+    big = rs.choice(3000, 40, replace=False)
+    x[big, rs.randint(0, 13, 40)] = rs.choice([-1.0, 1.0], 40) * rs.uniform(7e4, 3e6, 40)
+    h = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()})
+    rows = rows16(x)
+    rows[:, 13:15] = np.nan                                       # pad slots never reach the arithmetic, rescue included
+    got = h.forward(T(rows), precision).cpu().numpy()
+    want = omlp.forward(x, f64=True)[:, 0]
+    assert np.isfinite(got).all()
+    assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= (OCC_TOL if precision == "f16x3" else 3e-4)
+    assert np.abs(want[big]).max() > 1e3                          # the redone points are the large ones
+    v = (body.smpl_verts * np.asarray((1.0, 1.0, 1e-4), np.float32)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, precision=precision)
+        eng.set_mesh(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+        eng.set_regressor({k: torch.from_numpy(w) for k, w in body.state_dict.items()})
+        eng._mlp_handle()
+        args = (v[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp)
+        seen_big = 0
+        # the f32 arithmetic itself rounds at 2^-24 of the LARGEST operand: the bound carries a term in max |input| (5e-6 of it:
+        # just under the range limit the split's low piece no longer reaches 2^-22)
+        tol = OCC_TOL if eng._effective_precision != "mx6" else 3e-4
+        for res in (5, 9, 17):
+            vol = eng.eval_slab(T(body.features), res, 0, res).cpu().numpy().ravel()
+            ref, X = orc.query_icon(*args, synth.lattice_points(res), sdf_clip=body.sdf_clip)
+            inside = (np.abs(synth.lattice_points(res)) < 1.0).all(1)
+            seen_big += int((np.abs(X[inside]).max(1) > 65504).sum())
+            assert np.isfinite(vol).all() and (vol[~inside] == 0).all()
+            assert (np.abs(vol - ref) <= tol * np.maximum(1.0, np.abs(ref)) + 5e-6 * np.abs(X).max(1)).all(), res
+        pts = np.concatenate([synth.lattice_points(9), rs.uniform(-1.2, 1.2, (2000, 3)).astype(np.float32) * np.array([1, 1, 1e-3], np.float32)])
+        occ = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+        ref, X = orc.query_icon(*args, pts, sdf_clip=body.sdf_clip)
+        inside = (np.abs(pts) < 1.0).all(1)
+        seen_big += int((np.abs(X[inside]).max(1) > 65504).sum())
+        assert np.isfinite(occ).all() and (occ[~inside] == 0).all()
+        assert (np.abs(occ - ref) <= tol * np.maximum(1.0, np.abs(ref)) + 5e-6 * np.abs(X).max(1)).all()
+    assert seen_big > 0                                           # the case really exercises the range path
