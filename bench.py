@@ -242,7 +242,7 @@ def main():
     import torch.distributed as dist
     from icon_amd import synth, _lib
     from icon_amd.engine import IconQueryEngine, query_func
-    from icon_amd.recon import DenseReconEngine, slab_bounds
+    from icon_amd.recon import DenseReconEngine
     from types import SimpleNamespace
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

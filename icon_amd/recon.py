@@ -19,7 +19,6 @@ from __future__ import annotations
 
 import ctypes as C
 import threading
-from typing import Optional
 
 import numpy as np
 import torch
