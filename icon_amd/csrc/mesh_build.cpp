@@ -15,6 +15,8 @@
 #include <cstring>
 #include <limits>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <numeric>
 #include <thread>
 
@@ -27,18 +29,78 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 const char *last_error_cstr() { return g_err.c_str(); }
 
+// ---- host thread pool ----------------------------------------------------------------------------------
+// The per-image preparation is a handful of sub-millisecond parallel sections (BVH subtrees, slot records, ray bins,
+// operand packing); starting fifteen threads for each of them cost more than the work.  The workers are started once,
+// detached, and never torn down (a static destructor would race with them at exit).  One job at a time: a caller that
+// finds the pool busy (another host thread preparing another image) runs its section on its own thread.
+namespace {
+struct Pool {
+    std::mutex job_mu;                       // held for the duration of one run()
+    std::mutex mu;
+    std::condition_variable cv_start, cv_done;
+    const std::function<void(int)> *fn = nullptr;
+    int n = 0, active = 0, n_workers = 0;
+    uint64_t epoch = 0;
+    std::atomic<int> next{0};
+
+    explicit Pool(int workers) : n_workers(workers)
+    {
+        for (int t = 0; t < workers; ++t) std::thread([this] { worker(); }).detach();
+    }
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_start.wait(lk, [&] { return epoch != seen; });
+            seen = epoch;
+            const std::function<void(int)> *f = fn;
+            const int nn = n;
+            lk.unlock();
+            for (int i = next.fetch_add(1); i < nn; i = next.fetch_add(1)) (*f)(i);
+            lk.lock();
+            if (--active == 0) cv_done.notify_one();
+        }
+    }
+    void run(int nn, const std::function<void(int)> &f)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            fn = &f; n = nn; next.store(0); active = n_workers; ++epoch;
+        }
+        cv_start.notify_all();
+        for (int i = next.fetch_add(1); i < nn; i = next.fetch_add(1)) f(i);
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return active == 0; });      // every worker has left the loop: `f` may go out of scope
+    }
+};
+
+Pool *pool_instance()
+{
+    static Pool *p = [] {
+        const int hw = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return hw > 1 ? new Pool(hw - 1) : nullptr;          // never deleted, see above
+    }();
+    return p;
+}
+}  // namespace
+
+// ICON_AMD_BUILD_THREADS=1: everything on the calling thread (the same results - the parallel sections write disjoint data)
 void parallel_for(int n, const std::function<void(int)> &fn)
 {
     int nt = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char *e = getenv("ICON_AMD_BUILD_THREADS")) nt = std::max(atoi(e), 1);
-    nt = std::min(nt, n);
-    if (nt <= 1) { for (int i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<int> next{0};
-    auto worker = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-    std::vector<std::thread> pool;
-    for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-    worker();
-    for (std::thread &t : pool) t.join();
+    static thread_local bool in_section = false;             // a section that opens another one runs it inline
+    Pool *p = (nt > 1 && n > 1 && !in_section) ? pool_instance() : nullptr;
+    if (p && p->job_mu.try_lock()) {
+        in_section = true;
+        p->run(n, [&](int i) { in_section = true; fn(i); });
+        in_section = false;
+        p->job_mu.unlock();
+        return;
+    }
+    for (int i = 0; i < n; ++i) fn(i);
 }
 
 namespace {
@@ -157,37 +219,13 @@ struct Builder {
     }
 
     // ---- the same tree, built by several threads ---------------------------------------------------
-    // The top of the tree is split sequentially down to kParDepth; every subtree below is an independent
+    // The top of the tree is split level by level down to kParDepth; every subtree below is an independent
     // job on a disjoint range of `order` (own node / leaf vectors).  A final pass emits top nodes and
     // job results in depth-first pre-order with rebased indices, so the arrays are IDENTICAL to what
     // build() produces (same node numbering, same leaf numbering, same `order`).
     static constexpr int kParDepth = 5;
     struct Job { int begin, end, depth; Builder *sub; int32_t ref; Box box; };
     struct Plan { int mid; int left, right; bool is_job; int job; Box box; };     // index into plans
-
-    int plan(int begin, int end, int depth, std::vector<Plan> &plans, std::vector<Job> &jobs)
-    {
-        const int me = (int)plans.size();
-        plans.emplace_back();
-        if (depth >= kParDepth || end - begin <= 64) {
-            plans[me].is_job = true; plans[me].job = (int)jobs.size();
-            jobs.push_back(Job{begin, end, depth, nullptr, 0, Box()});
-            return me;
-        }
-        Box box;
-        const int mid = split(begin, end, depth, box);
-        if (mid < 0) {          // cannot happen for n > 64 >= leaf_cap, kept for safety: a leaf-sized job
-            plans[me].is_job = true; plans[me].job = (int)jobs.size();
-            jobs.push_back(Job{begin, end, depth, nullptr, 0, Box()});
-            return me;
-        }
-        max_depth = std::max(max_depth, depth);
-        plans[me].is_job = false; plans[me].mid = mid; plans[me].box = box;
-        const int l = plan(begin, mid, depth + 1, plans, jobs);
-        const int r = plan(mid, end, depth + 1, plans, jobs);
-        plans[me].left = l; plans[me].right = r;
-        return me;
-    }
 
     int32_t emit(int pi, const std::vector<Plan> &plans, std::vector<Job> &jobs, Box &box)
     {
@@ -216,25 +254,67 @@ struct Builder {
         return me;
     }
 
+    // The top of the tree level by level: the nodes of one level own disjoint ranges of `order`, so their splits run side
+    // by side (the sequential recursion spent 5 x F triangle visits here, more than the 32 subtree jobs together); the
+    // plan tree that comes out is the one a depth-first recursion builds - emit() numbers nodes by ITS walk, not by creation order.
+    int plan_levels(int F, std::vector<Plan> &plans, std::vector<Job> &jobs)
+    {
+        struct Item { int begin, end, plan; };
+        plans.emplace_back();
+        std::vector<Item> level{{0, F, 0}};
+        for (int depth = 0; !level.empty(); ++depth) {
+            std::vector<int> mids(level.size(), -1);
+            std::vector<Box> boxes(level.size());
+            std::vector<char> is_job(level.size(), 0);
+            for (size_t i = 0; i < level.size(); ++i) is_job[i] = depth >= kParDepth || level[i].end - level[i].begin <= 64;
+            parallel_for((int)level.size(), [&](int i) {
+                if (!is_job[i]) mids[i] = split(level[i].begin, level[i].end, depth, boxes[i]);
+            });
+            std::vector<Item> next;
+            for (size_t i = 0; i < level.size(); ++i) {
+                const Item it = level[i];
+                if (is_job[i] || mids[i] < 0) {          // mids < 0 cannot happen for n > 64 >= leaf_cap, kept for safety: a leaf-sized job
+                    plans[it.plan].is_job = true; plans[it.plan].job = -1;
+                    plans[it.plan].mid = it.begin; plans[it.plan].left = it.end; plans[it.plan].right = depth;     // parked until numbered below
+                    continue;
+                }
+                max_depth = std::max(max_depth, depth);
+                const int l = (int)plans.size(), r = l + 1;
+                plans.emplace_back(); plans.emplace_back();
+                plans[it.plan].is_job = false; plans[it.plan].mid = mids[i]; plans[it.plan].box = boxes[i];
+                plans[it.plan].left = l; plans[it.plan].right = r;
+                next.push_back({it.begin, mids[i], l});
+                next.push_back({mids[i], it.end, r});
+            }
+            level.swap(next);
+        }
+        // jobs numbered depth-first, left before right (the order is not visible in the output)
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+            const int pi = stack.back(); stack.pop_back();
+            Plan &p = plans[pi];
+            if (p.is_job) {
+                p.job = (int)jobs.size();
+                jobs.push_back(Job{p.mid, p.left, p.right, nullptr, 0, Box()});
+            } else {
+                stack.push_back(p.right); stack.push_back(p.left);
+            }
+        }
+        return 0;
+    }
+
     int32_t build_parallel(int F, Box &box, int n_threads)
     {
         std::vector<Plan> plans;
         std::vector<Job> jobs;
-        const int root = plan(0, F, 0, plans, jobs);
+        const int root = plan_levels(F, plans, jobs);
         std::vector<Builder> subs(jobs.size(), *this);
         for (size_t i = 0; i < jobs.size(); ++i) { subs[i].nodes.clear(); subs[i].leaves.clear(); subs[i].max_depth = 0; jobs[i].sub = &subs[i]; }
-        std::atomic<int> next{0};
-        auto worker = [&]() {
-            for (int i = next.fetch_add(1); i < (int)jobs.size(); i = next.fetch_add(1)) {
-                Job &j = jobs[i];
-                j.ref = j.sub->build(j.begin, j.end, j.depth, j.box);
-            }
-        };
-        std::vector<std::thread> pool;
-        const int nt = std::max(1, std::min(n_threads, (int)jobs.size()));
-        for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
-        worker();
-        for (std::thread &t : pool) t.join();
+        (void)n_threads;
+        parallel_for((int)jobs.size(), [&](int i) {
+            Job &j = jobs[i];
+            j.ref = j.sub->build(j.begin, j.end, j.depth, j.box);
+        });
         return emit(root, plans, jobs, box);
     }
 };
@@ -391,7 +471,9 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
     std::vector<int32_t> face2slot(std::max<int64_t>(F, 1), 0);
     std::vector<LeafRec> leafrec(n_leaves);
     std::vector<int64_t> slot_src(S, -1);          // real slots: index into bd.order; padding: -1
-    for (int64_t L = 0; L < n_leaves; ++L) {
+    const int n_rec_chunks = (int)std::min<int64_t>(64, std::max<int64_t>(n_leaves, 1));
+    parallel_for(n_rec_chunks, [&](int chunk) {
+    for (int64_t L = n_leaves * chunk / n_rec_chunks; L < n_leaves * (chunk + 1) / n_rec_chunks; ++L) {
         const int begin = bd.leaves[L].first, cnt = bd.leaves[L].second;
         for (int t = 0; t < kLeafMax; ++t) {
             const int64_t s = L * kLeafMax + t;
@@ -414,6 +496,7 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
             for (int fld = 0; fld < 24; ++fld) leafrec[L].pair[t >> 1][fld][t & 1] = src[fld];
         }
     }
+    });
 
     const auto t4 = now();
     // (y,z) ray bins: every triangle is listed in all cells its (y,z) bounding box, grown by
@@ -433,23 +516,48 @@ extern "C" int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *
         cy0 = cell_of(b.lo[1] - eps, y0, inv_y, gy); cy1 = cell_of(b.hi[1] + eps, y0, inv_y, gy);
         cz0 = cell_of(b.lo[2] - eps, z0, inv_z, gz); cz1 = cell_of(b.hi[2] + eps, z0, inv_z, gz);
     };
-    for (int64_t s = 0; s < S; ++s) {
-        if (slot_src[s] < 0) continue;
-        int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
-        for (int cz = cz0; cz <= cz1; ++cz)
-            for (int cy = cy0; cy <= cy1; ++cy) bin_start[(size_t)cz * gy + cy + 1]++;
-    }
+    // three parallel passes over the slots (count, fill, sort) around a sequential prefix sum; the atomics only decide
+    // the order INSIDE a bin, which the last pass makes ascending again - the arrays are those of a sequential fill
+    const int n_bin_chunks = (int)std::min<int64_t>(64, std::max<int64_t>(S / 256, 1));
+    parallel_for(n_bin_chunks, [&](int chunk) {
+        for (int64_t s = S * chunk / n_bin_chunks; s < S * (chunk + 1) / n_bin_chunks; ++s) {
+            if (slot_src[s] < 0) continue;
+            int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
+            for (int cz = cz0; cz <= cz1; ++cz)
+                for (int cy = cy0; cy <= cy1; ++cy) __atomic_fetch_add(&bin_start[(size_t)cz * gy + cy + 1], 1, __ATOMIC_RELAXED);
+        }
+    });
     int64_t max_bin = 0;
     for (size_t i = 1; i < bin_start.size(); ++i) { max_bin = std::max<int64_t>(max_bin, bin_start[i]); bin_start[i] += bin_start[i - 1]; }
     std::vector<int32_t> bin_slots(bin_start.back());
     {
         std::vector<int32_t> fill(bin_start.begin(), bin_start.end() - 1);
-        for (int64_t s = 0; s < S; ++s) {   // ascending slot order inside every bin
+        parallel_for(n_bin_chunks, [&](int chunk) {
+            for (int64_t s = S * chunk / n_bin_chunks; s < S * (chunk + 1) / n_bin_chunks; ++s) {
+                if (slot_src[s] < 0) continue;
+                int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
+                for (int cz = cz0; cz <= cz1; ++cz)
+                    for (int cy = cy0; cy <= cy1; ++cy)
+                        bin_slots[__atomic_fetch_add(&fill[(size_t)cz * gy + cy], 1, __ATOMIC_RELAXED)] = (int32_t)s;
+            }
+        });
+        const int64_t n_cells = (int64_t)gy * gz;
+        const int n_sort_chunks = (int)std::min<int64_t>(64, std::max<int64_t>(n_cells / 256, 1));
+        parallel_for(n_sort_chunks, [&](int chunk) {
+            for (int64_t c = n_cells * chunk / n_sort_chunks; c < n_cells * (chunk + 1) / n_sort_chunks; ++c)
+                std::sort(bin_slots.begin() + bin_start[c], bin_slots.begin() + bin_start[c + 1]);      // ascending slot order inside every bin
+        });
+    }
+
+    if (getenv("ICON_AMD_BUILD_CHECK")) {      // self-test: the parallel passes must reproduce the sequential fill exactly
+        std::vector<int32_t> fill2(bin_start.begin(), bin_start.end() - 1), slots2(bin_slots.size());
+        for (int64_t s = 0; s < S; ++s) {
             if (slot_src[s] < 0) continue;
             int cy0, cy1, cz0, cz1; range(s, cy0, cy1, cz0, cz1);
             for (int cz = cz0; cz <= cz1; ++cz)
-                for (int cy = cy0; cy <= cy1; ++cy) bin_slots[fill[(size_t)cz * gy + cy]++] = (int32_t)s;
+                for (int cy = cy0; cy <= cy1; ++cy) slots2[fill2[(size_t)cz * gy + cy]++] = (int32_t)s;
         }
+        if (slots2 != bin_slots) return fail(ICON_ERR_STATE, "icon_mesh_create: parallel ray-bin fill differs from the sequential fill");
     }
 
     const auto t5 = now();
