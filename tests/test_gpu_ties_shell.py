@@ -460,6 +460,21 @@ def test_per_axis_resolutions(body):
     assert torch.equal(fast, eng.eval_slab(T(body.features), 33, 0, 33))
 
 
+def test_explicit_points_at_scale_equal_the_lattice_path(body):
+    """(257, 257, 129): 8.5 M explicit points through query() (Morton packets, fused kernel in point mode) - every second
+    plane of the 257^3 lattice, so in the per-point cmap mode the volume must be bit for bit the lattice path's
+    (the same check passes at (513, 513, 257) = 67.6 M points, 71 ms)"""
+    from types import SimpleNamespace
+    from icon_amd.recon import DenseReconEngine
+    from icon_amd.engine import query_func
+    eng = make_engine(body, cmap_mode="local")
+    full = eng.eval_slab(T(body.features), 257, 0, 257)
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[(257, 257, 129)],
+                             align_corners=True, engine=eng).to(dev())
+    vol = recon(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    assert vol.shape == (129, 257, 257) and torch.equal(vol, full[::2])
+
+
 # ---------------------------------------------------------------------------------------------
 # last_op = Sigmoid (cfg.test_mode False, lib/net/HGPIFuNet.py:133; lib/net/MLP.py:68-70)
 # ---------------------------------------------------------------------------------------------
