@@ -1112,3 +1112,29 @@ def test_operands_beyond_the_f16_range_are_redone_in_f32(body, precision):
         assert np.isfinite(occ).all() and (occ[~inside] == 0).all()
         assert (np.abs(occ - ref) <= tol * np.maximum(1.0, np.abs(ref)) + 5e-6 * np.abs(X).max(1)).all()
     assert seen_big > 0                                           # the case really exercises the range path
+
+
+@pytest.mark.parametrize("prior", ["pamir", "pifu"])
+def test_range_rescue_for_the_volume_priors(prior):
+    """feature planes / volume features with a patch of absurd values (3e5): the rows of the points that sample it are beyond
+    the f16 range - redone in f32 by k_rescue_fused<pamir|pifu> from the rebuilt rows; explicit points and a lattice"""
+    from icon_amd.engine import IconQueryEngine
+    rs = np.random.RandomState(4)
+    C, Cv = (6, 7) if prior == "pamir" else (12, 1)
+    planes = rs.normal(0, 1, (1, C, 128, 128)).astype(np.float32)
+    planes[0, 2, 40:60, 40:60] *= 3e5
+    vol = rs.normal(0, 1, (1, Cv, 32, 32, 32)).astype(np.float32) if prior == "pamir" else None
+    if vol is not None:
+        vol[0, 3, 10:14, 10:14, 10:14] *= 2e5
+    sd = synth.make_mlp_state_dict(synth.SEED + 9, dims=(13, 512, 256, 128, 1), sdf_channel=None)
+    eng = IconQueryEngine(prior_type=prior)
+    if prior == "pamir":
+        eng.set_volume_features(T(vol))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    omlp = orc.Mlp(sd)
+    pts = rs.uniform(-1.1, 1.1, (20000, 3)).astype(np.float32)
+    occ = eng.query([T(planes)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    for got, p in ((occ, pts), (eng.eval_slab(T(planes), 33, 0, 33).cpu().numpy().ravel(), synth.lattice_points(33))):
+        ref, X = orc.query_vol(planes, vol, omlp, p)
+        assert np.isfinite(got).all() and (np.abs(X).max(1) > 65504).sum() > 100
+        assert (np.abs(got - ref) <= OCC_TOL * np.maximum(1.0, np.abs(ref)) + 5e-6 * np.abs(X).max(1)).all()
