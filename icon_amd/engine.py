@@ -275,6 +275,7 @@ class MlpHandle(_Handle):
 
 
 _WARNED_VOXELIZER = False
+_WARNED_COMPOSED = set()      # reasons the composed path was announced for
 
 # precision="mx6" is accepted only while its calibrated deviation from the f32-class path leaves 4x
 # headroom under the 1e-4 occupancy tolerance of BASELINE.json's north star
@@ -543,6 +544,36 @@ class IconQueryEngine:
             raise IconAmdError("no regressor bound: pass regressor= or call set_regressor()")
         return reg
 
+    def _composed_reason(self, reg, im_feat) -> Optional[str]:
+        """why this regressor / feature layout is outside what the fused kernels carry (icon_amd/composed.py evaluates it from
+        the HIP geometry leaf + PyTorch-ROCm operators instead), or None"""
+        from . import composed
+        if isinstance(reg, dict):
+            sd = effective_filters(reg)
+            last_ok = self.last_op in (None, "sigmoid")
+        else:
+            sd = effective_filters(reg.state_dict())
+            lo = getattr(reg, "last_op", None)
+            last_ok = lo is None or isinstance(lo, nn.Sigmoid)
+        n = 0
+        while f"filters.{n}.weight" in sd:
+            n += 1
+        if n == 0:
+            return None                                   # not an MLP state_dict: let the ordinary path say so
+        shapes = [(int(sd[f"filters.{l}.weight"].shape[0]), int(sd[f"filters.{l}.weight"].shape[1])) for l in range(n)]
+        C_ = int(im_feat.shape[-3])
+        n_img = C_ // 2 if (self.prior_type == "icon" and "vis" in self.smpl_feats) else C_
+        return composed.unsupported_reason(shapes, self.res_layers, last_ok, n_img, shapes[0][1])
+
+    def _composed_query(self, reason, features, points, calibs, reg):
+        from . import composed
+        if reason not in _WARNED_COMPOSED:
+            _WARNED_COMPOSED.add(reason)
+            import warnings
+            warnings.warn(f"icon_amd: {reason} - evaluated by the composed path (HIP geometry leaf + PyTorch-ROCm operators, "
+                          "icon_amd/composed.py), about ten times the fused kernel's time")
+        return composed.query_composed(self, features, points, calibs.to(points.device), reg)
+
     def _callnorm_spec(self, reg):
         """CallNormSpec of a Group / InstanceNorm regressor (icon_amd/callnorm.py), None for everything that folds"""
         from . import callnorm
@@ -663,6 +694,9 @@ class IconQueryEngine:
             calib12 = np.ascontiguousarray(calibs[0, :3, :4].detach().to(torch.float32).numpy())
             pts = points[0].t().to(torch.float32).contiguous()
         reg = self._bound_regressor(regressor)
+        reason = self._composed_reason(reg, features[-1]) if len(features) else None
+        if reason is not None:      # outside what the kernels carry: the reference's operator sequence around the HIP geometry leaf
+            return self._composed_query(reason, features, points, calibs, reg)
         spec = self._callnorm_spec(reg)
         if spec is not None:        # Group / InstanceNorm: the statistics of THIS call's points (icon_amd/callnorm.py)
             return [self._callnorm_eval(reg, spec, self._rows(im_feat, points=pts, calib12=calib12)).view(1, 1, n) for im_feat in features]
@@ -686,6 +720,19 @@ class IconQueryEngine:
     @_guarded
     def eval_slab(self, im_feat, res: int, z0: int, z1: int, regressor=None, out=None) -> torch.Tensor:
         reg = self._bound_regressor(regressor)
+        reason = self._composed_reason(reg, im_feat)
+        if reason is not None:      # the lattice materialised exactly as batch_eval does, one composed query over the planes [z0,z1)
+            from .recon import lattice_coords
+            dev_ = im_feat.device
+            b_min = torch.tensor([[-1.0, 1.0, -1.0]], device=dev_)
+            b_max = torch.tensor([[1.0, -1.0, 1.0]], device=dev_)
+            pts_l = lattice_coords(res, b_min, b_max, True, dev_)[:, z0 * res * res: z1 * res * res]
+            occ = self._composed_query(reason, [im_feat], pts_l.permute(0, 2, 1).contiguous(), torch.eye(4, device=dev_)[None], reg)[0]
+            occ = occ.view(z1 - z0, res, res)
+            if out is not None:
+                out.copy_(occ)
+                return out
+            return occ
         spec = self._callnorm_spec(reg)
         if spec is not None:        # Group / InstanceNorm: the planes [z0,z1) are ONE call, their points the statistics' population
             occ = self._callnorm_eval(reg, spec, self._rows(im_feat, lattice=(res, z0, z1))).view(z1 - z0, res, res)

@@ -793,3 +793,83 @@ def test_sharded_path_on_rccl_world_size_one():
         env.pop(k, None)
     p = subprocess.run([sys.executable, "-c", _NCCL_WORLD1], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert p.returncode == 0 and "NCCL-WORLD1-OK" in p.stdout, p.stdout[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------
+# regressors outside what the fused kernels carry: icon_amd/composed.py (HIP geometry leaf + PyTorch-ROCm operators)
+# ---------------------------------------------------------------------------------------------
+class _AnyMLP(torch.nn.Module):
+    """lib/net/MLP.py's attribute surface and forward for arbitrary filter_channels / res_layers / last_op, eval-mode BatchNorm"""
+
+    def __init__(self, dims, res_layers, last_op=None, seed=0):
+        super().__init__()
+        torch.manual_seed(seed)
+        self.norm, self.last_op, self.res_layers = "batch", last_op, list(res_layers)
+        self.filters = torch.nn.ModuleList([torch.nn.Conv1d(dims[l] + (dims[0] if l in res_layers else 0), dims[l + 1], 1) for l in range(len(dims) - 1)])
+        self.norms = torch.nn.ModuleList([torch.nn.BatchNorm1d(c) for c in dims[1:-1]])
+        with torch.no_grad():
+            for m in self.norms:
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+
+    def forward(self, x):
+        y = x
+        for i, f in enumerate(self.filters):
+            y = f(torch.cat([y, x], 1) if i in self.res_layers else y)
+            if i != len(self.filters) - 1:
+                y = torch.nn.functional.leaky_relu(self.norms[i](y), 0.01)
+        return self.last_op(y) if self.last_op is not None else y
+
+
+@pytest.mark.parametrize("case", ["pifu_size_mlp", "nineteen_inputs", "tanh"])
+def test_composed_path_on_the_gpu(body, case):
+    """what the fused kernels do not carry goes through icon_amd/composed.py with a warning that says why: the same code on the
+    CPU with the checker's geometry leaf (that pairing is pinned against the reference's query() in
+    tests/test_oracle_vs_reference.py) gives the same occupancies; explicit points and a lattice"""
+    import warnings
+    from types import SimpleNamespace
+    from icon_amd import composed
+    from icon_amd.engine import IconQueryEngine
+    feats, dims, last_op = ["sdf", "norm", "vis", "cmap"], [13, 512, 256, 128, 1], None
+    if case == "pifu_size_mlp":
+        dims = [13, 1024, 512, 256, 128, 1]
+    elif case == "nineteen_inputs":
+        feats, dims = ["sdf", "norm", "cmap"], [19, 512, 256, 128, 1]
+    else:
+        last_op = torch.nn.Tanh()
+    mlp = _AnyMLP(dims, [2, 3, 4], last_op, seed=3).eval()
+    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 3000, seed=52)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1], [1.2, 0.0, 0.0]], np.float32)])
+
+    def checker_leaf(p):
+        o = orc.cal_sdf(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], p.numpy())
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in o.items() if k in ("sdf", "norm", "cmap", "vis")}
+    cpu = SimpleNamespace(prior_type="icon", smpl_feats=tuple(feats), sdf_clip=body.sdf_clip, cmap_mode="reference", res_layers=(2, 3, 4),
+                          norm_mlp=None, last_op=None)
+    Tc = lambda x: torch.from_numpy(np.ascontiguousarray(x))
+    want = composed.query_composed(cpu, [Tc(body.features)], Tc(pts.T.copy())[None], torch.eye(4)[None], mlp, sdf_query=checker_leaf)[0][0, 0].numpy()
+    want33 = composed.query_composed(cpu, [Tc(body.features)], Tc(synth.lattice_points(33).T.copy())[None], torch.eye(4)[None], mlp,
+                                     sdf_query=checker_leaf)[0][0, 0].numpy()
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip, smpl_feats=feats)
+    eng.set_mesh(T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+    eng.set_regressor(mlp.to(dev()))
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        import icon_amd.engine as E
+        E._WARNED_COMPOSED.clear()
+        occ = eng.query([T(body.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+        vol = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
+    assert sum("composed path" in str(w.message) for w in rec) == 1           # announced once, with the reason
+    scale = max(1.0, float(np.abs(want).max()))
+    assert np.abs(occ - want).max() <= 2e-5 * scale and (occ[-2:] == 0).all()
+    assert np.abs(vol - want33).max() <= 2e-5 * max(1.0, float(np.abs(want33).max()))
+    if case == "tanh":
+        # more points than one chunk (129^3 = 2.15 M > 2^21; MIOpen's batch norm refuses such inputs - ATen's kernels run): in the
+        # per-point cmap mode a sample of the volume equals the same points asked for on their own
+        eng.cmap_mode, cpu.cmap_mode = "local", "local"
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            big = eng.eval_slab(T(body.features), 129, 0, 129).cpu().numpy().ravel()
+        idx = np.random.RandomState(0).choice(129 ** 3, 3000, replace=False)
+        p = synth.lattice_points(129)[idx]
+        sub = composed.query_composed(cpu, [Tc(body.features)], Tc(p.T.copy())[None], torch.eye(4)[None], mlp.cpu(), sdf_query=checker_leaf)[0][0, 0].numpy()
+        assert np.isfinite(big).all() and np.abs(big[idx] - sub).max() <= 2e-5

@@ -258,6 +258,62 @@ def test_call_normalised_regressors_against_the_reference(ref, body_net, kind):
     assert np.abs(half - want[:1500]).max() > 1e-3          # the population of the call matters
 
 
+@pytest.mark.parametrize("case", ["pifu_size_mlp", "nineteen_inputs", "tanh", "res_layers_1_3", "dict_group_5_layers"])
+def test_composed_path_against_the_reference(ref, body_net, case):
+    """icon_amd/composed.py - the operator sequence for regressors the fused kernels do not carry - against the reference's own
+    query() on the configurations that need it: a PIFu-size 5-layer MLP, 12 planes + every SMPL feature without 'vis' (19
+    inputs), last_op Tanh, other res_layers, a GroupNorm state_dict with 5 layers.  The geometry leaf is injected (the checker's
+    cal_sdf here, icon_sdf_query on the GPU); everything else is the code that runs in production."""
+    from types import SimpleNamespace
+    from icon_amd import composed
+    a = assets("body")
+    netG, cfg = body_net
+    torch.manual_seed(5)
+    feats, planes, norm, last_op, res_layers = ["sdf", "norm", "vis", "cmap"], 12, "batch", None, [2, 3, 4]
+    dims = [13, 512, 256, 128, 1]
+    if case == "pifu_size_mlp":
+        dims = [13, 1024, 512, 256, 128, 1]
+    elif case == "nineteen_inputs":
+        feats, dims = ["sdf", "norm", "cmap"], [19, 512, 256, 128, 1]
+    elif case == "tanh":
+        last_op = torch.nn.Tanh()
+    elif case == "res_layers_1_3":
+        res_layers = [1, 3]
+    elif case == "dict_group_5_layers":
+        dims, norm = [13, 64, 64, 32, 32, 1], "group"
+    mlp = ref.MLP(filter_channels=dims, name="if", res_layers=res_layers, norm=norm, last_op=last_op).eval()
+    with torch.no_grad():
+        for m in mlp.norms:
+            if hasattr(m, "running_mean"):
+                m.running_mean.normal_(0, 0.1); m.running_var.uniform_(0.5, 1.5)
+            if getattr(m, "weight", None) is not None:
+                m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.1)
+    shapes = [(int(f.weight.shape[0]), int(f.weight.shape[1])) for f in mlp.filters]
+    n_img = planes // 2 if "vis" in feats else planes
+    reason = composed.unsupported_reason(shapes, res_layers, last_op is None, n_img, dims[0])
+    assert reason is not None, case
+    pts = synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 2500, seed=51)
+    pts = np.concatenate([pts, np.array([[1.0, 0.2, 0.1], [1.2, 0.0, 0.0]], np.float32)])
+    saved = (netG.smpl_feats, netG.if_regressor)
+    try:
+        netG.smpl_feats, netG.if_regressor = feats, mlp
+        with torch.no_grad():
+            want = ref.query_func(cfg, netG, [T(a.features)], T(pts)[None])[0, 0].numpy()
+    finally:
+        netG.smpl_feats, netG.if_regressor = saved
+
+    def checker_leaf(p):
+        o = orc.cal_sdf(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], p.numpy())
+        return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in o.items() if k in ("sdf", "norm", "cmap", "vis")}
+    eng = SimpleNamespace(prior_type="icon", smpl_feats=tuple(feats), sdf_clip=a.sdf_clip, cmap_mode="reference", res_layers=tuple(res_layers),
+                          norm_mlp="group" if case == "dict_group_5_layers" else None, last_op=None)
+    reg = {k: v for k, v in mlp.state_dict().items()} if case == "dict_group_5_layers" else mlp
+    got = composed.query_composed(eng, [T(a.features)], T(pts.T.copy())[None], torch.eye(4)[None], reg, sdf_query=checker_leaf)[0][0, 0].numpy()
+    assert np.abs(got - want).max() <= 5e-6 * max(1.0, float(np.abs(want).max())), case
+    # what the kernels DO carry is not sent here
+    assert composed.unsupported_reason([(512, 13), (256, 512), (128, 269), (1, 141)], [2, 3, 4], True, 6, 13) is None
+
+
 def test_attach_reads_the_reference_network(ref):
     """IconQueryEngine.attach() on the reference's REAL HGPIFuNet (no device needed up to the first kernel launch):
     every attribute the engine reads exists with the meaning it assumes, the regressor check accepts the shipped
