@@ -130,6 +130,7 @@ def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequen
     # One pass over the rows per hidden layer.  The pre-norm outputs of the layer whose statistics were taken last are kept
     # for the next pass when they fit (257^3: 35 GB then 17 GB of the 288): the next layer is then one GEMM over them;
     # otherwise (513^3) the layers below are recomputed with their norms folded in.
+    x_all = rows[:, :c0].contiguous()              # one strided copy instead of one per chunk and pass
     kept = None
     for l in range(n_hidden):
         cl = W[l].shape[0]
@@ -140,7 +141,7 @@ def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequen
             kept_sc, kept_sh = (t.float() for t in affine(l - 1))
         keep = torch.empty((n_pts, cl), dtype=torch.float32, device=dev) if (l + 1 < n_hidden and n_pts * cl * 4 <= keep_bytes) else None
         for i in range(0, n_pts, chunk):
-            x = rows[i:i + chunk, :c0]
+            x = x_all[i:i + chunk]
             if kept is not None:                       # y_{l-1} of this chunk is there: only its norm + activation remain
                 h = F.leaky_relu_(torch.addcmul(kept_sh, kept[i:i + chunk], kept_sc), 0.01)
             else:
@@ -148,11 +149,11 @@ def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequen
                 for k in range(l):
                     Wf, bf = below[k]
                     h = F.leaky_relu_(F.linear(torch.cat([h, x], 1) if is_res[k] else h, Wf, bf), 0.01)
-            y = F.linear(torch.cat([h, x], 1) if is_res[l] else h, W[l], b[l])
+            inp = torch.cat([h, x], 1) if is_res[l] else h
+            # the GEMM writes straight into the kept buffer (a third of the path's GPU time went into copies before)
+            y = torch.addmm(b[l], inp, W[l].t(), out=keep[i:i + chunk]) if keep is not None else F.linear(inp, W[l], b[l])
             s1 += y.sum(0, dtype=torch.float64)
             s2 += torch.linalg.vector_norm(y, dim=0, dtype=torch.float64) ** 2
-            if keep is not None:
-                keep[i:i + chunk] = y
         mu, var = _group_stats(s1 / n_pts, s2 / n_pts, spec.groups[l])
         means.append(mu)
         variances.append(var)
