@@ -163,7 +163,11 @@ def query_composed(eng, features, points: torch.Tensor, calibs: torch.Tensor, re
                 point_feat = torch.cat([local, F.grid_sample(vol, g3, align_corners=True)[:, :, :, 0, 0]], 1)
             else:
                 point_feat = torch.cat([local, xyz[:, 2:3, a:b]], 1)
-            with torch.backends.cudnn.flags(enabled=False):      # MIOpen's batch norm refuses [1, C, 2 M] (miopenStatusBadParm): ATen's own kernels
+            prev = torch.backends.cudnn.enabled                  # MIOpen's batch norm refuses [1, C, 2 M] (miopenStatusBadParm): ATen's own kernels
+            torch.backends.cudnn.enabled = False
+            try:
                 out[:, :, a:b] = in_cube[:, :, a:b] * regressor(point_feat)                         # :361-363
+            finally:
+                torch.backends.cudnn.enabled = prev
         preds.append(out)
     return preds
