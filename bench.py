@@ -335,7 +335,12 @@ def main():
     images = world if args.replicas else 1
     value = images * n_points * args.steps / elapsed
     mlp_s = stage[2] * 1e-3
-    achieved = (MLP_FLOP_PER_POINT * my_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
+    # the points the MLP kernel actually multiplies: with the shell skip (fused f16x3 path, BVH search) the strict in_cube
+    # shell of the lattice is written as 0 without being evaluated - 393 k of the 16.97 M points of a 257^3 volume
+    shell_skipped = args.precision == "f16x3" and args.search == "bvh" and os.environ.get("ICON_AMD_SHELL_SKIP", "1") != "0" \
+        and os.environ.get("ICON_AMD_UNFUSED", "0") == "0"
+    exec_points = max(min(z1, res - 1) - max(z0, 1), 0) * (res - 2) ** 2 if shell_skipped else my_points
+    achieved = (MLP_FLOP_PER_POINT * exec_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
     # HBM bytes of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs,
     # tools/gpu_round.sh): quoted only while profiles/traffic.json was taken on exactly these kernel sources
     traffic, traffic_note = None, "profiles/traffic.json absent"
@@ -421,6 +426,41 @@ def main():
                                           "a sub-voxel non-zero value is expected (SURVEY.md finding 1)"}
             except Exception as ex:
                 extras["mesh"] = {"error": repr(ex)}
+        # (2b) COLD per-image figures: fresh SMPL tensors every step (what apps/infer.py does: filter() hands over new tensors
+        #      per image, lib/net/HGPIFuNet.py:236-240) - the mesh preparation (normals, BVH, records, ray bins: kernels on the
+        #      stream, icon_mesh_create_arena) is inside the timed region, unlike `value`
+        try:
+            base = [T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis)]
+
+            def cold(fn, n=6):
+                ts, host = [], []
+                for _ in range(n):
+                    fresh = [t.clone() for t in base]            # stands for filter(): new tensors, new addresses
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    eng.set_mesh(*fresh)
+                    eng._mesh_handle()
+                    host.append(time.perf_counter() - t1)
+                    fn()
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t1)
+                return float(np.median(ts[1:]) * 1e3), float(np.median(host[1:]) * 1e3)
+            dense_ms, create_host_ms = cold(step)
+            cold_cfg = {"dense": dense_ms, "mesh_create_host_ms": create_host_ms,
+                        "note": "median of 5 after one warm-up; new SMPL tensors every step, mesh built on the device inside the timed region; "
+                                "mesh_create_host_ms = host time of icon_mesh_create_arena (enqueue only, it never waits)"}
+            if res == 257:
+                cold_cfg["reference_schedule"] = cold(lambda: ad(opt=opt, netG=eng, features=feats, proj_matrix=None))[0]
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            fresh = [t.clone() for t in base]
+            eng.set_mesh(*fresh)
+            torch.cuda.synchronize()
+            ev0.record(); eng._mesh_handle(); ev1.record()
+            torch.cuda.synchronize()
+            cold_cfg["mesh_build_device_ms"] = float(ev0.elapsed_time(ev1))
+            extras["cold_image_ms"] = cold_cfg
+        except Exception as ex:
+            extras["cold_image_ms"] = {"error": repr(ex)}
         # (4) live parity sample against the checker
         try:
             extras["parity"] = parity_sample(a, res, occ, args.cmap_mode, eng=eng)
@@ -454,7 +494,8 @@ def main():
             "roofline": {"bound": "mfma", "kernel": KERNEL[args.precision], "achieved": achieved,
                          "peak": PEAK_TFLOPS[args.precision],
                          "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS[args.precision], "traffic": traffic, "traffic_note": traffic_note,
-                         "flop_per_launch": MLP_FLOP_PER_POINT * my_points, "avg_launch_ms": stage[2],
+                         "flop_per_launch": MLP_FLOP_PER_POINT * exec_points, "points_multiplied_per_launch": exec_points,
+                         "avg_launch_ms": stage[2],
                          "algorithmic_hbm_bytes_per_launch": ALGO_BYTES_PER_POINT * my_points},
         }
         if rank_stage is not None:

@@ -24,6 +24,7 @@ PRECISION = {"f32": 0, "f16x3": 1, "mx6": 2}
 SYMBOLS = [
     "icon_last_error", "icon_version", "icon_device_count",
     "icon_mesh_create", "icon_mesh_destroy", "icon_mesh_vertex_normals", "icon_mesh_stats",
+    "icon_mesh_arena_bytes", "icon_mesh_create_arena", "icon_mesh_status", "icon_debug_set_mesh_build", "icon_debug_mesh_layout", "icon_debug_host_mesh_build",
     "icon_sdf_query",
     "icon_feat_create", "icon_feat_destroy", "icon_feat_set_smpl_feats",
     "icon_mlp_create", "icon_mlp_destroy", "icon_mlp_forward", "icon_mlp_set_last_op",

@@ -28,9 +28,13 @@ int fail(int code, const std::string &msg);
 
 // ---- device data layouts (HBM) --------------------------------------------------------------
 // BVH2 node, 64 B (one cache line): both children's boxes live in the parent so one load
-// decides both.  child >= 0: internal node index; child < 0: leaf, ~child = (leaf index << 2) |
-// (triangle count - 1); the leaf's triangles are slots 4*leaf .. 4*leaf+3; an empty child has
-// lo = +inf, hi = -inf (distance = +inf).
+// decides both.  child >= 0: internal node index; child < 0: leaf, ~child = (leaf id << 2) |
+// (triangle count - 1).
+// IDs ARE POSITIONS (round 4: the tree is built on the device, where nothing can be counted first):
+// the triangles are permuted into `order` (slot2face), a node owns a contiguous range [begin, end) of
+// it and splits it at `mid`: node id = mid - 1 (every position is the split point of at most one
+// node), leaf id = begin, triangle SLOT = position in `order` - the leaf's triangles are slots
+// begin .. begin + count - 1.  All arrays have F entries; the root reference lives in MeshDyn.
 struct alignas(64) BvhNode {
     float lo[3][2], hi[3][2];   // [axis][child]: the two children's bounds interleaved (packed-f32 operands)
     int32_t child0, child1;
@@ -69,7 +73,7 @@ struct alignas(32) TriPre {
 };
 static_assert(sizeof(TriPre) == 96, "TriPre must be 96 bytes");
 
-// BVH leaf as the packet traversal reads it: two PAIRS of triangles, each pair stored
+// BVH leaf (indexed by leaf id = first slot) as the packet traversal reads it: two PAIRS of triangles, each pair stored
 // field-interleaved ([field 0..23][triangle 0..1]) so that one 8-byte scalar load yields the same
 // constant of both triangles - the operand shape of the packed-f32 VALU (v_pk_fma_f32 & co), which
 // evaluates the distance test for two triangles per instruction.  Short leaves repeat their last
@@ -93,21 +97,37 @@ constexpr uint32_t kCodeInside = 16u;          // check_sign: the point is insid
 constexpr int kScanBlock = 256;    // points per block of the outlier count / scan / compact passes == one tile of the fused kernel
 constexpr int kMaxWorld = 64;      // ranks whose sign messages one gathered buffer may hold
 
+// What the BUILD decides lives in device memory (the host never reads it back on the hot path: icon_mesh_create
+// enqueues kernels and returns); the query kernels read it through wave-uniform scalar loads.
+struct MeshDyn {
+    int32_t root;               // reference of the BVH root: node id >= 0, or a leaf code (meshes of <= kLeafMax triangles)
+    int32_t gy, gz;             // ray bins over (y, z); gy == 0: the bin lists overflowed their buffer -> brute-force parity
+    float bin_y0, bin_z0, bin_y1, bin_z1, bin_inv_y, bin_inv_z;
+    float box_lo[3], box_hi[3]; // bounding box of the vertices
+    // statistics / status (icon_mesh_stats, icon_mesh_status)
+    int32_t n_nodes, n_leaves, depth, bin_entries, max_bin;
+    int32_t status;             // kMeshBad* bits
+    int32_t pad[11];
+};
+static_assert(sizeof(MeshDyn) == 128, "MeshDyn layout");
+constexpr int kMeshBadFace = 1;       // a face names a vertex that does not exist (treated as vertex 0)
+constexpr int kMeshBadVertex = 2;     // a non-finite / absurdly large coordinate (treated as 0)
+constexpr int kMeshBinOverflow = 4;   // ray-bin lists did not fit (inside tests fall back to brute force): not an error
+constexpr int kMeshInternal = 8;      // an invariant of the device build failed (a bug: partition count mismatch, queue overflow)
+constexpr int kMeshBuilt = 0x100;     // the last kernel of the build has run (pinned host mirror only)
+
 struct MeshDev {
-    const BvhNode *nodes;
-    const TriRec *tris;
-    const TriAttr *attr;
-    const int32_t *slot2face;
-    const int32_t *face2slot;   // [faces] the (real) slot holding face f: the packet traversal tracks (d^2, face) only
-    const LeafRec *leaves;
-    int32_t n_tris;             // triangle slots = 4 * leaves (incl. padding copies)
-    int32_t root_is_leaf;
+    const BvhNode *nodes;       // [F] indexed by node id = mid - 1
+    const TriRec *tris;         // [F] by slot
+    const TriAttr *attr;        // [F] by slot
+    const int32_t *slot2face;   // [F] the permutation `order`
+    const int32_t *face2slot;   // [F] its inverse: the packet traversal tracks (d^2, face) only
+    const LeafRec *leaves;      // [F] indexed by leaf id = first slot of the leaf
+    const MeshDyn *dyn;         // device
+    int32_t n_tris;             // triangle slots = F
     // ray bins over (y, z)
     const int32_t *bin_start;   // [gy*gz + 1]
     const int32_t *bin_slots;   // triangle slots
-    float bin_y0, bin_z0, bin_y1, bin_z1, bin_inv_y, bin_inv_z;
-    int32_t gy, gz;
-    float box_lo[3], box_hi[3]; // bounding box of the vertices
 };
 
 struct FeatDev {
@@ -146,6 +166,11 @@ struct LatticeMap {
     int zs, nzi;               // planes of the MLP tiles: global [zs, zs + nzi) = slab planes minus the z shell
     int sx0, sx1, sy0, sy1;    // search region of k_nearest: lattice indices [s?0, s?1) in x and y ...
     int sz0, sz1;              // ... and planes [sz0, sz1) RELATIVE to the slab
+    // trim = 1: the region above is the WHOLE slab and the launch grid covers it; the kernel itself leaves out the far
+    // faces (lattice_trim in geom_device.h) from the body's bounding box in MeshDyn - the host does not know the box
+    // (device-built mesh, no read-back).  Workgroups beyond the trimmed tiling exit at once.
+    int trim;
+    float trim_need;           // distance from the cube's boundary beyond which a face is "far" (from sdf_clip)
 };
 
 // inf or NaN, as a test on the bits of an OPAQUE copy: in a translation unit compiled with -fno-honor-nans a NaN result is
@@ -185,17 +210,15 @@ struct FusedSigns {
 // ---- opaque handle bodies -------------------------------------------------------------------
 struct icon_mesh {
     int64_t V = 0, F = 0;
+    char *arena = nullptr;            // ONE device allocation holding every array below (mesh_layout in mesh_device.hip)
+    size_t arena_bytes = 0;
+    bool owns_arena = false;          // icon_mesh_create: hipMalloc'ed here; icon_mesh_create_arena: the caller's memory
     float *d_vnormals = nullptr;
-    icon::BvhNode *d_nodes = nullptr;
-    icon::TriRec *d_tris = nullptr;
-    icon::TriAttr *d_attr = nullptr;
-    int32_t *d_slot2face = nullptr;
-    int32_t *d_face2slot = nullptr;
-    icon::LeafRec *d_leaves = nullptr;
-    int32_t *d_bin_start = nullptr;
-    int32_t *d_bin_slots = nullptr;
+    icon::MeshDyn *d_dyn = nullptr;
+    icon::MeshDyn *h_dyn = nullptr;   // pinned host mirror, written by the last copy of the build (never waited for on the hot path)
+    hipEvent_t built = nullptr;       // recorded after that copy: icon_mesh_stats / icon_mesh_status wait on it
+    int depth_bound = 0;              // the builder never exceeds it (depth_bound(F)): sizes the traversal stacks without a read-back
     icon::MeshDev dev{};
-    int64_t stats[6] = {0, 0, 0, 0, 0, 0};
 };
 
 struct icon_feat {
@@ -224,6 +247,12 @@ struct icon_mlp {
 namespace icon {
 // host helper: fn(i) for i in [0, n) on up to 16 threads (operand packing, BVH subtrees)
 void parallel_for(int n, const std::function<void(int)> &fn);
+// mesh_device.hip: the per-image build on the device; pooled pinned mirrors of MeshDyn + events
+struct MeshLayout;
+int mesh_host_state_get(MeshDyn **h, hipEvent_t *ev);
+void mesh_host_state_put(MeshDyn *h, hipEvent_t ev);
+void mesh_bind_arena(icon_mesh *m, const MeshLayout &L);
+int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces, const float *d_cmap, const float *d_vis, hipStream_t st);
 // mc_device.hip
 struct McDevState;
 void mc_destroy(McDevState *s);
@@ -252,7 +281,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
                        const icon_work *work, const FusedSigns &fs, float *d_occ, bool lattice, hipStream_t st);
 // per-device launch facts (CU count; one-off kernel attributes): a process may drive several devices
 int device_cu_count(int *n_cu);
-bool first_use_on_device(int kernel_id);   // true exactly once per (kernel_id, current device)
+int once_per_device(int kernel_id, const std::function<hipError_t()> &set);   // runs `set` once per (kernel_id, current device), under a mutex
 // mlp_mx6.hip
 int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
 int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
@@ -314,7 +343,7 @@ inline NearRef work_near(const icon_work *w, const icon_mesh *mesh)
 {
     NearRef r;
     r.lo = w->d_near16; r.d2 = w->d_near_d2;
-    r.hi = (mesh && mesh->dev.n_tris > kNearLoSlots) ? w->d_near_hi : nullptr;
+    r.hi = (mesh && mesh->F > kNearLoSlots) ? w->d_near_hi : nullptr;
     return r;
 }
 }  // namespace icon

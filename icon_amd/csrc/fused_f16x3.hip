@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
     // outside the clip band (~94 % of a lattice): the code needs the inside test only.  Nine points in ten are
     // farther from the body's bounding box than the band is wide - they are known to be outside it without
     // reading anything; for the rest the search left a flag in the slot word
-    const bool far = box_dist2(m.box_lo[0], m.box_lo[1], m.box_lo[2], m.box_hi[0], m.box_hi[1], m.box_hi[2], p) > far_box2 || near_is_far(near, i);
+    const MeshDyn &d = *m.dyn;
+    const bool far = box_dist2(d.box_lo[0], d.box_lo[1], d.box_lo[2], d.box_hi[0], d.box_hi[1], d.box_hi[2], p) > far_box2 || near_is_far(near, i);
     code = far ? sign_code_far(p, ins) : sign_code(p, near.d2[i], ins, sdf_clip);
     code8[i] = (uint8_t)code;
     }
@@ -457,14 +458,21 @@ int device_cu_count(int *n_cu)
     return ICON_OK;
 }
 
-bool first_use_on_device(int kernel_id)
+// Runs `set` (a hipFuncSetAttribute) exactly once per (kernel_id, current device), UNDER the mutex and before the pair
+// is marked: a second host thread cannot launch the kernel with its dynamic LDS size before the attribute exists.
+int once_per_device(int kernel_id, const std::function<hipError_t()> &set)
 {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || kernel_id < 0 || kernel_id >= kMaxKernelIds) return true;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices || kernel_id < 0 || kernel_id >= kMaxKernelIds) {
+        const hipError_t e = set();
+        return e == hipSuccess ? ICON_OK : fail(ICON_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
+    }
     std::lock_guard<std::mutex> lk(g_dev_mutex);
-    const bool first = !g_attr_set[kernel_id][dev];
+    if (g_attr_set[kernel_id][dev]) return ICON_OK;
+    const hipError_t e = set();
+    if (e != hipSuccess) return fail(ICON_ERR_HIP, std::string("hipFuncSetAttribute: ") + hipGetErrorString(e));
     g_attr_set[kernel_id][dev] = true;
-    return first;
+    return ICON_OK;
 }
 
 int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_mlp *mlp, int prior, const Calib &cal,
@@ -513,9 +521,8 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
 #define ICON_FUSED(P, L_, ID)                                                                                              \
     do {                                                                                                                   \
-        if (first_use_on_device(ID))                                                                                       \
-            ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),                               \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds));                          \
+        if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),   \
+                                                                    hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds); }))) return rc; \
         hipLaunchKernelGGL((k_fused_f16x3<P, L_>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);               \
         hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
     } while (0)

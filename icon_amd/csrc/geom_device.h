@@ -12,6 +12,7 @@
 #pragma clang fp contract(off)
 
 #include "common.h"
+#include "mesh_rules.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -223,6 +224,13 @@ __device__ __forceinline__ f2 box_dist2_pair(cf2 *q, f3 p)
 
 struct Nearest { float d2; int slot; int face; };
 
+// the BVH root (a node id, or a leaf code for meshes of at most kLeafMax triangles): decided by the device build, read
+// through a wave-uniform scalar load
+__device__ __forceinline__ int mesh_root(const MeshDev &m)
+{
+    return __builtin_amdgcn_readfirstlane(*reinterpret_cast<__attribute__((address_space(4))) const int *>((uintptr_t)&m.dyn->root));
+}
+
 // Pruning bound: a subtree may be skipped only if no triangle in it can tie or beat `best`.
 // Computed distances carry < 1e-6 absolute error (coordinates are O(1)), so the bound must be at least
 // (sqrt(best) + 4e-6)^2 (1 + 1e-6); see DESIGN.md "BVH conservativeness".  Evaluated without the square
@@ -256,7 +264,7 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
     unsigned long long key2 = 0x7f8000007fffffffull;
     float thr = live ? thr0 : -INFINITY;
     int sp = 0;
-    int cur = 0;
+    int cur = mesh_root(m);
     while (true) {
         if (cur < 0) {
             const int code = ~cur;
@@ -328,7 +336,7 @@ __device__ __forceinline__ Nearest nearest_packet_alt(const MeshDev &m, f3 p, bo
     const uint32_t lim = best_bits + ulps;                 // d^2 >= 0: bit patterns order like the values
     int face = -1;
     uint32_t fbits = best_bits;
-    int sp = 0, cur = 0;                                   // the root is always node 0 (mesh_build.cpp)
+    int sp = 0, cur = mesh_root(m);
     while (true) {
         if (cur < 0) {
             const int code = ~cur;
@@ -423,7 +431,7 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, const Co
         tc.ac = mk3(q[18], q[20], q[22]); tc.bc = mk3(q[24], q[26], q[28]);
         tc.i00 = q[30]; tc.i11 = q[32]; tc.ibc = q[34]; tc.a00 = q[36]; tc.a01 = q[38]; tc.a11 = q[40]; tc.inn = q[42];
         const float d2 = tri_dist2(p, tc);
-        out_slot = leaf * kLeafMax + t;
+        out_slot = leaf + t;                                  // slots are positions: a leaf's id is its first slot
         return ((unsigned long long)(unsigned)__float_as_int(d2) << 32) | (unsigned)__float_as_int(q[44]);
     };
     // wave minimum of (key, slot) -> uniform
@@ -440,7 +448,8 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, const Co
     };
 
     // ---- 1. greedy descent ---------------------------------------------------------------------------
-    int cur = 0;
+    const int root = mesh_root(m);
+    int cur = root;
     while (cur >= 0) {
         const float4 *q4 = reinterpret_cast<const float4 *>(m.nodes + cur);
         const float4 n0 = q4[0], n1 = q4[1], n2 = q4[2];
@@ -458,8 +467,8 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, const Co
     float thr = prune_threshold(__int_as_float((int)(key >> 32)));
 
     // ---- 2. frontier -----------------------------------------------------------------------------------
-    int nf = 1, nl = 0;                           // uniform counters
-    if (lane == 0) S.frontier[0] = 0;
+    int nf = root >= 0 ? 1 : 0, nl = 0;           // uniform counters (a root that is a leaf has been tested already)
+    if (lane == 0) S.frontier[0] = root;
     __builtin_amdgcn_wave_barrier();
     while (nf > 0 || nl > 0) {
         if (nl >= 16 || nf == 0) {
@@ -512,20 +521,23 @@ __device__ __forceinline__ Nearest nearest_coop(const MeshDev &m, f3 p, const Co
     return nr;
 }
 
-// Brute force over all triangle slots, staged through LDS in tiles (validation path).
-// Reads the same TriPre constants as the packet traversal (slot s = record s&3 of leaf s>>2).
+// Brute force over all triangle slots, staged through LDS in tiles (validation path).  The S2 constants of a slot are
+// formed here from its corners by the builder's own tri_setup (mesh_rules.h): the same operations, the same bits as the
+// LeafRec the packet traversal reads.
 constexpr int kBruteTile = 128;   // 128 x 96 B = 12 KiB of LDS
 template <int BLOCK>
 __device__ __forceinline__ Nearest nearest_brute(const MeshDev &m, f3 p, float *tile /* LDS, kBruteTile*24 floats */)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
-    const float *src = reinterpret_cast<const float *>(m.leaves);
     for (int base = 0; base < m.n_tris; base += kBruteTile) {
         __syncthreads();
         const int n = min(kBruteTile, m.n_tris - base);
-        for (int k = threadIdx.x; k < n * 24; k += BLOCK) {
-            const int s = base + k / 24, fld = k % 24;        // slot s = pair (s>>1)&1, lane s&1 of leaf s>>2
-            tile[k] = src[((size_t)(s >> 2) * 2 + ((s >> 1) & 1)) * 48 + fld * 2 + (s & 1)];
+        for (int k = threadIdx.x; k < n; k += BLOCK) {
+            const TriRec &tr = m.tris[base + k];
+            TriPre pre;
+            tri_setup(tr.a, tr.b, tr.c, m.slot2face[base + k], pre);
+            const float *src = reinterpret_cast<const float *>(&pre);
+            for (int fld = 0; fld < 24; ++fld) tile[k * 24 + fld] = src[fld];
         }
         __syncthreads();
         for (int t = 0; t < n; ++t) {
@@ -544,12 +556,16 @@ __device__ __forceinline__ int bin_cell(float v, float v0, float inv, int g)
     return min(max(c, 0), g - 1);
 }
 
+__device__ __forceinline__ bool inside_brute(const MeshDev &m, f3 p);
+
 __device__ __forceinline__ bool inside_bins(const MeshDev &m, f3 p)
 {
-    if (!(p.y >= m.bin_y0 && p.y <= m.bin_y1 && p.z >= m.bin_z0 && p.z <= m.bin_z1)) return false;
-    const int cy = bin_cell(p.y, m.bin_y0, m.bin_inv_y, m.gy);
-    const int cz = bin_cell(p.z, m.bin_z0, m.bin_inv_z, m.gz);
-    const int cell = cz * m.gy + cy;
+    const MeshDyn &d = *m.dyn;
+    if (d.gy == 0) return inside_brute(m, p);      // the bin lists did not fit their buffer (kMeshBinOverflow)
+    if (!(p.y >= d.bin_y0 && p.y <= d.bin_y1 && p.z >= d.bin_z0 && p.z <= d.bin_z1)) return false;
+    const int cy = bin_cell(p.y, d.bin_y0, d.bin_inv_y, d.gy);
+    const int cz = bin_cell(p.z, d.bin_z0, d.bin_inv_z, d.gz);
+    const int cell = cz * d.gy + cy;
     const int beg = m.bin_start[cell], end = m.bin_start[cell + 1];
     int cnt = 0;
     for (int k = beg; k < end; ++k) {
@@ -566,7 +582,7 @@ __device__ __forceinline__ bool inside_brute(const MeshDev &m, f3 p)
     for (int s = 0; s < m.n_tris; ++s) {
         f3 a, b, c; int ia, ib, ic;
         load_tri_full(m.tris + s, a, b, c, ia, ib, ic);
-        if (ia >= 0) cnt += ray_hit(p, a, b, c, ia, ib, ic);     // ia < 0: padding copy of a short leaf
+        cnt += ray_hit(p, a, b, c, ia, ib, ic);
     }
     return (cnt & 1) != 0;
 }
@@ -730,10 +746,36 @@ __device__ __forceinline__ int xcd_remap(int b, int nb)
     return start + k;
 }
 
+// L.trim: the host tiled the whole slab; leave out every face of the cube that is farther from the body's bounding box
+// than the clip band is wide - those points are "outside" outliers without looking at the mesh (k_sign's own far
+// test) - and re-tile.  Wave-uniform scalar arithmetic on the box in MeshDyn.
+__device__ __forceinline__ LatticeMap lattice_trim(LatticeMap L, const MeshDev &m)
+{
+    if (!L.trim) return L;
+    const MeshDyn &d = *m.dyn;
+    const int res = L.res, z0 = L.z0, z1 = L.z0 + L.nz;
+    int lo[3] = {0, 0, 0}, hi[3] = {res, res, res};
+    const float need = L.trim_need;
+    // lattice_world: x = -1 at ix = 0, +1 at ix = res-1; y = +1 at iy = 0, -1 at iy = res-1; z like x
+    if (d.box_lo[0] + 1.0f > need) lo[0] = 1;
+    if (1.0f - d.box_hi[0] > need) hi[0] = res - 1;
+    if (1.0f - d.box_hi[1] > need) lo[1] = 1;
+    if (d.box_lo[1] + 1.0f > need) hi[1] = res - 1;
+    if (d.box_lo[2] + 1.0f > need) lo[2] = 1;
+    if (1.0f - d.box_hi[2] > need) hi[2] = res - 1;
+    L.sx0 = lo[0]; L.sx1 = hi[0]; L.sy0 = lo[1]; L.sy1 = hi[1];
+    L.sz0 = max(z0, lo[2]) - z0; L.sz1 = min(z1, hi[2]) - z0;
+    if (L.sz1 < L.sz0) L.sz1 = L.sz0;
+    L.tx = (L.sx1 - L.sx0 + 15) / 16; L.ty = (L.sy1 - L.sy0 + 3) / 4; L.tz = (L.sz1 - L.sz0 + 3) / 4;
+    L.trim = 0;
+    return L;
+}
+
 __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
 {
     const int nb = L.tx * L.ty * L.tz;
     int t = (int)blockIdx.x;
+    if (t >= nb) { ix = iy = iz = 0x3fffffff; return false; }     // a workgroup beyond the (trimmed) tiling
     if (L.remap == 1) t = xcd_remap(t, nb);
     else if (L.remap == 2) {
         // the tx workgroups of one (y,z) block row on ONE XCD (block b runs on XCD b % 8): the row's results are
@@ -787,6 +829,18 @@ __device__ __forceinline__ f3 clamp_far(f3 r)
     r.x = fminf(fmaxf(r.x, -kFarCoord), kFarCoord);
     r.y = fminf(fmaxf(r.y, -kFarCoord), kFarCoord);
     r.z = fminf(fmaxf(r.z, -kFarCoord), kFarCoord);
+    return r;
+}
+
+// The raw cal_sdf_batch leaf (icon_sdf_query) takes points in whatever units the caller's mesh is in (voxel units of
+// export_mesh, centimetres of a scan): only what cannot be searched is changed - NaN / Inf / beyond +-1e18 (where d^2
+// leaves float32) - never an ordinary far point.
+__device__ __forceinline__ f3 clamp_raw(f3 r)
+{
+    constexpr float kBig = 1e18f;
+    r.x = fminf(fmaxf(r.x, -kBig), kBig);
+    r.y = fminf(fmaxf(r.y, -kBig), kBig);
+    r.z = fminf(fmaxf(r.z, -kBig), kBig);
     return r;
 }
 

@@ -620,9 +620,12 @@ int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_ou
     ICON_ARG(nt < (1ll << 31), "mlp: N too large for one launch");
     int n_cu = 0;
     { const int rc = device_cu_count(&n_cu); if (rc) return rc; }
-    if (first_use_on_device(7)) {          // per device: a process may drive several (common.h)
-        ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
-        ICON_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds));
+    {
+        const int rc = once_per_device(7, [] {   // per device: a process may drive several (common.h)
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds);
+            return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void *>(k_mlp_mx6<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMxLds);
+        });
+        if (rc) return rc;
     }
     const unsigned nb = (unsigned)std::min<int64_t>(nt, n_cu);      // one persistent workgroup per CU (LDS-limited)
     if (mask) hipLaunchKernelGGL(k_mlp_mx6<true>, dim3(nb), dim3(kMxBlock), kMxLds, st, d_x, N, d_out, w, (int)nt);

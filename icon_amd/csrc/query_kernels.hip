@@ -33,7 +33,7 @@ __global__ __launch_bounds__(kBlock) void k_sdf_query(MeshDev m, const float *__
     const bool live = i < N;
     if (live && perm) i = perm[i];           // Morton order (sort_points.hip): a wave's 64 points are neighbours
     const int64_t ic = live ? i : (N - 1);
-    const f3 p = clamp_far(mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]));
+    const f3 p = clamp_raw(mk3(pts[3 * ic], pts[3 * ic + 1], pts[3 * ic + 2]));
     Nearest nr;
     bool ins;
     if (BRUTE) { nr = nearest_brute<kBlock>(m, p, reinterpret_cast<float *>(lds)); ins = inside_brute(m, p); }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
     extern __shared__ __attribute__((aligned(16))) char coop_smem[];
     const int64_t i = (int64_t)blockIdx.x * kCoopWaves + (threadIdx.x >> 6);
     if (i >= N) return;
-    const f3 p = clamp_far(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    const f3 p = clamp_raw(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     const Nearest nr = nearest_coop(m, p, coop_lds(coop_smem, threadIdx.x >> 6, cap));
     if ((threadIdx.x & 63) != 0) return;
     const bool ins = inside_bins(m, p);
@@ -95,6 +95,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
     if (LATTICE) {
+        L = lattice_trim(L, m);
+        if ((int)blockIdx.x >= L.tx * L.ty * L.tz) return;       // beyond the trimmed tiling (the host tiled the whole slab)
         int ix, iy, iz, cx, cy, cz;
         live = lattice_point(L, ix, iy, iz);
         lattice_clamp(L, ix, iy, iz, cx, cy, cz);
@@ -123,7 +125,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest_ties(MeshDev m, const float 
     const bool live = i < N;
     if (!live) i = N - 1;
     if (perm) i = perm[i];
-    const f3 p = clamp_far(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+    const f3 p = clamp_raw(mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     unsigned long long k2 = 0;
     const Nearest nr = nearest_packet<false, true>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, nullptr, nullptr, INFINITY, &k2);
     if (!live) return;
@@ -235,6 +237,8 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
 __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMap L, unsigned long long *out /* [4] */, int seeded)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
+    L = lattice_trim(L, m);
+    if ((int)blockIdx.x >= L.tx * L.ty * L.tz) return;
     int ix, iy, iz, cx, cy, cz;
     const bool live = lattice_point(L, ix, iy, iz);
     lattice_clamp(L, ix, iy, iz, cx, cy, cz);
@@ -274,10 +278,12 @@ __global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap 
     const int iy = (int)(row % L.res), iz = (int)(row / L.res);
     const f3 p = lattice_world(L.res, 0, iy, iz + L.z0);
     int n = 0;
-    if (p.y >= m.bin_y0 && p.y <= m.bin_y1 && p.z >= m.bin_z0 && p.z <= m.bin_z1) {
-        const int cy = bin_cell(p.y, m.bin_y0, m.bin_inv_y, m.gy);
-        const int cz = bin_cell(p.z, m.bin_z0, m.bin_inv_z, m.gz);
-        const int cell = cz * m.gy + cy;
+    const MeshDyn &d = *m.dyn;
+    if (d.gy == 0) { row_count[row] = -1; return; }          // no bin lists (kMeshBinOverflow): every point takes inside_bins' brute-force branch
+    if (p.y >= d.bin_y0 && p.y <= d.bin_y1 && p.z >= d.bin_z0 && p.z <= d.bin_z1) {
+        const int cy = bin_cell(p.y, d.bin_y0, d.bin_inv_y, d.gy);
+        const int cz = bin_cell(p.z, d.bin_z0, d.bin_inv_z, d.gz);
+        const int cell = cz * d.gy + cy;
         const int beg = m.bin_start[cell], end = m.bin_start[cell + 1];
         for (int k = beg; k < end; ++k) {
             const int slot = m.bin_slots[k];
@@ -498,7 +504,7 @@ extern "C" int icon_sdf_query(const icon_mesh_t *mesh, const float *d_points, in
         hipLaunchKernelGGL(k_sdf_query<true>, dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, d_points, N, d_sdf, d_norm,
                            d_cmap, d_vis, d_face, d_inside, nullptr);
     } else if (N < kPacketMinPoints) {    // sparse / unordered points: one wavefront per point (see nearest_coop)
-        const int cap = coop_cap((int)mesh->stats[1]);
+        const int cap = coop_cap(mesh->depth_bound);
         hipLaunchKernelGGL(k_sdf_query_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64), kCoopWaves * coop_wave_bytes(cap), st,
                            mesh->dev, d_points, N, d_sdf, d_norm, d_cmap, d_vis, d_face, d_inside, cap);
     } else {                              // large batches: packets over the Morton order (scratch freed after a stream sync)
@@ -724,7 +730,7 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
     ICON_ARG(nb >= 0 && nb < (1ll << 31), "too many workgroups for one launch");
-    if (mesh->dev.n_tris > kNearLoSlots && work->cap_points_hi < work->cap_points) {      // big meshes: the byte of higher slot bits
+    if (mesh->F > kNearLoSlots && work->cap_points_hi < work->cap_points) {      // big meshes: the byte of higher slot bits
         (void)hipFree(work->d_near_hi); work->d_near_hi = nullptr; work->cap_points_hi = 0;
         ICON_HIP(hipMalloc((void **)&work->d_near_hi, (size_t)work->cap_points));
         work->cap_points_hi = work->cap_points;
@@ -736,7 +742,7 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
     static const int mode = getenv("ICON_AMD_POINT_SEARCH") ? atoi(getenv("ICON_AMD_POINT_SEARCH")) : 0;   // 0 auto, 2 coop, 3 packets
     const bool alt = work->tie_rule != 0;        // diagnostics: the alternative tie rule lives in the packet kernel only
     if (!LATTICE && !alt && mode != 3 && (N < kPacketMinPoints || mode == 2)) {
-        const int cap = coop_cap((int)mesh->stats[1]);
+        const int cap = coop_cap(mesh->depth_bound);
         hipLaunchKernelGGL(k_nearest_coop, dim3((unsigned)((N + kCoopWaves - 1) / kCoopWaves)), dim3(kCoopWaves * 64),
                            kCoopWaves * coop_wave_bytes(cap), st, mesh->dev, cal, d_points, N, near, cap, sdf_clip);
     } else if (nb > 0) {                         // nb == 0: a slab that is all shell (nothing to search)
@@ -984,23 +990,12 @@ static int lattice_map(int res, int z0, int z1, const icon_mesh_t *mesh, float s
     L->off = off;
     L->zs = std::max(z0, off); L->nzi = std::min(z1, res - off) - L->zs;
     if (L->nzi < 0) L->nzi = 0;
-    // search region: the whole slab, minus the far faces
-    int lo[3] = {0, 0, 0}, hi[3] = {res, res, res};       // lattice index ranges in x, y, z
-    if (off && mesh) {
-        const MeshDev &m = mesh->dev;
-        const float need = std::sqrt(far_box_dist2(sdf_clip)) * 1.001f + 1e-5f;
-        // lattice_world: x = -1 at ix = 0, +1 at ix = res-1; y = +1 at iy = 0, -1 at iy = res-1; z like x
-        if (m.box_lo[0] + 1.0f > need) lo[0] = 1;
-        if (1.0f - m.box_hi[0] > need) hi[0] = res - 1;
-        if (1.0f - m.box_hi[1] > need) lo[1] = 1;
-        if (m.box_lo[1] + 1.0f > need) hi[1] = res - 1;
-        if (m.box_lo[2] + 1.0f > need) lo[2] = 1;
-        if (1.0f - m.box_hi[2] > need) hi[2] = res - 1;
-    }
-    L->sx0 = lo[0]; L->sx1 = hi[0]; L->sy0 = lo[1]; L->sy1 = hi[1];
-    L->sz0 = std::max(z0, lo[2]) - z0; L->sz1 = std::min(z1, hi[2]) - z0;
-    if (L->sz1 < L->sz0) L->sz1 = L->sz0;
+    // search region: the whole slab here - the kernel itself leaves out the far faces (lattice_trim: the body's box is
+    // known on the device only) and workgroups beyond the trimmed tiling exit at once
+    L->sx0 = 0; L->sx1 = res; L->sy0 = 0; L->sy1 = res; L->sz0 = 0; L->sz1 = z1 - z0;
     L->tx = (L->sx1 - L->sx0 + 15) / 16; L->ty = (L->sy1 - L->sy0 + 3) / 4; L->tz = (L->sz1 - L->sz0 + 3) / 4;
+    L->trim = (off && mesh) ? 1 : 0;
+    L->trim_need = std::sqrt(far_box_dist2(sdf_clip)) * 1.001f + 1e-5f;
     const char *e = getenv("ICON_AMD_XCD_REMAP");
     // 0: single blocks alternate over the XCDs (default, fastest); 2: whole x-rows of blocks per XCD - 14 % fewer HBM
     // write bytes (partial lines meet in one L2) but 1.5 % slower; 1: contiguous XCD bands, 1.6x slower
@@ -1163,7 +1158,6 @@ extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int 
     LatticeMap L;
     int rc = lattice_map(res, z0, z1, mesh, 0.05f, true, &L);
     if (rc) return rc;
-    if (L.tx * L.ty * L.tz == 0) { out[0] = out[1] = out[2] = 0; return ICON_OK; }
     unsigned long long *d = nullptr;
     ICON_HIP(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
     ICON_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));

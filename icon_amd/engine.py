@@ -71,11 +71,15 @@ class _Handle:
 
 
 class MeshHandle(_Handle):
-    """Per-image SMPL body (icon_mesh_create): the tensors of ``smpl_feat_dict``
-    (lib/net/HGPIFuNet.py:236-240), batch size 1."""
+    """Per-image SMPL body (icon_mesh_create_arena): the tensors of ``smpl_feat_dict``
+    (lib/net/HGPIFuNet.py:236-240), batch size 1.  Built by kernels on the current stream into a block of the caching
+    allocator: no copy of the mesh to the host, no allocation in the steady state, no synchronisation - as the reference's
+    own per-call prologue runs on the device (lib/dataset/mesh_util.py:367-372).  ``validate=True`` (the default for a
+    handle made by hand) waits for the build and raises on bad input as the round-3 host build did; the engine passes
+    False and polls ``status()`` on later calls instead (an error surfaces one call late, nothing ever faults)."""
     _destroy = "icon_mesh_destroy"
 
-    def __init__(self, smpl_verts, smpl_faces, smpl_cmap, smpl_vis):
+    def __init__(self, smpl_verts, smpl_faces, smpl_cmap, smpl_vis, validate: bool = True):
         super().__init__()
         _lib.require_device()
         v = _dev_f32(smpl_verts, "smpl_verts").reshape(-1, 3)
@@ -89,9 +93,28 @@ class MeshHandle(_Handle):
             raise IconAmdError("smpl_cmap / smpl_vis do not match smpl_verts")
         self.V, self.F = int(v.shape[0]), int(f.shape[0])
         self.device = v.device
+        self.checked = False
+        nbytes = C.c_int64(0)
+        check(_lib.lib().icon_mesh_arena_bytes(C.c_int64(self.V), C.c_int64(self.F), C.byref(nbytes)), "icon_mesh_arena_bytes")
         with _on(v):
-            check(_lib.lib().icon_mesh_create(ptr(v), C.c_int64(self.V), ptr(f), C.c_int64(self.F), ptr(cm), ptr(vs),
-                                              _stream(), C.byref(self.h)), "icon_mesh_create")
+            # every array of the mesh lives in this block (freed - to the allocator's cache, in stream order - with the handle)
+            self.arena = torch.empty(int(nbytes.value), dtype=torch.uint8, device=v.device)
+            check(_lib.lib().icon_mesh_create_arena(ptr(v), C.c_int64(self.V), ptr(f), C.c_int64(self.F), ptr(cm), ptr(vs),
+                                                    ptr(self.arena), nbytes, _stream(), C.byref(self.h)), "icon_mesh_create")
+        if validate:
+            self.status(wait=True)
+
+    def status(self, wait: bool = False) -> Optional[int]:
+        """Input check of the device build (icon_mesh_status): raises IconAmdError for a face naming a missing vertex or a
+        non-finite coordinate; returns the status bits, or None while the build has not run yet (``wait=False`` never blocks)."""
+        if self.checked:
+            return 0
+        bits = C.c_int(0)
+        check(_lib.lib().icon_mesh_status(self.h, C.c_int(int(wait)), C.byref(bits)), "icon_mesh_create")
+        if bits.value < 0:
+            return None
+        self.checked = True
+        return int(bits.value)
 
     def vertex_normals(self) -> torch.Tensor:
         out = torch.empty((self.V, 3), dtype=torch.float32, device=self.device)
@@ -456,8 +479,10 @@ class IconQueryEngine:
         ts = (d["smpl_verts"], d["smpl_faces"], d["smpl_cmap"], d["smpl_vis"])
         k = _key(*ts)
         if k != self._mesh_key:
-            self._mesh = MeshHandle(*ts)
+            self._mesh = MeshHandle(*ts, validate=False)
             self._mesh_key, self._mesh_src = k, ts      # strong refs: see _key
+        elif not self._mesh.checked:
+            self._mesh.status()                         # a host read of a pinned word: raises once the build has reported bad input
         return self._mesh
 
     def mesh_z_range(self):

@@ -81,15 +81,33 @@ int icon_device_count(void);
  * plus the acceleration structures our kernels need (BVH over triangles, (y,z) ray bins).
  * The reference redoes this work on every query() call; here it is once per image.
  * d_verts [V,3] f32, d_faces [F,3] i64, d_cmap [V,3] f32, d_vis [V] f32 (the [1,V,1] tensor).
- * Synchronises (copies the mesh to the host to build the BVH).
+ * Built ON THE DEVICE (round 4), as the reference's own prologue runs on the device (mesh_util.py:367-372): kernels on
+ * `stream`, no copy of the mesh to the host, no synchronisation - the handle is usable by later calls on the same
+ * stream as soon as the function returns.  icon_mesh_create allocates the mesh's device memory itself (one hipMalloc;
+ * icon_mesh_destroy frees it, which waits for the device); icon_mesh_create_arena builds into memory the CALLER owns
+ * (>= icon_mesh_arena_bytes(V, F) bytes, 256-byte aligned, alive and untouched until the last call that uses the
+ * handle has run) - with a caching allocator behind it nothing is allocated per image and nothing ever waits.
+ * What the build finds wrong with its input (a face naming a missing vertex, a non-finite coordinate) cannot be
+ * returned by a call that does not wait: such input is made harmless (vertex 0 / coordinate 0 - no fault) and
+ * reported by icon_mesh_status.
  * ------------------------------------------------------------------------------------------- */
 int icon_mesh_create(const float *d_verts, int64_t V, const int64_t *d_faces, int64_t F,
                      const float *d_cmap, const float *d_vis, void *stream, icon_mesh_t **out);
+int icon_mesh_arena_bytes(int64_t V, int64_t F, int64_t *bytes);
+int icon_mesh_create_arena(const float *d_verts, int64_t V, const int64_t *d_faces, int64_t F,
+                           const float *d_cmap, const float *d_vis, void *d_arena, int64_t arena_bytes,
+                           void *stream, icon_mesh_t **out);
 int icon_mesh_destroy(icon_mesh_t *mesh);
+/* Input check of the build.  wait != 0: blocks until the build has run; wait == 0: answers from a pinned host word
+ * the build's last copy writes - *bits = -1 while it has not run yet (returns ICON_OK), otherwise a bit set:
+ * 1 bad face index, 2 bad vertex coordinate (both: ICON_ERR_ARG, the checks the reference's tensors would fail in
+ * kaolin), 4 the ray-bin lists did not fit (not an error: inside tests count crossings over all triangles), 8 an
+ * internal check of the build failed (ICON_ERR_STATE). */
+int icon_mesh_status(const icon_mesh_t *mesh, int wait, int *bits);
 /* copy the area-weighted unit vertex normals [V,3] to a device buffer (for tests) */
 int icon_mesh_vertex_normals(const icon_mesh_t *mesh, float *d_out, void *stream);
-/* BVH statistics: out[0]=nodes, out[1]=max depth, out[2]=ray-bin entries, out[3]=max bin length,
- * out[4]=leaves, out[5]=triangle slots (4 per leaf, short leaves padded) */
+/* BVH statistics (waits for the build): out[0]=nodes, out[1]=max depth, out[2]=ray-bin entries, out[3]=max bin length,
+ * out[4]=leaves, out[5]=triangle slots (= F: a slot is a position in the BVH order) */
 int icon_mesh_stats(const icon_mesh_t *mesh, int64_t out[6]);
 
 /* ---------------------------------------------------------------------------------------------
@@ -263,6 +281,15 @@ int icon_grid_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior_t
  * forces the materialising path (rows written by a feature kernel, patched, read back by the MLP kernel) that
  * the other precisions use; both give bit-identical results (tests/test_gpu_parity.py).  Process-wide. */
 int icon_debug_set_unfused(int on);
+/* Diagnostics: host != 0 makes icon_mesh_create* build on the HOST (copy to the host, sequential builder, copy back,
+ * synchronises) - the checker of the device build: both emit the same arrays bit for bit.  Process-wide; default device
+ * (or ICON_AMD_MESH_BUILD=host in the environment).  icon_debug_mesh_layout: byte offsets of the arena sections
+ * [dyn, vnormals, nodes, leaves, tris, attr, slot2face, face2slot, bin_start, bin_slots, end of bin_slots, total]. */
+int icon_debug_set_mesh_build(int host);
+int icon_debug_mesh_layout(int64_t V, int64_t F, int64_t out[12]);
+/* the host builder on HOST buffers, no device involved: fills h_arena (zeroed by the caller) in the arena layout */
+int icon_debug_host_mesh_build(const float *h_verts, int64_t V, const int64_t *h_faces, int64_t F,
+                               const float *h_cmap, const float *h_vis, void *h_arena, int64_t arena_bytes);
 /* Diagnostics: on == 0 evaluates and masks the shell of the lattice like every other point (the reference's own
  * order of operations) instead of skipping it; both give identical results.  Process-wide; default on
  * (or ICON_AMD_SHELL_SKIP=0 in the environment). */

@@ -208,6 +208,33 @@ def test_mlp_init_net_weights(precision):
     assert np.abs(y - ref).max() <= 1e-4 * np.abs(ref).max(), np.abs(y - ref).max()   # relative: ~2.5e-6 absolute
 
 
+@pytest.mark.parametrize("layer", [0, 1])
+@pytest.mark.parametrize("g", [1e-3, 1e-4, 1e-5, 1e3])
+def test_hidden_activations_below_the_f16_normal_range(g, layer):
+    """The split-precision MLP carries the hidden activations as f16 pieces: f16's range on the LOW side too.  A checkpoint
+    whose BatchNorm gamma / beta of a hidden layer are g = 1e-3 .. 1e-5 with the next layer's weights multiplied by 1 / g is
+    the SAME function (LeakyReLU is positively homogeneous, lib/net/MLP.py:49-72) with hidden activations of 1e-5 - f16
+    subnormals, a few significant bits - in front of weights of 1e5.  The packer's per-layer activation scale
+    (mlp_f16x3.hip: activation_scale) keeps the pieces in the normal range: 1e-4 absolute against the float64 MLP, as for
+    the unscaled checkpoint.  g = 1e3: the same on the high side (activations of 1e3-1e4 stay far from 65504)."""
+    from icon_amd.engine import MlpHandle
+    sd = synth.make_mlp_state_dict(seed=synth.SEED + 7, sdf_gain=8.0, learned_std=0.5)
+    sd = {k: v.copy() for k, v in sd.items()}
+    sd[f"norms.{layer}.weight"] = (sd[f"norms.{layer}.weight"] * g).astype(np.float32)
+    sd[f"norms.{layer}.bias"] = (sd[f"norms.{layer}.bias"] * g).astype(np.float32)
+    w = sd[f"filters.{layer + 1}.weight"].copy()
+    n_hidden = 512 if layer == 0 else 256                     # layer 2 also takes the raw 13 inputs behind the 256 activations
+    w[:, :n_hidden] = (w[:, :n_hidden] / g).astype(np.float32)
+    sd[f"filters.{layer + 1}.weight"] = w
+    x = synth.representative_rows(65536, 13, seed=11)
+    ref = orc.Mlp(sd).forward(x, f64=True)[:, 0]
+    for precision in F32_CLASS:
+        y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x)), precision=precision).cpu().numpy()
+        err = np.abs(y - ref)
+        print(f"g {g} layer {layer} {precision}: max {err.max():.2e} |ref|max {np.abs(ref).max():.1f}")
+        assert err.max() <= OCC_TOL, (precision, err.max())
+
+
 def test_mx6_is_gated_per_checkpoint(body):
     """precision='mx6' is only honoured when its calibrated deviation from the f32-class path leaves 4x
     headroom under 1e-4; on a checkpoint with an unattenuated last layer the engine falls back to f16x3
@@ -455,20 +482,22 @@ def test_lattice_slab_split_equals_single_call(body):
 
 
 @pytest.mark.parametrize("mesh", ["body", "ico"])
-def test_threaded_bvh_build_equals_sequential(mesh, monkeypatch):
-    """the multi-threaded SAH builder must emit exactly the sequential builder's arrays (checked inside
-    icon_mesh_create under ICON_AMD_BUILD_CHECK) and, of course, the same query results"""
+def test_host_built_mesh_gives_the_same_answers(mesh):
+    """ICON_AMD_MESH_BUILD=host / icon_debug_set_mesh_build(1): the host builder (the checker of the device build,
+    tests/test_gpu_mesh_build.py compares their arrays byte for byte) behind the same handle - same query results"""
+    from icon_amd import _lib
     from icon_amd.engine import MeshHandle
     a = assets(mesh)
     args = (T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
     pts = T(synth.stratified_points(a.smpl_verts[0], a.smpl_faces[0], 3000, seed=3))
-    monkeypatch.setenv("ICON_AMD_BUILD_THREADS", "1")
-    seq = MeshHandle(*args)
-    monkeypatch.setenv("ICON_AMD_BUILD_THREADS", "7")
-    monkeypatch.setenv("ICON_AMD_BUILD_CHECK", "1")
-    par = MeshHandle(*args)                       # raises if the arrays differ
-    assert seq.stats() == par.stats()
-    o1, o2 = seq.sdf_query(pts), par.sdf_query(pts)
+    dev_built = MeshHandle(*args)
+    _lib.lib().icon_debug_set_mesh_build(1)
+    try:
+        host_built = MeshHandle(*args)
+    finally:
+        _lib.lib().icon_debug_set_mesh_build(0)
+    assert dev_built.stats() == host_built.stats()
+    o1, o2 = dev_built.sdf_query(pts), host_built.sdf_query(pts)
     for k in o1:
         assert torch.equal(o1[k], o2[k]), k
 

@@ -316,7 +316,89 @@ def test_hot_kernels_do_not_spill():
     assert len(icon_fused) == 2, list(fused)
     for k, v in {**icon_fused, **{k: v for k, v in mlp.items() if "k_mlp_f16x3" in k}}.items():
         assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
+    # no timing-only experiment switch (wrong results by construction) is left in the product sources: one stray -D in the
+    # compiler flags must not be able to ship a broken library (the round-3 variants live in tools/probes/exp_r03/)
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith((".h", ".hip", ".cpp")):
+            text = open(os.path.join(csrc, name)).read()
+            assert "defined(ICON_EXP_" not in text and "ifdef ICON_EXP_" not in text, name
     near = {k: v for k, v in query.items() if "k_nearestILb1ELb0" in k}
     assert len(near) == 1
     for k, v in near.items():
         assert v["ScratchSize [bytes/lane]"] == 0 and v["Occupancy [waves/SIMD]"] == 8, (k, v)
+
+
+@pytest.mark.parametrize("mesh", ["ico", "body", "dup"])
+def test_host_mesh_builder_invariants(mesh):
+    """the host builder (icon_amd/csrc/mesh_build.cpp, the checker of the device build) through icon_debug_host_mesh_build - pure
+    host code, no device: every face sits in exactly one leaf, a child's box lies inside its parent's and contains its
+    triangles, the depth stays under the bound the traversal stacks are sized for (mesh_rules.h: depth_bound), the
+    permutation and its inverse agree, the ray-bin lists are ascending and cover every triangle's cells"""
+    import ctypes as C
+    from icon_amd import _lib, synth
+    if mesh == "dup":           # 3,000 copies of one triangle + a sphere: zero centroid extents, positional splits
+        v, f0 = synth.icosphere(2, radius=0.3)
+        f = np.concatenate([np.tile(f0[:1], (3000, 1)), f0])
+        vs, cm = synth.make_vis_cmap(v, f)
+    else:
+        a = synth.make_assets(mesh)
+        v, f, cm, vs = a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0]
+    v = np.ascontiguousarray(v, np.float32); f = np.ascontiguousarray(f, np.int64)
+    cm = np.ascontiguousarray(np.asarray(cm, np.float32).reshape(-1, 3)); vs = np.ascontiguousarray(np.asarray(vs, np.float32).reshape(-1))
+    V, F = len(v), len(f)
+    L = _lib.lib()
+    lay = (C.c_int64 * 12)()
+    _lib.check(L.icon_debug_mesh_layout(C.c_int64(V), C.c_int64(F), lay))
+    lay = list(lay)
+    ar = np.zeros(lay[11], np.uint8)
+    _lib.check(L.icon_debug_host_mesh_build(_lib.ptr(v), C.c_int64(V), _lib.ptr(f), C.c_int64(F), _lib.ptr(cm), _lib.ptr(vs), _lib.ptr(ar), C.c_int64(len(ar))))
+    dyn_i, dyn_f = ar[lay[0]:lay[0] + 128].view(np.int32), ar[lay[0]:lay[0] + 128].view(np.float32)
+    root, gy, gz = int(dyn_i[0]), int(dyn_i[1]), int(dyn_i[2])
+    n_nodes, n_leaves, depth, entries = (int(x) for x in dyn_i[15:19])
+    nodes = ar[lay[2]:lay[2] + 64 * F].view(np.float32).reshape(F, 16)
+    refs = nodes.view(np.int32)[:, 12:14]
+    order = ar[lay[6]:lay[6] + 4 * F].view(np.int32)
+    inv = ar[lay[7]:lay[7] + 4 * F].view(np.int32)
+    assert sorted(order.tolist()) == list(range(F)) and np.array_equal(inv[order], np.arange(F))
+    tri = v[f]
+    tlo, thi = tri.min(1), tri.max(1)
+    seen = np.zeros(F, bool)
+    stack, maxd, nn, nl = [(root, 0, None)], 0, 0, 0
+    while stack:
+        ref, d, box = stack.pop()
+        maxd = max(maxd, d)
+        if ref < 0:
+            code = ~ref
+            b, cnt = code >> 2, (code & 3) + 1
+            assert not seen[b:b + cnt].any()
+            seen[b:b + cnt] = True
+            nl += 1
+            if box is not None:
+                fs = order[b:b + cnt]
+                assert (tlo[fs] >= box[0]).all() and (thi[fs] <= box[1]).all()
+        else:
+            nn += 1
+            lo, hi = nodes[ref, 0:6].reshape(3, 2), nodes[ref, 6:12].reshape(3, 2)
+            for s in (0, 1):
+                cb = (lo[:, s], hi[:, s])
+                if box is not None:
+                    assert (cb[0] >= box[0]).all() and (cb[1] <= box[1]).all()
+                stack.append((int(refs[ref, s]), d + 1, cb))
+    assert seen.all() and (nn, nl, maxd) == (n_nodes, n_leaves, depth)
+    bound = min(48 - 2, int(np.ceil(np.log2(max(F, 2)))) + 10)
+    assert depth <= bound
+    if gy:                       # ray bins: ascending lists; every triangle listed in the cells its (y,z) box covers
+        start = ar[lay[8]:lay[8] + 4 * (gy * gz + 1)].view(np.int32)
+        slots = ar[lay[9]:lay[9] + 4 * entries].view(np.int32)
+        assert start[0] == 0 and start[-1] == entries and (np.diff(start) >= 0).all()
+        for c in np.random.RandomState(0).randint(0, gy * gz, 300):
+            lst = slots[start[c]:start[c + 1]]
+            assert (np.diff(lst) > 0).all()
+        y0, z0, y1, z1, iy, iz = (float(x) for x in dyn_f[3:9])
+        rs = np.random.RandomState(1)
+        for p in rs.randint(0, F, 200):
+            fc = order[p]
+            cy = int(np.clip(np.floor((np.float32(0.5) * (tlo[fc, 1] + thi[fc, 1]) - np.float32(y0)) * np.float32(iy)), 0, gy - 1))
+            cz = int(np.clip(np.floor((np.float32(0.5) * (tlo[fc, 2] + thi[fc, 2]) - np.float32(z0)) * np.float32(iz)), 0, gz - 1))
+            c = cz * gy + cy
+            assert p in slots[start[c]:start[c + 1]]

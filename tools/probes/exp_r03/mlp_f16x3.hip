@@ -33,6 +33,9 @@ __global__ __launch_bounds__(kF16Block, 2) void k_mlp_f16x3(const float *__restr
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 31, h = lane >> 5;
+#if defined(ICON_EXP_PRIO)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);      // the second-dispatched half loses the issue arbitration otherwise
+#endif
     const int64_t base = ((int64_t)blockIdx.x * (kF16Block / 64) + wave) * 32;
     const int64_t pi = min(base + j, N - 1);      // waves past the end still help with the DMA + barriers
 
@@ -145,33 +148,7 @@ float pick_scale(const std::vector<float> &W)
     for (float v : W) mx = std::max(mx, std::fabs(v));
     if (!(mx > 0.f) || !std::isfinite(mx)) return 1.0f;
     int e = (int)std::floor(std::log2(8192.0 / (double)mx));
-    e = std::min(std::max(e, -60), 60);
-    return std::ldexp(1.0f, e);
-}
-
-// Activation scale of a hidden layer (a power of two): the hidden activations are SPLIT into f16 pieces for the next
-// GEMM, so the path has f16's range there - beyond 65504 the point is redone in f32 (k_rescue_*), but BELOW 2^-14 the
-// pieces are f16 subnormals and lose their bits silently: a checkpoint whose BatchNorm gamma is 1e-4 with a next layer
-// that compensates (the same function!) would come out with a few significant bits.  LeakyReLU is positively
-// homogeneous, so a layer's activations may carry any factor A > 0 as long as the next layer's weights carry 1 / A:
-// A is chosen from the weights alone so that the TYPICAL activation (RMS over the channels of the RMS pre-activation
-// for inputs of the given mean squares) becomes 16 - 12 binades below the overflow point, 7 above the point where the
-// lo piece starts to lose bits.  Exact (powers of two): for activations that were in range all along the results do
-// not change by a bit.  out_ms[c] = mean square of channel c's pre-activation under that model.
-float activation_scale(const std::vector<float> &W, const std::vector<float> &B, int cout, int cin, int n_used, const std::vector<double> &in_ms,
-                       std::vector<double> &out_ms)
-{
-    out_ms.assign(cout, 0.0);
-    double acc = 0.0;
-    for (int c = 0; c < cout; ++c) {
-        double s = (double)B[c] * B[c];
-        for (int k = 0; k < n_used; ++k) s += (double)W[(size_t)c * cin + k] * W[(size_t)c * cin + k] * in_ms[k];
-        out_ms[c] = s; acc += s;
-    }
-    const double typical = std::sqrt(acc / std::max(cout, 1));
-    if (!(typical > 0.0) || !std::isfinite(typical)) return 1.0f;
-    int e = (int)std::lround(std::log2(16.0 / typical));
-    e = std::min(std::max(e, -60), 60);
+    e = std::min(std::max(e, -12), 24);
     return std::ldexp(1.0f, e);
 }
 
@@ -180,18 +157,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
                    hipStream_t st)
 {
     const int c0 = m->c0;
-    // activation scales A0, A1 of the two hidden layers whose outputs are split (layer 2's go to the f32 VALU layer as they
-    // are); inputs of layer 0 taken as unit mean square.  The next layer's weights carry 1 / A (exact).
-    std::vector<double> ms_in(c0, 1.0), ms0, ms1;
-    const float A0 = activation_scale(W[0], B[0], 512, c0, c0, ms_in, ms0);
-    std::vector<float> W1(W[1]);
-    for (float &v : W1) v /= A0;
-    const float A1 = activation_scale(W[1], B[1], 256, 512, 512, ms0, ms1);
-    const int ci2_ = 256 + c0;
-    std::vector<float> W2(W[2]);
-    for (int c = 0; c < 128; ++c)
-        for (int k = 0; k < 256; ++k) W2[(size_t)c * ci2_ + k] /= A1;           // the raw-input columns [256, 256 + c0) are not activations
-    const float s0 = pick_scale(W[0]), s1 = pick_scale(W1), s2 = pick_scale(W2);
+    const float s0 = pick_scale(W[0]), s1 = pick_scale(W[1]), s2 = pick_scale(W[2]);
     std::vector<uint16_t> img(kImageBytes / 2, 0);
     auto rho = [](int t, int h) { return (t & 3) + 8 * (t >> 2) + 4 * h; };
     // one 1-KiB slot = [lane 64][8 halves]; write hi into `slot`, lo into `slot + 1`
@@ -213,7 +179,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
                 put(-1, 2 * c, lane, e, slot0 < c0 ? W[0][(size_t)(32 * c + i) * c0 + slot0] : 0.f, s0);
                 for (int u = 0; u < 2; ++u)
                     for (int mm = 0; mm < 8; ++mm)
-                        put(c, (u * 8 + mm) * 2, lane, e, W1[(size_t)(32 * mm + i) * 512 + 32 * c + rho(8 * u + e, g)], s1);
+                        put(c, (u * 8 + mm) * 2, lane, e, W[1][(size_t)(32 * mm + i) * 512 + 32 * c + rho(8 * u + e, g)], s1);
             }
             // layer 2, chunk 16+q covers hidden tiles 2q, 2q+1
             for (int q = 0; q < 4; ++q)
@@ -221,10 +187,10 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
                     for (int u = 0; u < 2; ++u)
                         for (int m2 = 0; m2 < 4; ++m2)
                             put(16 + q, ((mm * 2 + u) * 4 + m2) * 2, lane, e,
-                                W2[(size_t)(32 * m2 + i) * ci2 + 32 * (2 * q + mm) + rho(8 * u + e, g)], s2);
+                                W[2][(size_t)(32 * m2 + i) * ci2 + 32 * (2 * q + mm) + rho(8 * u + e, g)], s2);
             for (int m2 = 0; m2 < 4; ++m2) {
                 const int slot0 = 8 * g + e;
-                put(19, 32 + m2 * 2, lane, e, slot0 < c0 ? W2[(size_t)(32 * m2 + i) * ci2 + 256 + slot0] : 0.f, s2);
+                put(19, 32 + m2 * 2, lane, e, slot0 < c0 ? W[2][(size_t)(32 * m2 + i) * ci2 + 256 + slot0] : 0.f, s2);
             }
         }
     });
@@ -247,8 +213,7 @@ int mlp_pack_f16x3(icon_mlp *m, const std::vector<std::vector<float>> &W, const 
     ICON_HIP(hipMemcpyAsync(m->d_f16, img.data(), kImageBytes, hipMemcpyHostToDevice, st));
     ICON_HIP(hipMemcpyAsync(m->d_f16 + kImageBytes, side.data(), side_bytes, hipMemcpyHostToDevice, st));
     ICON_HIP(hipStreamSynchronize(st));
-    // what an accumulator is multiplied by before LeakyReLU: 1 / weight scale, times the activation scale of the layer
-    m->f16_inv[0] = A0 / s0; m->f16_inv[1] = A1 / s1; m->f16_inv[2] = 1.0f / s2;
+    m->f16_inv[0] = 1.0f / s0; m->f16_inv[1] = 1.0f / s1; m->f16_inv[2] = 1.0f / s2;
     return ICON_OK;
 }
 

@@ -12,9 +12,19 @@ typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void gvoid_t;
 typedef __attribute__((address_space(3))) void lvoid_t;
 
+#if defined(ICON_EXP_HALFWG)
+// experiment (with NO_DMA + SLOTWRAP): workgroups of 4 waves / 128 points and 52 KiB of LDS, TWO per CU - do the serial
+// phases of one tile (prologue, barriers, layer 3) hide behind the MFMA phases of the other workgroup's tile?
+constexpr int kF16Block = 256;
+#else
 constexpr int kF16Block = 512;                 // 8 waves x 32 points
+#endif
 constexpr int kF16Pts = (kF16Block / 64) * 32; // 256 points per workgroup
+#if defined(ICON_EXP_SLOTWRAP)
+constexpr int kBufBytes = 8 * 1024;            // experiment: every A-operand read wraps into the first 8 slots
+#else
 constexpr int kBufBytes = 40 * 1024;
+#endif
 constexpr int kSideFloats = 512 + 256 + 128 + 144;   // b0 | b1 | b2 | w3, staged once per workgroup
 constexpr int kW0Off = 2 * kBufBytes;                // layer-0 operands, resident for the whole workgroup
 constexpr int kW0Bytes = 32 * 1024;
@@ -117,18 +127,27 @@ __device__ __forceinline__ void activate_split(const f32x16 &acc, const LeakyK &
 
 __device__ __forceinline__ half8 lds_op(const char *buf, int slot, int lane)
 {
+#if defined(ICON_EXP_SLOTWRAP)
+    if (slot >= 8) slot &= 7;                  // (the resident W0 region is addressed with slots < 32 through the same helper: keep those)
+#endif
     return *reinterpret_cast<const half8 *>(buf + slot * 1024 + lane * 16);
 }
 
-// (The timing-only variants of round 3 - builds that remove one component of these bodies and give WRONG results by
-//  construction - live in tools/probes/exp_r03/, a snapshot of this header with its ICON_EXP_* switches; the product
-//  header has no such switch: tests/test_host.py::test_hot_kernels_do_not_spill checks.)
-#define ICON_CHUNK_BARRIER() __syncthreads()
-
 // every wave DMAs 1 KiB pieces round-robin: global [piece][lane][16 B] -> LDS, same order
+// Timing-only experiment switches (tools/exp_fused.sh builds variants with -DICON_EXP_*; every one of them gives WRONG
+// results - they price one component of the kernel by removing it): NO_AREADS - one A-operand group per chunk, reused;
+// NO_DMA - no global->LDS weight stream; NO_ACT - no LeakyReLU / hi-lo split VALU work; NO_BAR - no chunk barriers.
+#if defined(ICON_EXP_NO_BAR)
+#define ICON_CHUNK_BARRIER() do { } while (0)
+#else
+#define ICON_CHUNK_BARRIER() __syncthreads()
+#endif
 
 __device__ __forceinline__ void issue_units(const char *src, char *buf, int units, int wave, int lane)
 {
+#if defined(ICON_EXP_NO_DMA)
+    if (units != kW0Bytes / 1024) return;
+#endif
     for (int u = wave; u < units; u += kF16Block / 64)
         __builtin_amdgcn_global_load_lds((gvoid_t *)(src + u * 1024 + lane * 16), (lvoid_t *)(buf + u * 1024), 16, 0, 0);
 }
@@ -150,10 +169,18 @@ __device__ __forceinline__ void issue_chunk(const char *image, char *buf, int k,
 // stays in flight for the whole multiplication of chunk k and is only waited for at the barrier.
 
 // 3-term product group for 2 output tiles sharing one B operand pair
+#if defined(ICON_EXP_GRAY)
+// experiment: every MFMA shares one operand with its predecessor (does operand-latch toggling cost energy?)
+#define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
+    ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); \
+    ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
+    ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]); ACC[M0] = MFMA16(AL[0], BH, ACC[M0]);
+#else
 #define TRIPLE2(ACC, M0, AH, AL, BH, BL)                                     \
     ACC[M0] = MFMA16(AH[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BH, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AH[0], BL, ACC[M0]); ACC[M0 + 1] = MFMA16(AH[1], BL, ACC[M0 + 1]); \
     ACC[M0] = MFMA16(AL[0], BH, ACC[M0]); ACC[M0 + 1] = MFMA16(AL[1], BH, ACC[M0 + 1]);
+#endif
 
 // layer 0, hidden tile c (32 channels): 3 MFMAs from the resident W0 region
 __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const float *__restrict__ sb0, int c, half8 xhi, half8 xlo,
@@ -169,10 +196,31 @@ __device__ __forceinline__ f32x16 l0_tile(const char *__restrict__ W0, const flo
 // hi/lo halves -> pair (k&3) of the next B operand (u = k>>2)
 __device__ __forceinline__ void act_part(const f32x16 &acc, int k, const LeakyK &inv, half8 (&nh)[2], half8 (&nl)[2])
 {
+#if defined(ICON_EXP_NO_ACT)
+    {   // keep the data dependence on the accumulator (one v_mov-class op per pair), drop the arithmetic
+        const int u = k >> 2, q = k & 3;
+        const fp16x2 raw = __builtin_bit_cast(fp16x2, __float_as_int(acc[2 * k]) ^ __float_as_int(inv.inv));
+        nh[u][2 * q] = (_Float16)raw[0]; nh[u][2 * q + 1] = (_Float16)raw[1];
+        nl[u][2 * q] = (_Float16)raw[1]; nl[u][2 * q + 1] = (_Float16)raw[0];
+        return;
+    }
+#endif
 
     const float v0 = leaky_scaled(acc[2 * k], inv), v1 = leaky_scaled(acc[2 * k + 1], inv);      // 7 VALU per pair with the split below
     fp16x2 hh = __builtin_amdgcn_cvt_pkrtz(v0, v1);
     fp16x2 ll = residual_pair(hh, v0, v1);
+#if defined(ICON_EXP_ACT2X)
+    {   // the same 9 VALU once more on the same data, results discarded: what does a VALU instruction cost on real data?
+        float y0 = acc[2 * k], y1 = acc[2 * k + 1];
+        asm volatile("" : "+v"(y0), "+v"(y1));
+        const float z0 = y0 * inv.inv, z1 = y1 * inv.inv;
+        const float u0 = fmaxf(z0, 0.01f * z0), u1 = fmaxf(z1, 0.01f * z1);
+        fp16x2 h2 = __builtin_amdgcn_cvt_pkrtz(u0, u1);
+        fp16x2 l2 = residual_pair(h2, u0, u1);
+        int a2 = __builtin_bit_cast(int, h2), b2 = __builtin_bit_cast(int, l2);
+        asm volatile("" :: "v"(a2), "v"(b2));
+    }
+#endif
     // the (empty) volatile asm is ordered against the surrounding sched_barriers, which keeps this
     // VALU work in the MFMA group it was written next to instead of being sunk to the end of the chunk
     int hb = __builtin_bit_cast(int, hh), lb = __builtin_bit_cast(int, ll);
@@ -209,7 +257,11 @@ __device__ __forceinline__ void l01_chunk(const char *__restrict__ L, char *__re
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
+#if defined(ICON_EXP_NO_AREADS)
+        if (g == 0) load_group(L, 1, lane, a[1]);
+#else
         if (g + 1 < 8) load_group(L, g + 1, lane, a[(g + 1) & 1]);
+#endif
         const int u = g >> 2, m0 = (g & 3) * 2;
         const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
         TRIPLE2(acc1, m0, ah, al, bh[u], bl[u])
@@ -246,7 +298,11 @@ __device__ __forceinline__ void l2_chunk(const char *__restrict__ L, char *__res
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+#if defined(ICON_EXP_NO_AREADS)
+            if (g == 0) load2(1, a[1]);
+#else
             if (g + 1 < 4) load2(g + 1, a[(g + 1) & 1]);
+#endif
             const int u = g >> 1, m0 = (g & 1) * 2;
             const half8 ah[2] = {a[g & 1][0], a[g & 1][1]}, al[2] = {a[g & 1][2], a[g & 1][3]};
             TRIPLE2(acc2, m0, ah, al, bh[u], bl[u])
