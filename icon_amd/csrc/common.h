@@ -247,6 +247,8 @@ struct icon_mlp {
 namespace icon {
 // host helper: fn(i) for i in [0, n) on up to 16 threads (operand packing, BVH subtrees)
 void parallel_for(int n, const std::function<void(int)> &fn);
+// ICON_AMD_DEBUG_SYNC=1: wait for the stream after the named launch and say so on stderr (localises a hung / faulting kernel)
+void debug_sync(const char *what, hipStream_t st);
 // mesh_device.hip: the per-image build on the device; pooled pinned mirrors of MeshDyn + events
 struct MeshLayout;
 int mesh_host_state_get(MeshDyn **h, hipEvent_t *ev);

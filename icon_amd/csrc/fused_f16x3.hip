@@ -524,7 +524,9 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
         if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),   \
                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds); }))) return rc; \
         hipLaunchKernelGGL((k_fused_f16x3<P, L_>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);               \
+        debug_sync("k_fused_f16x3", st);                                                                                   \
         hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
+        debug_sync("k_rescue_fused", st);                                                                                  \
     } while (0)
     if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }
     else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true, 2); else ICON_FUSED(ICON_PRIOR_PAMIR, false, 3); }

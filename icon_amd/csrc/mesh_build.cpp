@@ -35,6 +35,20 @@ void set_error(const std::string &msg) { g_err = msg; }
 int fail(int code, const std::string &msg) { g_err = msg; return code; }
 const char *last_error_cstr() { return g_err.c_str(); }
 
+void debug_sync(const char *what, hipStream_t st)
+{
+    static const int on = getenv("ICON_AMD_DEBUG_SYNC") ? atoi(getenv("ICON_AMD_DEBUG_SYNC")) : 0;
+    if (!on) return;
+    static thread_local std::chrono::steady_clock::time_point last = std::chrono::steady_clock::now();
+    const double since = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - last).count();
+    fprintf(stderr, "[icon_amd] (+%.3f ms on the host) %s ...", since, what); fflush(stderr);
+    const auto t0 = std::chrono::steady_clock::now();
+    const hipError_t e = hipStreamSynchronize(st);
+    last = std::chrono::steady_clock::now();
+    fprintf(stderr, " %s after %.3f ms\n", e == hipSuccess ? "done" : hipGetErrorString(e), std::chrono::duration<double, std::milli>(last - t0).count());
+    fflush(stderr);
+}
+
 // ---- host thread pool ----------------------------------------------------------------------------------
 // The per-image preparation is a handful of sub-millisecond parallel sections (BVH subtrees, slot records, ray bins,
 // operand packing); starting fifteen threads for each of them cost more than the work.  The workers are started once,

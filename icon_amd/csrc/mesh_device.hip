@@ -46,13 +46,19 @@ struct BuildCtx {
     int32_t *valence; uint8_t *leaf_cnt; BTask *tasks; uint32_t *hist; int32_t *cell_count, *cell_cursor;
     float *vnormals; BvhNode *nodes; LeafRec *leaves; TriRec *tris; TriAttr *attr; int32_t *slot2face, *face2slot;
     int32_t *bin_start, *bin_slots;
-    float *tbox, *cen; int32_t *order[2]; int32_t *adj; int32_t *chunkcnt; int32_t *subq;
+    float *tbox, *cen; int32_t *order[2]; int32_t *adj; int32_t *chunkcnt; int32_t *subq; struct STask *sublist;
     int32_t nck; int64_t cells_cap, entries_cap;
 };
 
 // ---- ordered-uint encoding of floats: max-atomics with a zero identity ---------------------------------------
 __device__ __forceinline__ uint32_t enc(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
 __device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u); }
+// MINIMA are kept as maxima of the COMPLEMENTED code (~enc is order-reversing; 0 is still the identity).  No float negation
+// anywhere: with minima stored as max(enc(-x)) and decoded as -dec(u) - or with the sign bit flipped by an integer xor
+// next to the bitcast - hipcc (ROCm 7.2) lost the sign flip of ONE element of the unrolled decode loops (the select had
+// gone to the scalar ALU and the fneg was dropped: lo.x came out as +|lo.x|; found by the byte comparison with the host build).
+__device__ __forceinline__ uint32_t enc_min(float f) { return ~enc(f); }
+__device__ __forceinline__ float dec_min(uint32_t u) { return dec(~u); }
 
 __device__ __forceinline__ void wave_sync()
 {
@@ -101,8 +107,8 @@ __global__ __launch_bounds__(256) void k_face_prep(BuildCtx c)
     // mesh bounds: wave reduction, one atomic per value and wave
     uint32_t u[12];
     for (int a = 0; a < 3; ++a) {
-        u[a] = live ? enc(-lo[a]) : 0u; u[3 + a] = live ? enc(hi[a]) : 0u;
-        u[6 + a] = live ? enc(-ce[a]) : 0u; u[9 + a] = live ? enc(ce[a]) : 0u;
+        u[a] = live ? enc_min(lo[a]) : 0u; u[3 + a] = live ? enc(hi[a]) : 0u;
+        u[6 + a] = live ? enc_min(ce[a]) : 0u; u[9 + a] = live ? enc(ce[a]) : 0u;
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
@@ -132,8 +138,8 @@ __global__ __launch_bounds__(256) void k_vertex_normals(BuildCtx c)
         // the root task and what the query kernels need of the bounding box
         float box[6], cb[6];
         for (int a = 0; a < 3; ++a) {
-            box[a] = -dec(c.hdr->mesh_ubox[a]); box[3 + a] = dec(c.hdr->mesh_ubox[3 + a]);
-            cb[a] = -dec(c.hdr->mesh_ubox[6 + a]); cb[3 + a] = dec(c.hdr->mesh_ubox[9 + a]);
+            box[a] = dec_min(c.hdr->mesh_ubox[a]); box[3 + a] = dec(c.hdr->mesh_ubox[3 + a]);
+            cb[a] = dec_min(c.hdr->mesh_ubox[6 + a]); cb[3 + a] = dec(c.hdr->mesh_ubox[9 + a]);
         }
         BTask &r = c.tasks[0];
         r.begin = 0; r.end = c.F; r.depth = 0; r.parent = -1; r.side = 0; r.buf = 0; r.from_atomics = 0;
@@ -193,8 +199,8 @@ __device__ __forceinline__ void task_bounds(const BTask &t, float box[6], float 
 {
     if (t.from_atomics) {
         for (int a = 0; a < 3; ++a) {
-            box[a] = -dec(t.ubox[a]); box[3 + a] = dec(t.ubox[3 + a]);
-            cb[a] = -dec(t.ubox[6 + a]); cb[3 + a] = dec(t.ubox[9 + a]);
+            box[a] = dec_min(t.ubox[a]); box[3 + a] = dec(t.ubox[3 + a]);
+            cb[a] = dec_min(t.ubox[6 + a]); cb[3 + a] = dec(t.ubox[9 + a]);
         }
     } else {
         for (int k = 0; k < 6; ++k) { box[k] = t.box[k]; cb[k] = t.cb[k]; }
@@ -207,8 +213,8 @@ __device__ __forceinline__ void hist_add(uint32_t *h, const float lo[3], const f
 {
     const float cx = cen(0), cy = cen(1), cz = cen(2);
     uint32_t u[12];
-    u[0] = enc(-tb(0)); u[1] = enc(-tb(1)); u[2] = enc(-tb(2)); u[3] = enc(tb(3)); u[4] = enc(tb(4)); u[5] = enc(tb(5));
-    u[6] = enc(-cx); u[7] = enc(-cy); u[8] = enc(-cz); u[9] = enc(cx); u[10] = enc(cy); u[11] = enc(cz);
+    u[0] = enc_min(tb(0)); u[1] = enc_min(tb(1)); u[2] = enc_min(tb(2)); u[3] = enc(tb(3)); u[4] = enc(tb(4)); u[5] = enc(tb(5));
+    u[6] = enc_min(cx); u[7] = enc_min(cy); u[8] = enc_min(cz); u[9] = enc(cx); u[10] = enc(cy); u[11] = enc(cz);
     const float cc[3] = {cx, cy, cz};
 #pragma unroll
     for (int ax = 0; ax < 3; ++ax) {
@@ -240,8 +246,8 @@ __device__ __forceinline__ void sah_choose(const uint32_t *h, const float ext[3]
             const int s = k <= b ? 0 : 1;
             cnt[s] += n;
             for (int a = 0; a < 3; ++a) {
-                bl[s][a] = fminf(bl[s][a], -dec(q[1 + a])); bl[s][3 + a] = fmaxf(bl[s][3 + a], dec(q[4 + a]));
-                cl[s][a] = fminf(cl[s][a], -dec(q[7 + a])); cl[s][3 + a] = fmaxf(cl[s][3 + a], dec(q[10 + a]));
+                bl[s][a] = fminf(bl[s][a], dec_min(q[1 + a])); bl[s][3 + a] = fmaxf(bl[s][3 + a], dec(q[4 + a]));
+                cl[s][a] = fminf(cl[s][a], dec_min(q[7 + a])); cl[s][3 + a] = fmaxf(cl[s][3 + a], dec(q[10 + a]));
             }
         }
         if (cnt[0] && cnt[1]) cost = box_area(bl[0], bl[0] + 3) * cnt[0] + box_area(bl[1], bl[1] + 3) * cnt[1];
@@ -365,8 +371,8 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
         uint32_t *u = C[isl ? 0 : 1].ubox;
         const float *ce = c.cen + 3 * (size_t)e, *tb = c.tbox + 6 * (size_t)e;
         for (int a = 0; a < 3; ++a) {
-            atomicMax(u + a, enc(-tb[a])); atomicMax(u + 3 + a, enc(tb[3 + a]));
-            atomicMax(u + 6 + a, enc(-ce[a])); atomicMax(u + 9 + a, enc(ce[a]));
+            atomicMax(u + a, enc_min(tb[a])); atomicMax(u + 3 + a, enc(tb[3 + a]));
+            atomicMax(u + 6 + a, enc_min(ce[a])); atomicMax(u + 9 + a, enc(ce[a]));
         }
     }
     if (k == 0 && threadIdx.x == 0) {
@@ -385,9 +391,14 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
     }
 }
 
-// ---- subtrees: one workgroup, wave-per-node ------------------------------------------------------------------------
+// ---- subtrees: one workgroup per subtree, level by level, one wavefront per node ------------------------------------
+// The nodes of one level of the subtree sit in a list; wave w takes nodes w, w + 8, ...: histogram by LDS atomics,
+// 45 SAH candidates on 45 lanes, ballot-ranked stable partition; children that are not leaves are appended to the next
+// level's list (one LDS atomic per child), a barrier, the lists swap.  (A first version handed nodes from wave to wave
+// through a lock-protected pool with sleeping pollers: correct, and 16-43 SECONDS per mesh - seven idle waves per
+// workgroup kept the lock busy around the clock.  No locks, no polling now.)
 constexpr int kSubWaves = 8;
-constexpr int kPoolCap = 256;
+constexpr int kListCap = 256;          // nodes of one level: every pending node holds >= 5 of the subtree's <= kSubMax triangles
 struct STask { int32_t begin, end, depth, parent, side, buf; float box[6], cb[6]; int32_t pad[2]; };
 static_assert(sizeof(STask) == 80, "STask layout");
 
@@ -398,9 +409,8 @@ struct SubLds {
     uint16_t ord[2][kSubMax];
     uint32_t hist[kSubWaves][kHistWords];
     Decision dec[kSubWaves];
-    STask pool[kPoolCap];
-    STask scratch[kSubWaves];
-    int pool_n, lock, remaining;
+    STask list[2][kListCap];
+    int count[2];
 };
 
 // element access of a subtree: LDS-resident (local ids) or in global memory (face ids; a subtree too large for LDS)
@@ -422,7 +432,7 @@ struct GlbAcc {
 };
 
 template <class A>
-__device__ __forceinline__ void finalize_leaf(const BuildCtx &c, const A &acc, SubLds *S, const STask &t, int lane)
+__device__ __forceinline__ void finalize_leaf(const BuildCtx &c, const A &acc, const STask &t, int lane)
 {
     const int n = t.end - t.begin;
     if (lane < n) c.slot2face[t.begin + lane] = acc.face(acc.get(t.buf, t.begin + lane));
@@ -431,7 +441,6 @@ __device__ __forceinline__ void finalize_leaf(const BuildCtx &c, const A &acc, S
         link_node(c, t.parent, t.side, ~((t.begin << 2) | (n - 1)), t.box);
         atomicAdd(&c.dyn->n_leaves, 1);
         atomicMax(&c.dyn->depth, t.depth);
-        atomicSub(&S->remaining, n);
     }
 }
 
@@ -455,33 +464,18 @@ __device__ __forceinline__ void range_bounds(const A &acc, int buf, int a, int b
     for (int k = 0; k < 6; ++k) { box[k] = v[k]; cb[k] = v[6 + k]; }
 }
 
-__device__ __forceinline__ void pool_lock(SubLds *S, int lane)
-{
-    if (lane == 0) while (atomicCAS(&S->lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
-    wave_sync();
-}
-__device__ __forceinline__ void pool_unlock(SubLds *S, int lane)
-{
-    wave_sync();
-    if (lane == 0) atomicExch(&S->lock, 0);
-}
-__device__ __forceinline__ void copy_task(STask *dst, const STask *src, int lane)
-{
-    if (lane < (int)(sizeof(STask) / 4)) reinterpret_cast<volatile int *>(dst)[lane] = reinterpret_cast<const volatile int *>(src)[lane];
-}
-
-// one node by one wavefront; returns true when `t` has been replaced by a child to continue with
-template <class A>
-__device__ __forceinline__ bool process_node(const BuildCtx &c, const A &acc, SubLds *S, STask &t, STask *scratch /* LDS, this wave's */, int wave, int lane)
+// one node by one wavefront: a leaf is finished, anything else is split and its children that are not leaves are handed
+// to `emit` (all lanes call it with the same task)
+template <class A, class Emit>
+__device__ __forceinline__ void process_node(const BuildCtx &c, const A &acc, uint32_t *h /* LDS, this wave's */, Decision *D /* LDS, this wave's */,
+                                             const STask &t, int lane, Emit emit)
 {
     const int n = t.end - t.begin;
-    if (n <= kLeafMax) { finalize_leaf(c, acc, S, t, lane); return false; }
+    if (n <= kLeafMax) { finalize_leaf(c, acc, t, lane); return; }
     float lo[3], ext[3];
     for (int a = 0; a < 3; ++a) { lo[a] = t.cb[a]; ext[a] = t.cb[3 + a] - t.cb[a]; }
-    Decision *D = &S->dec[wave];
     bool valid = false;
     if (!force_median(t.depth, n, c.bound) && (ext[0] > 0.0f || ext[1] > 0.0f || ext[2] > 0.0f)) {
-        uint32_t *h = S->hist[wave];
         for (int i = lane; i < kHistWords; i += 64) h[i] = 0;
         wave_sync();
         for (int i = lane; i < n; i += 64) {
@@ -491,18 +485,15 @@ __device__ __forceinline__ bool process_node(const BuildCtx &c, const A &acc, Su
         wave_sync();
         sah_choose(h, ext, lane, D);
         wave_sync();
-        valid = *reinterpret_cast<volatile int *>(&D->valid) != 0;
+        valid = D->valid != 0;
     }
     int nleft, cbuf;
     float cbox[2][6], ccb[2][6];
     if (valid) {
-        const int axis = *reinterpret_cast<volatile int *>(&D->axis), bin = *reinterpret_cast<volatile int *>(&D->bin);
-        nleft = *reinterpret_cast<volatile int *>(&D->nleft);
+        const int axis = D->axis, bin = D->bin;
+        nleft = D->nleft;
         for (int s = 0; s < 2; ++s)
-            for (int k = 0; k < 6; ++k) {
-                cbox[s][k] = *reinterpret_cast<volatile float *>(&D->cbox[s][k]);
-                ccb[s][k] = *reinterpret_cast<volatile float *>(&D->ccb[s][k]);
-            }
+            for (int k = 0; k < 6; ++k) { cbox[s][k] = D->cbox[s][k]; ccb[s][k] = D->ccb[s][k]; }
         int lb = 0, rb = nleft;
         const unsigned long long lt = (1ull << lane) - 1ull;
         for (int i0 = 0; i0 < n; i0 += 64) {
@@ -525,63 +516,43 @@ __device__ __forceinline__ bool process_node(const BuildCtx &c, const A &acc, Su
     }
     const int mid = t.begin + nleft, id = mid - 1;
     if (lane == 0) { link_node(c, t.parent, t.side, id, t.box); atomicAdd(&c.dyn->n_nodes, 1); }
-    STask ch[2];
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
-        ch[s].begin = s ? mid : t.begin; ch[s].end = s ? t.end : mid; ch[s].depth = t.depth + 1; ch[s].parent = id; ch[s].side = s; ch[s].buf = cbuf;
-        for (int k = 0; k < 6; ++k) { ch[s].box[k] = cbox[s][k]; ch[s].cb[k] = ccb[s][k]; }
-        ch[s].pad[0] = ch[s].pad[1] = 0;
+        STask ch;
+        ch.begin = s ? mid : t.begin; ch.end = s ? t.end : mid; ch.depth = t.depth + 1; ch.parent = id; ch.side = s; ch.buf = cbuf;
+        for (int k = 0; k < 6; ++k) { ch.box[k] = cbox[s][k]; ch.cb[k] = ccb[s][k]; }
+        ch.pad[0] = ch.pad[1] = 0;
+        if (ch.end - ch.begin <= kLeafMax) finalize_leaf(c, acc, ch, lane);
+        else emit(ch);
     }
-    const bool big0 = nleft > kLeafMax, big1 = n - nleft > kLeafMax;
-    if (!big0) finalize_leaf(c, acc, S, ch[0], lane);
-    if (!big1) finalize_leaf(c, acc, S, ch[1], lane);
-    if (big0 && big1) {
-        // the right child goes to the pool (its ranges never outnumber the pool: every pending task holds >= 5 of the
-        // subtree's <= kSubMax triangles; the single-wave walk of an oversize subtree keeps at most one per level)
-        if (lane == 0) *scratch = ch[1];
-        pool_lock(S, lane);
-        const int np = *reinterpret_cast<volatile int *>(&S->pool_n);
-        if (np < kPoolCap) {
-            copy_task(&S->pool[np], scratch, lane);
-            if (lane == 0) *reinterpret_cast<volatile int *>(&S->pool_n) = np + 1;
-        } else if (lane == 0) {
-            atomicOr(&c.dyn->status, kMeshInternal);
-        }
-        pool_unlock(S, lane);
-        t = ch[0];
-        return true;
-    }
-    if (big0) { t = ch[0]; return true; }
-    if (big1) { t = ch[1]; return true; }
-    return false;
 }
 
+// the levels of one subtree.  `lists`: [2][cap] task lists (LDS, or - for a subtree too large for LDS - this subtree's
+// slice of the arena), counts[2] in LDS; all `nwaves` waves of the workgroup call this together.
 template <class A>
-__device__ __forceinline__ void sub_loop(const BuildCtx &c, const A &acc, SubLds *S, STask *scratch, int wave, int lane)
+__device__ __forceinline__ void sub_levels(const BuildCtx &c, const A &acc, SubLds *S, STask *list0, STask *list1, int cap,
+                                           int wave, int lane, int nwaves)
 {
-    for (;;) {
-        bool have = false;
-        pool_lock(S, lane);
-        const int np = *reinterpret_cast<volatile int *>(&S->pool_n);
-        if (np > 0) {
-            copy_task(scratch, &S->pool[np - 1], lane);
-            if (lane == 0) *reinterpret_cast<volatile int *>(&S->pool_n) = np - 1;
-            have = true;
+    STask *lists[2] = {list0, list1};
+    for (int lv = 0;; ++lv) {
+        __syncthreads();                                       // the level's list is complete, the other count is 0
+        const int cur = lv & 1, nc = S->count[cur];
+        if (nc == 0) break;
+        for (int i = wave; i < nc; i += nwaves) {
+            const STask t = lists[cur][i];                     // (a plain struct copy: punning it through int* broke under strict aliasing)
+            process_node(c, acc, S->hist[wave], &S->dec[wave], t, lane, [&](const STask &ch) {
+                int idx = 0;
+                if (lane == 0) idx = atomicAdd(&S->count[cur ^ 1], 1);
+                idx = __builtin_amdgcn_readfirstlane(idx);
+                if (idx < cap) {
+                    if (lane == 0) lists[cur ^ 1][idx] = ch;
+                } else if (lane == 0) {
+                    atomicOr(&c.dyn->status, kMeshInternal);
+                }
+            });
         }
-        pool_unlock(S, lane);
-        if (!have) {
-            if (*reinterpret_cast<volatile int *>(&S->remaining) <= 0) break;
-            __builtin_amdgcn_s_sleep(8);
-            continue;
-        }
-        wave_sync();
-        STask t;
-        {
-            const volatile int *q = reinterpret_cast<const volatile int *>(scratch);
-            int *d = reinterpret_cast<int *>(&t);
-            for (int k = 0; k < (int)(sizeof(STask) / 4); ++k) d[k] = q[k];
-        }
-        wave_sync();
-        while (process_node(c, acc, S, t, scratch, wave, lane)) {}
+        __syncthreads();                                       // every wave is done with this level
+        if (threadIdx.x == 0) S->count[cur] = 0;
     }
 }
 
@@ -593,29 +564,32 @@ __global__ __launch_bounds__(kSubWaves * 64) void k_bvh_sub(BuildCtx c)
     const BTask &T = c.tasks[c.subq[blockIdx.x]];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n = T.end - T.begin;
+    const bool in_lds = n <= kSubMax;
     if (threadIdx.x == 0) {
         STask r;
         r.begin = T.begin; r.end = T.end; r.depth = T.depth; r.parent = T.parent; r.side = T.side;
-        r.buf = n <= kSubMax ? 0 : T.buf;
+        r.buf = in_lds ? 0 : T.buf;
         task_bounds(T, r.box, r.cb);
         r.pad[0] = r.pad[1] = 0;
-        S->pool[0] = r; S->pool_n = 1; S->lock = 0; S->remaining = n;
+        (in_lds ? S->list[0] : c.sublist + (size_t)(T.begin / 5) * 2)[0] = r;
+        S->count[0] = 1; S->count[1] = 0;
     }
-    if (n <= kSubMax) {
+    if (in_lds) {
         for (int i = threadIdx.x; i < n; i += kSubWaves * 64) {
             const int e = c.order[T.buf][T.begin + i];
             S->gid[i] = e; S->ord[0][i] = (uint16_t)i;
             for (int a = 0; a < 3; ++a) S->cen[i * 3 + a] = c.cen[3 * (size_t)e + a];
             for (int q = 0; q < 6; ++q) S->tbox[i * 6 + q] = c.tbox[6 * (size_t)e + q];
         }
-        __syncthreads();
         LdsAcc acc{S, T.begin};
-        sub_loop(c, acc, S, &S->scratch[wave], wave, lane);
+        sub_levels(c, acc, S, S->list[0], S->list[1], kListCap, wave, lane, kSubWaves);
     } else {
-        __syncthreads();
-        if (wave != 0) return;                                 // an oversize subtree (pathologically unbalanced top): one wave, global memory
+        // an oversize subtree (pathologically unbalanced top levels): elements and task lists in global memory; the lists
+        // are this subtree's slice of c.sublist - [begin / 5, begin / 5 + n / 5) entries of each list, disjoint between subtrees
         GlbAcc acc{{c.order[0], c.order[1]}, c.cen, c.tbox};
-        sub_loop(c, acc, S, &S->scratch[0], 0, lane);
+        STask *base = c.sublist + (size_t)(T.begin / 5) * 2;
+        const int cap = n / 5;                                  // pending nodes hold >= 5 triangles each; 2 * cap entries fit the slice
+        sub_levels(c, acc, S, base, base + cap, cap, wave, lane, kSubWaves);
     }
 }
 
@@ -735,12 +709,22 @@ __global__ __launch_bounds__(256) void k_bin_sort(BuildCtx c)
 std::mutex g_pool_mu;
 std::vector<MeshDyn *> g_free_dyn;
 std::vector<hipEvent_t> g_free_ev;
+// a handle destroyed while its build was still in flight: its mirror must not be handed out before the build's last copy has
+// landed in it (it would report the OLD mesh's status for the new one)
+std::vector<std::pair<MeshDyn *, hipEvent_t>> g_in_flight;
 
 }  // namespace
 
 int mesh_host_state_get(MeshDyn **h, hipEvent_t *ev)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (size_t i = 0; i < g_in_flight.size();) {
+        if (hipEventQuery(g_in_flight[i].second) != hipErrorNotReady) {
+            g_free_dyn.push_back(g_in_flight[i].first); g_free_ev.push_back(g_in_flight[i].second);
+            g_in_flight[i] = g_in_flight.back(); g_in_flight.pop_back();
+        } else ++i;
+    }
+    (void)hipGetLastError();
     if (g_free_dyn.empty()) {
         constexpr int kBatch = 32;
         MeshDyn *blk = nullptr;
@@ -761,6 +745,8 @@ int mesh_host_state_get(MeshDyn **h, hipEvent_t *ev)
 void mesh_host_state_put(MeshDyn *h, hipEvent_t ev)
 {
     std::lock_guard<std::mutex> lk(g_pool_mu);
+    if (h && ev && hipEventQuery(ev) == hipErrorNotReady) { g_in_flight.emplace_back(h, ev); (void)hipGetLastError(); return; }
+    (void)hipGetLastError();
     if (h) g_free_dyn.push_back(h);
     if (ev) g_free_ev.push_back(ev);
 }
@@ -803,17 +789,21 @@ int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces
     c.cen = reinterpret_cast<float *>(b + L.cen); c.order[0] = reinterpret_cast<int32_t *>(b + L.order0);
     c.order[1] = reinterpret_cast<int32_t *>(b + L.order1); c.adj = reinterpret_cast<int32_t *>(b + L.adj);
     c.chunkcnt = reinterpret_cast<int32_t *>(b + L.chunkcnt); c.subq = reinterpret_cast<int32_t *>(b + L.subq);
+    c.sublist = reinterpret_cast<STask *>(b + L.sublist);
     c.nck = (int32_t)L.nck; c.cells_cap = bin_cells_cap(m->F); c.entries_cap = bin_entries_cap(m->F);
 
     ICON_HIP(hipMemsetAsync(b + L.dyn, 0, L.zero_end - L.dyn, st));
     const unsigned nbF = (unsigned)((m->F + 255) / 256), nbV = (unsigned)((m->V + 255) / 256);
     hipLaunchKernelGGL(k_face_prep, dim3(nbF), dim3(256), 0, st, c);
+    debug_sync("k_face_prep", st);
     hipLaunchKernelGGL(k_vertex_normals, dim3(nbV), dim3(256), 0, st, c);
+    debug_sync("k_vertex_normals", st);
     if (m->F > kSubMax) {
         for (int lv = 0; lv < kTopLevels; ++lv) {
             const unsigned nb = (unsigned)(m->F / kChunk + (1 << lv) + 1);
             hipLaunchKernelGGL(k_bvh_bin, dim3(nb), dim3(kChunk), 0, st, c, lv);
             hipLaunchKernelGGL(k_bvh_part, dim3(nb), dim3(kChunk), 0, st, c, lv);
+            debug_sync("k_bvh_bin + k_bvh_part", st);
         }
     }
     static_assert(sizeof(SubLds) <= 160 * 1024 - 2048, "k_bvh_sub: LDS");
@@ -822,10 +812,13 @@ int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_bvh_sub, dim3((unsigned)(m->F > kSubMax ? kTaskSlots + 1 : 1)), dim3(kSubWaves * 64), sizeof(SubLds), st, c);
+    debug_sync("k_bvh_sub", st);
     hipLaunchKernelGGL(k_tri_records, dim3(nbF), dim3(256), 0, st, c);
+    debug_sync("k_tri_records", st);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c);
     hipLaunchKernelGGL(k_bin_fill, dim3(nbF), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_bin_sort, dim3((unsigned)((c.cells_cap + 255) / 256)), dim3(256), 0, st, c);
+    debug_sync("ray bins", st);
     ICON_HIP(hipGetLastError());
     ICON_HIP(hipMemcpyAsync(m->h_dyn, c.dyn, sizeof(MeshDyn), hipMemcpyDeviceToHost, st));
     ICON_HIP(hipEventRecord(m->built, st));

@@ -754,7 +754,10 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
         else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0);
     }
     ICON_HIP(hipGetLastError());
-    return launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
+    debug_sync(LATTICE ? "k_row_crossings + k_nearest<lattice>" : "nearest (points)", st);
+    const int rc_sign = launch_sign(mesh, cal, L.res, L.z0, d_points, N, sdf_clip, work, LATTICE, st);
+    debug_sync("k_sign", st);
+    return rc_sign;
 }
 
 // X rows + codes (the materialising path): k_features, reading `near` unless the search is brute force
@@ -797,6 +800,7 @@ int outlier_list(icon_work *w, int64_t N, int8_t *signs, bool counted, hipStream
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total);
     hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
     ICON_HIP(hipGetLastError());
+    debug_sync("outlier scan + compact", st);
     return ICON_OK;
 }
 

@@ -4,6 +4,7 @@ normals, BVH nodes, leaf records, slot-ordered triangle records, inverse permuta
 queries on a device-built mesh must equal the oracle as before.  Reference being replaced: the per-call prologue of
 cal_sdf_batch, lib/dataset/mesh_util.py:367-372 (on the device there too)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -108,7 +109,13 @@ def test_device_build_equals_host_build(name):
             same = np.array_equal(host[a:b], devar[a:b])
             if not same:
                 bad = np.nonzero(host[a:b] != devar[a:b])[0]
-                raise AssertionError(f"{name}: section {sec} differs in {len(bad)} bytes, first at +{bad[0]}")
+                dump = os.environ.get("ICON_AMD_DUMP_DIR")
+                if dump:                        # both arenas for a post-mortem off the GPU box
+                    os.makedirs(dump, exist_ok=True)
+                    np.savez_compressed(os.path.join(dump, f"arena_{name}.npz"), host=host[: lay[10]], dev=devar[: lay[10]], lay=np.array(lay))
+                raise AssertionError(f"{name}: section {sec} differs in {len(bad)} bytes, first at +{bad[0]} "
+                                     f"(record {bad[0] // {'nodes': 64, 'leaves': 384, 'tris': 48, 'attr': 96}.get(sec, 4)}); dyn host {host[lay[0]:lay[0] + 84].view(np.int32)[[0, 15, 16, 17, 18, 19, 20]]} "
+                                     f"dev {devar[lay[0]:lay[0] + 84].view(np.int32)[[0, 15, 16, 17, 18, 19, 20]]}")
     finally:
         m.close()
 
