@@ -1,0 +1,380 @@
+// adaptive.hip - the reference's coarse-to-fine schedule (Seg3dLossless._forward_faster, lib/common/seg3d_lossless.py:152-265,
+// the mode apps/ICON.py:89 selects) as HIP kernels on one stream, no host read between the levels.
+//
+//   level 0        : the coarsest lattice, dense (the lattice kernels: one query() call over the whole 33^3 lattice)
+//   level l >= 1   : occ_l   = trilinear upsample of occ_{l-1} (F.interpolate, align_corners=True: :201, :213-216)
+//                    valid_l = upsample of (occ_{l-1} > balance); a voxel is a BOUNDARY voxel when 0 < valid < 1 (:217-218) -
+//                              with res_l = 2 res_{l-1} - 1 every weight is 0, 1/2 or 1, so that is exactly "the (up to 8)
+//                              parent corners around the voxel are not all on one side of the level" (integer logic, k_ad_boundary)
+//                    dilate the boundary by a 9^3 / 7^3 / 3^3 box (SmoothConv3D(k) > 0, lib/common/seg3d_utils.py:169-181:
+//                    a box is separable - three 1-D passes), drop the voxels evaluated at an earlier level (coords_accum),
+//                    compact in the reference's order (is_boundary.permute(2,1,0).nonzero(): x slowest, z fastest, :236-240),
+//                    query those points as ONE call (own outlier sign list, same order), scatter (:256-262)
+//   last level     : upsample only ("last step no examine", :186-203)
+//
+// What makes the sparse levels fast: their points are lattice points in a band around the surface, so the exact
+// nearest-triangle search runs as 4x4x4 PACKETS over the blocks of the level lattice that hold at least one candidate
+// (k_ad_nearest, the traversal of k_nearest<lattice>) instead of one wavefront per scattered point; the per-point phases
+// (inside test, sign list, feature rows + MLP) are the point-mode kernels of the ordinary query with the point count left on
+// the device (icon_work::q_n_dev) and the search results found through the lattice index (NearRef::map).
+// Masks live in [x][y][z] order (z fastest): the compaction's linear order IS the reference's point order.
+#pragma clang fp contract(off)
+
+#include "geom_device.h"
+
+#include <algorithm>
+#include <vector>
+
+constexpr int kAdMaxLevels = 8;
+
+struct icon_adaptive {
+    int n_levels = 0;
+    int res[kAdMaxLevels] = {0};
+    float *occ[kAdMaxLevels] = {nullptr};      // level volumes [z][y][x] (the last one is the caller's buffer, not owned)
+    uint8_t *P = nullptr;                      // (occ_{l-1} > balance) as bytes, [x][y][z]
+    uint8_t *M0 = nullptr, *M1 = nullptr;      // mask ping-pong, [x][y][z]
+    uint8_t *D[kAdMaxLevels] = {nullptr};      // voxels evaluated up to and including level l, [x][y][z] (level 0: all - not stored)
+    int32_t *map = nullptr;                    // compacted candidates: [z][y][x] linear index, in the reference's order
+    float *pts = nullptr;                      // their world positions [n][3]
+    int32_t *blk_count = nullptr, *blk_off = nullptr;   // compaction scratch (per 256 voxels)
+    uint8_t *blk_flag = nullptr;               // 4x4x4 blocks holding a candidate
+    int32_t *blk_list = nullptr;
+    int *counters = nullptr;                   // device: [0..levels) points queried per level, [8] n_blocks, [9] any-positive flag of level 0
+    int64_t cap = 0;                           // voxels of the largest queried level
+};
+
+namespace icon {
+
+void adaptive_destroy(icon_adaptive *a)
+{
+    if (!a) return;
+    for (int l = 0; l + 1 < a->n_levels; ++l) (void)hipFree(a->occ[l]);
+    for (int l = 1; l < kAdMaxLevels; ++l) (void)hipFree(a->D[l]);
+    (void)hipFree(a->P); (void)hipFree(a->M0); (void)hipFree(a->M1); (void)hipFree(a->map); (void)hipFree(a->pts);
+    (void)hipFree(a->blk_count); (void)hipFree(a->blk_off); (void)hipFree(a->blk_flag); (void)hipFree(a->blk_list); (void)hipFree(a->counters);
+    delete a;
+}
+
+namespace {
+
+// ---- F.interpolate(mode='trilinear', align_corners=True): ATen's upsample_trilinear3d expression, term for term --------------
+__global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)r * r * r) return;
+    const int w2 = (int)(i % r), h2 = (int)((i / r) % r), t2 = (int)(i / ((int64_t)r * r));
+    const float scale = (r > 1) ? (float)(rp - 1) / (float)(r - 1) : 0.0f;      // area_pixel_compute_scale, align_corners
+    const float t1r = scale * t2, h1r = scale * h2, w1r = scale * w2;
+    const int t1 = (int)t1r, h1 = (int)h1r, w1 = (int)w1r;
+    const int t1p = (t1 < rp - 1) ? 1 : 0, h1p = (h1 < rp - 1) ? 1 : 0, w1p = (w1 < rp - 1) ? 1 : 0;
+    const float t1l = t1r - t1, t0l = 1.0f - t1l, h1l = h1r - h1, h0l = 1.0f - h1l, w1l = w1r - w1, w0l = 1.0f - w1l;
+    auto at = [&](int t, int h, int w) { return src[((int64_t)t * rp + h) * rp + w]; };
+    dst[i] = t0l * (h0l * (w0l * at(t1, h1, w1) + w1l * at(t1, h1, w1 + w1p)) + h1l * (w0l * at(t1, h1 + h1p, w1) + w1l * at(t1, h1 + h1p, w1 + w1p))) +
+             t1l * (h0l * (w0l * at(t1 + t1p, h1, w1) + w1l * at(t1 + t1p, h1, w1 + w1p)) +
+                    h1l * (w0l * at(t1 + t1p, h1 + h1p, w1) + w1l * at(t1 + t1p, h1 + h1p, w1 + w1p)));
+}
+
+// [x][y][z] index of voxel (x, y, z)
+__device__ __forceinline__ int64_t xyz(int r, int x, int y, int z) { return ((int64_t)x * r + y) * r + z; }
+
+// P[x][y][z] = occ[z][y][x] > balance; any_pos: the reference returns None when nothing exceeds 0.5 on the coarsest lattice (:173-177)
+__global__ __launch_bounds__(256) void k_ad_pbits(const float *__restrict__ occ, int r, float balance, uint8_t *__restrict__ P, int *any_pos)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < (int64_t)r * r * r;
+    bool pos = false;
+    if (live) {
+        const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
+        const float v = occ[((int64_t)z * r + y) * r + x];
+        P[i] = v > balance ? 1 : 0;
+        pos = v > 0.5f;
+    }
+    if (any_pos && __any(pos) && (threadIdx.x & 63) == 0) atomicOr(any_pos, 1);
+}
+
+// boundary voxels of level l from the parents' bits (see the header)
+__global__ __launch_bounds__(256) void k_ad_boundary(const uint8_t *__restrict__ P, int rp, uint8_t *__restrict__ B, int r)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)r * r * r) return;
+    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
+    const int x0 = x >> 1, y0 = y >> 1, z0 = z >> 1, x1 = x0 + (x & 1), y1 = y0 + (y & 1), z1 = z0 + (z & 1);
+    const uint8_t a = P[xyz(rp, x0, y0, z0)];
+    const int diff = (int)(P[xyz(rp, x0, y0, z1)] != a) | (int)(P[xyz(rp, x0, y1, z0)] != a) | (int)(P[xyz(rp, x0, y1, z1)] != a) |
+                     (int)(P[xyz(rp, x1, y0, z0)] != a) | (int)(P[xyz(rp, x1, y0, z1)] != a) | (int)(P[xyz(rp, x1, y1, z0)] != a) | (int)(P[xyz(rp, x1, y1, z1)] != a);
+    B[i] = diff ? 1 : 0;
+}
+
+// one 1-D pass of the box dilation along `axis` (0 x, 1 y, 2 z); the LAST pass drops the voxels that were evaluated before:
+// done(v) = all coordinates even and D_prev[v / 2] (level 0: every voxel) - coords_accum * 2, seg3d_lossless.py:230-234
+__global__ __launch_bounds__(256) void k_ad_dilate(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int r, int axis, int rad,
+                                                  int last, const uint8_t *__restrict__ Dprev, int rp)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)r * r * r) return;
+    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
+    const int c = axis == 0 ? x : (axis == 1 ? y : z);
+    const int64_t stride = axis == 0 ? (int64_t)r * r : (axis == 1 ? r : 1);
+    uint8_t m = 0;
+    for (int d = -rad; d <= rad; ++d)
+        if (c + d >= 0 && c + d < r) m |= in[i + d * stride];
+    if (last && m && !((x | y | z) & 1)) {
+        const bool done = Dprev ? Dprev[xyz(rp, x >> 1, y >> 1, z >> 1)] != 0 : true;
+        if (done) m = 0;
+    }
+    out[i] = m;
+}
+
+// compaction in linear ([x][y][z]) order = the reference's nonzero() order: counts per 256 voxels, scan, scatter
+__global__ __launch_bounds__(256) void k_ad_count(const uint8_t *__restrict__ C, int64_t n, int32_t *__restrict__ blk_count)
+{
+    __shared__ int ws[4];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const unsigned long long b = __ballot(i < n && C[i]);
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = __popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
+}
+
+__global__ __launch_bounds__(1024) void k_ad_scan(const int32_t *__restrict__ cnt, int nb, int32_t *__restrict__ off, int *total)
+{
+    __shared__ int wtot[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < nb; base += 1024) {
+        const int i = base + (int)threadIdx.x;
+        const int v = i < nb ? cnt[i] : 0;
+        int incl = v;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        __syncthreads();
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int t = wtot[q]; before += q < w ? t : 0; all += t; }
+        if (i < nb) off[i] = carry + before + incl - v;
+        carry += all;
+    }
+    if (threadIdx.x == 0) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ C, int r, const int32_t *__restrict__ blk_off,
+                                                   int32_t *__restrict__ map, float *__restrict__ pts, uint8_t *__restrict__ blk_flag, int nbk)
+{
+    __shared__ int ws[4];
+    const int64_t n = (int64_t)r * r * r;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool c = i < n && C[i];
+    const unsigned long long b = __ballot(c);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) ws[w] = __popcll(b);
+    __syncthreads();
+    if (!c) return;
+    int k = blk_off[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+    for (int q = 0; q < w; ++q) k += ws[q];
+    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
+    map[k] = (int32_t)(((int64_t)z * r + y) * r + x);
+    const f3 p = lattice_world(r, x, y, z);          // == batch_eval's mapping of (coords * stride), bit for bit (quotients of the same rationals)
+    pts[3 * (int64_t)k] = p.x; pts[3 * (int64_t)k + 1] = p.y; pts[3 * (int64_t)k + 2] = p.z;
+    blk_flag[((int64_t)(z >> 2) * nbk + (y >> 2)) * nbk + (x >> 2)] = 1;
+}
+
+__global__ __launch_bounds__(256) void k_ad_blocks(const uint8_t *__restrict__ blk_flag, int nblocks, int32_t *__restrict__ list, int *n_blocks)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nblocks && blk_flag[i]) list[atomicAdd(n_blocks, 1)] = i;          // any order: the blocks are independent
+}
+
+// the exact nearest triangle of every lattice point of the listed 4x4x4 blocks (one wavefront per block, the packet traversal)
+__global__ __launch_bounds__(256) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list, const int *__restrict__ n_blocks,
+                                                   NearRef near, float sdf_clip)
+{
+    __shared__ int lds[4 * kStackDepth];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = *n_blocks;
+    for (int b = blockIdx.x * 4 + wave; b < nb; b += gridDim.x * 4) {
+        const int blk = list[b];
+        const int bx = blk % nbk, by = (blk / nbk) % nbk, bz = blk / (nbk * nbk);
+        const int ix = bx * 4 + (lane & 3), iy = by * 4 + ((lane >> 2) & 3), iz = bz * 4 + (lane >> 4);
+        const bool live = ix < r && iy < r && iz < r;
+        const int cx = min(ix, r - 1), cy = min(iy, r - 1), cz = min(iz, r - 1);
+        const f3 p = lattice_world(r, cx, cy, cz);
+        const Nearest nr = nearest_packet(m, p, live, lds + wave * kStackDepth);
+        if (live) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
+    }
+}
+
+// voxels evaluated up to and including this level
+__global__ __launch_bounds__(256) void k_ad_done(const uint8_t *__restrict__ C, const uint8_t *__restrict__ Dprev, int rp, uint8_t *__restrict__ D, int r)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (int64_t)r * r * r) return;
+    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
+    bool d = C[i] != 0;
+    if (!d && !((x | y | z) & 1)) d = Dprev ? Dprev[xyz(rp, x >> 1, y >> 1, z >> 1)] != 0 : true;
+    D[i] = d ? 1 : 0;
+}
+
+template <class T>
+int grow(T **p, size_t n)
+{
+    (void)hipFree(*p); *p = nullptr;
+    ICON_HIP(hipMalloc((void **)p, n * sizeof(T)));
+    return ICON_OK;
+}
+
+}  // namespace
+}  // namespace icon
+
+using namespace icon;
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// C ABI: the whole schedule.  resolutions[n_levels] ascending, odd, each 2 r - 1 of the one before; the standard box
+// (b_min = [-1,1,-1], b_max = [1,-1,1]), align_corners=True, identity calibration - the reconEngine of apps/ICON.py:78-90.
+// d_out [res_last^3] receives the final volume ([z][y][x]); h_counts (optional, host) is filled AFTER a stream
+// synchronisation with the points queried per level and h_counts[n_levels] = 1 when some voxel of the coarsest level
+// exceeds 0.5 (else the reference returns None) - pass NULL to stay asynchronous and read them later with
+// icon_adaptive_counts.
+// ---------------------------------------------------------------------------------------------------------------------------
+extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp, int prior_type, float sdf_clip,
+                                  int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
+                                  int search, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(feat && mlp && work && resolutions && d_out, "icon_adaptive_eval: null argument");
+    ICON_ARG(n_levels >= 1 && n_levels <= kAdMaxLevels, "icon_adaptive_eval: 1..8 levels");
+    ICON_ARG(prior_type != ICON_PRIOR_ICON || mesh != nullptr, "icon_adaptive_eval: the icon prior needs a mesh");
+    if (precision != ICON_PRECISION_F16X3 || search != ICON_SEARCH_BVH)
+        return fail(ICON_ERR_UNSUPPORTED, "icon_adaptive_eval: the fused f16x3 path with the BVH search only (other settings: the host-driven schedule)");
+    if (work->tie_rule != 0) return fail(ICON_ERR_UNSUPPORTED, "icon_adaptive_eval: diagnostics tie rule set on this workspace");
+    for (int l = 0; l < n_levels; ++l) {
+        ICON_ARG(resolutions[l] >= 3 && (resolutions[l] & 1), "icon_adaptive_eval: resolutions must be odd and >= 3 (seg3d_lossless.py:84-86)");
+        ICON_ARG(l == 0 || resolutions[l] == 2 * resolutions[l - 1] - 1, "icon_adaptive_eval: every level must be 2 r - 1 of the one before");
+    }
+    ICON_ARG((int64_t)resolutions[n_levels - 1] * resolutions[n_levels - 1] * resolutions[n_levels - 1] < (1ll << 31), "icon_adaptive_eval: lattice too large");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+
+    // ---- level buffers (allocated once per schedule) ----------------------------------------------------------------
+    icon_adaptive *a = work->ad;
+    bool same = a && a->n_levels == n_levels;
+    for (int l = 0; same && l < n_levels; ++l) same = a->res[l] == resolutions[l];
+    if (!same) {
+        adaptive_destroy(a);
+        work->ad = a = new icon_adaptive();
+        a->n_levels = n_levels;
+        for (int l = 0; l < n_levels; ++l) a->res[l] = resolutions[l];
+        const int rq = n_levels >= 2 ? resolutions[n_levels - 2] : resolutions[0];      // the largest level that is queried / masked
+        a->cap = (int64_t)rq * rq * rq;
+        for (int l = 0; l + 1 < n_levels; ++l) {
+            const size_t n = (size_t)resolutions[l] * resolutions[l] * resolutions[l];
+            if ((rc = grow(&a->occ[l], n))) return rc;
+            if (l >= 1 && (rc = grow(&a->D[l], n))) return rc;
+        }
+        const int nbk = (rq + 3) / 4;
+        if ((rc = grow(&a->P, (size_t)a->cap)) || (rc = grow(&a->M0, (size_t)a->cap)) || (rc = grow(&a->M1, (size_t)a->cap)) ||
+            (rc = grow(&a->map, (size_t)a->cap)) || (rc = grow(&a->pts, (size_t)a->cap * 3)) ||
+            (rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256)) || (rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256)) ||
+            (rc = grow(&a->blk_flag, (size_t)nbk * nbk * nbk)) || (rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk)) ||
+            (rc = grow(&a->counters, (size_t)16)))
+            return rc;
+    }
+    a->occ[n_levels - 1] = d_out;
+    ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
+
+    // ---- level 0: the coarsest lattice, dense, ONE call ---------------------------------------------------------------
+    const int r0 = resolutions[0];
+    float *occ0 = a->occ[0];
+    work->q_map = nullptr; work->q_n_dev = nullptr;
+    if ((rc = icon_grid_eval_slab(mesh, feat, mlp, prior_type, sdf_clip, cmap_mode, r0, 0, r0, occ0, search, precision, work, stream))) return rc;
+    {
+        const int64_t n0 = (int64_t)r0 * r0 * r0;
+        hipLaunchKernelGGL(k_ad_pbits, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, occ0, r0, balance, a->P, a->counters + 9);
+    }
+
+    const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int l = 1; l < n_levels; ++l) {
+        const int r = resolutions[l], rp = resolutions[l - 1];
+        const int64_t n = (int64_t)r * r * r;
+        const unsigned nbv = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(k_ad_up, dim3(nbv), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r);
+        if (l == n_levels - 1) break;                           // "last step no examine": interpolate only
+        // P holds (occ_{l-1} > balance): level 0's from above, later levels' from the end of the previous iteration
+        hipLaunchKernelGGL(k_ad_boundary, dim3(nbv), dim3(256), 0, st, a->P, rp, a->M0, r);
+        const int rad = l == 1 ? 4 : (l == 2 ? 3 : 1);           // SmoothConv3D 9 / 7 / 3 (seg3d_lossless.py:105-112, 219-226)
+        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 0, rad, 0, (const uint8_t *)nullptr, rp);
+        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M1, a->M0, r, 1, rad, 0, (const uint8_t *)nullptr, rp);
+        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 2, rad, 1, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp);
+        uint8_t *C = a->M1;
+        const int nbk = (r + 3) / 4, nblocks = nbk * nbk * nbk;
+        ICON_HIP(hipMemsetAsync(a->blk_flag, 0, (size_t)nblocks, st));
+        hipLaunchKernelGGL(k_ad_count, dim3(nbv), dim3(256), 0, st, C, n, a->blk_count);
+        hipLaunchKernelGGL(k_ad_scan, dim3(1), dim3(1024), 0, st, a->blk_count, (int)nbv, a->blk_off, a->counters + l);
+        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts, a->blk_flag, nbk);
+        ICON_HIP(hipGetLastError());
+        debug_sync("adaptive: upsample + boundary + dilate + compact", st);
+        // ---- the level's query: ONE call over the compacted points (count on the device) ---------------------------------
+        if ((rc = ensure_work_points(work, std::max<int64_t>(n, 1)))) return rc;      // near arrays by lattice index, codes / signs by call index
+        work->q_map = a->map; work->q_n_dev = a->counters + l;
+        Calib cal;
+        memcpy(cal.m, ident, sizeof(ident)); cal.d = nullptr;
+        const bool icon = prior_type == ICON_PRIOR_ICON;
+        const bool needs_list = icon && cmap_mode == ICON_CMAP_REFERENCE && (feat->dev.smpl_mask & kSmplCmap);
+        if (icon) {
+            if (mesh->F > kNearLoSlots && work->cap_points_hi < work->cap_points) {
+                (void)hipFree(work->d_near_hi); work->d_near_hi = nullptr; work->cap_points_hi = 0;
+                ICON_HIP(hipMalloc((void **)&work->d_near_hi, (size_t)work->cap_points));
+                work->cap_points_hi = work->cap_points;
+            }
+            ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
+            NearRef raw = work_near(work, mesh);
+            raw.map = nullptr;                                   // the search writes by lattice index
+            int n_cu = 0;
+            if ((rc = device_cu_count(&n_cu))) return rc;
+            hipLaunchKernelGGL(k_ad_nearest, dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
+            ICON_HIP(hipGetLastError());
+            debug_sync("adaptive: k_ad_nearest", st);
+            if ((rc = launch_sign(mesh, cal, r, 0, a->pts, n, sdf_clip, work, false, st))) return rc;
+            if (needs_list && (rc = outlier_list_dev(work, a->counters + l, n, st))) return rc;
+        }
+        FusedSigns fs{};
+        fs.mode = needs_list ? kSignSelf : kSignNone;
+        fs.list = work->d_signs; fs.k_dev = work->d_total;
+        LatticeMap L{};
+        rc = launch_fused_f16x3(mesh, feat, mlp, prior_type, cal, L, 0, 0, a->pts, n, sdf_clip, cmap_mode == ICON_CMAP_LOCAL ? 1 : 0, work, fs,
+                                a->occ[l], false, st);
+        work->q_map = nullptr; work->q_n_dev = nullptr;
+        if (rc) return rc;
+        debug_sync("adaptive: sign + list + fused", st);
+        // ---- bookkeeping for the next level -------------------------------------------------------------------------------
+        if (l + 1 < n_levels - 1) {                              // a further queried level follows
+            hipLaunchKernelGGL(k_ad_done, dim3(nbv), dim3(256), 0, st, C, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp, a->D[l], r);
+            hipLaunchKernelGGL(k_ad_pbits, dim3(nbv), dim3(256), 0, st, a->occ[l], r, balance, a->P, (int *)nullptr);
+        }
+        ICON_HIP(hipGetLastError());
+    }
+    ICON_HIP(hipGetLastError());
+    if (h_counts) {
+        int host[16];
+        ICON_HIP(hipMemcpyAsync(host, a->counters, sizeof(host), hipMemcpyDeviceToHost, st));
+        ICON_HIP(hipStreamSynchronize(st));
+        for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
+        h_counts[0] = (int64_t)r0 * r0 * r0;                    // level 0 evaluates every voxel
+        h_counts[n_levels] = host[9];
+    }
+    return ICON_OK;
+}
+
+// the counters of the most recent icon_adaptive_eval on this workspace (synchronises the stream): points queried per level,
+// then 1 / 0 for "some voxel of the coarsest level exceeds 0.5"
+extern "C" int icon_adaptive_counts(icon_work_t *work, int n_levels, int64_t *h_counts, void *stream)
+{
+    ICON_ARG(work && work->ad && h_counts && n_levels == work->ad->n_levels, "icon_adaptive_counts: no matching icon_adaptive_eval on this workspace");
+    int host[16];
+    ICON_HIP(hipMemcpyAsync(host, work->ad->counters, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    ICON_HIP(hipStreamSynchronize((hipStream_t)stream));
+    for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
+    h_counts[0] = (int64_t)work->ad->res[0] * work->ad->res[0] * work->ad->res[0];
+    h_counts[n_levels] = host[9];
+    return ICON_OK;
+}

@@ -191,7 +191,9 @@ __device__ __forceinline__ float apply_last_op(float y, int last_op)
 // Hand-over of the nearest-triangle search to k_sign / the feature phase, structure of arrays: 16 bits per point - the low 15
 // bits of the triangle slot and, in bit 15, "outside the clip band" - plus, only for meshes with more than 32,768 slots (SMPL:
 // 17 k, SMPL-X: 26 k), a byte with the higher slot bits, plus d^2 for the points inside the band (geom_device.h: store_near).
-struct NearRef { uint16_t *lo; uint8_t *hi; float *d2; };
+// `map` (the adaptive schedule, adaptive.hip): the search ran on a lattice, the call's points are a SUBSET of it - entry of
+// point i = map[i] (its [z][y][x] linear index); null: entry of point i = i.
+struct NearRef { uint16_t *lo; uint8_t *hi; float *d2; const int32_t *map; };
 
 // where the fused kernel / the patch kernels find the outlier signs of the whole call (HGPIFuNet.py:303-305)
 enum { kSignNone = 0, kSignSelf = 1, kSignGlobal = 2, kSignSeg = 3 };
@@ -227,6 +229,7 @@ struct icon_feat {
     icon::FeatDev dev{};
 };
 
+struct icon_adaptive;
 struct icon_mlp {
     int c0 = 0;               // input channels (<= 15)
     int last_op = 0;          // ICON_LASTOP_*: applied to the network output before the in_cube mask (MLP.py:68-70)
@@ -255,6 +258,11 @@ int mesh_host_state_get(MeshDyn **h, hipEvent_t *ev);
 void mesh_host_state_put(MeshDyn *h, hipEvent_t ev);
 void mesh_bind_arena(icon_mesh *m, const MeshLayout &L);
 int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces, const float *d_cmap, const float *d_vis, hipStream_t st);
+// adaptive.hip
+void adaptive_destroy(icon_adaptive *a);
+// query_kernels.hip: the outlier sign list of a point-mode call whose size is known on the device only (*n_dev <= n_max)
+int outlier_list_dev(icon_work *w, const int *n_dev, int64_t n_max, hipStream_t st);
+int ensure_work_points(icon_work *w, int64_t n_points);
 // mc_device.hip
 struct McDevState;
 void mc_destroy(McDevState *s);
@@ -332,6 +340,11 @@ struct icon_work {
     const float *q_points = nullptr;
     int64_t q_N = 0;
     bool q_lattice = false, q_rows_ready = false;
+    // lattice-subset calls of the adaptive schedule (adaptive.hip): the number of points lives on the device (no read-back
+    // between the levels), the search results are indexed through q_map, the occupancies go to d_occ[q_map[i]]
+    const int32_t *q_map = nullptr;
+    const int *q_n_dev = nullptr;
+    struct icon_adaptive *ad = nullptr;   // level buffers of icon_adaptive_eval
     icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
     bool prof = false;
@@ -346,6 +359,7 @@ inline NearRef work_near(const icon_work *w, const icon_mesh *mesh)
     NearRef r;
     r.lo = w->d_near16; r.d2 = w->d_near_d2;
     r.hi = (mesh && mesh->F > kNearLoSlots) ? w->d_near_hi : nullptr;
+    r.map = w->q_map;
     return r;
 }
 }  // namespace icon

@@ -68,6 +68,8 @@ struct FusedGeom {
     int off, nx, zs;             //   work item q -> (off + q % nx, off + (q / nx) % nx, zs + q / nx^2), nx = res - 2 off
     const float *pts;            // point mode
     int64_t N;                   // work items of this launch
+    const int *n_dev;            // point mode, adaptive levels: the number of work items lives on the device (N is its upper bound)
+    const int32_t *out_map;      //   ... and point i's occupancy goes to out[out_map[i]]
     float sdf_clip;
     int cmap_local;
     NearRef near;                // icon prior: slot of the nearest triangle (k_nearest / k_nearest_coop), far flag, d^2 inside the clip band
@@ -88,9 +90,11 @@ template <bool LATTICE>
 __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int z0, const float *__restrict__ pts, int64_t N,
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
                                               NearRef near, uint8_t *__restrict__ code8,
-                                              int32_t *__restrict__ block_counts, unsigned long long *__restrict__ grp_mask, float far_box2)
+                                              int32_t *__restrict__ block_counts, unsigned long long *__restrict__ grp_mask, float far_box2,
+                                              const int *__restrict__ n_dev)
 {
     __shared__ int wsum[4];
+    if (n_dev) { N = *n_dev; if ((int64_t)blockIdx.x * 256 >= N) return; }      // the call's size is on the device (adaptive levels)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < N;
     uint32_t code = 0;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
     // reading anything; for the rest the search left a flag in the slot word
     const MeshDyn &d = *m.dyn;
     const bool far = box_dist2(d.box_lo[0], d.box_lo[1], d.box_lo[2], d.box_hi[0], d.box_hi[1], d.box_hi[2], p) > far_box2 || near_is_far(near, i);
-    code = far ? sign_code_far(p, ins) : sign_code(p, near.d2[i], ins, sdf_clip);
+    code = far ? sign_code_far(p, ins) : sign_code(p, near_d2(near, i), ins, sdf_clip);
     code8[i] = (uint8_t)code;
     }
     // outliers of this 256-point block == one tile of the fused kernel (kScanBlock): the count pass for free
@@ -185,7 +189,7 @@ __device__ __forceinline__ void icon_row(const FusedGeom &G, f3 p, int64_t i, fl
     const uint32_t code = G.code8[i];
     Nearest nr;
     nr.slot = near_slot_of(G.near, i); nr.face = 0;
-    nr.d2 = (code & kCodeOutlier) ? 0.0f : G.near.d2[i];    // an outlier's sdf is its sign
+    nr.d2 = (code & kCodeOutlier) ? 0.0f : near_d2(G.near, i);    // an outlier's sdf is its sign
     const SdfOut o = sdf_attrs(G.m, p, nr, (code & kCodeInside) != 0);
     float s = o.sdf;
     f3 cmv = o.cm;
@@ -282,6 +286,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     // 250-register vector budget of the MFMA chain
     K = uniform64(K); rank0 = uniform64(rank0);
 
+    if (G.n_dev) { G.N = *G.n_dev; if (G.N <= 0) return; }
     // every workgroup walks a CONTIGUOUS run of tiles: consecutive tiles share the cache lines at their common boundary
     // (a tile of interior rows does not end on a line) and the triangles / feature texels of neighbouring points, and a
     // workgroup stays on one XCD - interleaved over the grid, those lines were fetched into two L2s (105 vs 91 MB of HBM
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const int64_t oq = tile * kTilePts + pt;
         if (h == 0 && oq < G.N) {
             int ix, iy, iz;
-            out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : oq] = masked_result(y, maskf != 0.0f, w.flag);
+            out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : (G.out_map ? (int64_t)G.out_map[oq] : oq)] = masked_result(y, maskf != 0.0f, w.flag);
         }
     }
 }
@@ -378,13 +383,14 @@ __global__ __launch_bounds__(64) void k_rescue_fused(FusedGeom G, float *__restr
 {
     __shared__ float s[kPlainLds];
     if (!always && *flag == 0) return;                        // the usual case: one word read per workgroup of a small grid
+    if (G.n_dev) G.N = *G.n_dev;
     const int lane = threadIdx.x;
     int64_t K = 0, rank0 = 0;
     if (PRIOR == ICON_PRIOR_ICON) sign_list_extent(G, K, rank0);
     for (int64_t base = (int64_t)blockIdx.x * 64; base < G.N; base += (int64_t)gridDim.x * 64) {
         const int64_t q = base + lane;
         int ix, iy, iz;
-        const int64_t o = q < G.N ? (LATTICE ? lattice_item(G, q, ix, iy, iz) : q) : 0;
+        const int64_t o = q < G.N ? (LATTICE ? lattice_item(G, q, ix, iy, iz) : (G.out_map ? (int64_t)G.out_map[q] : q)) : 0;
         const float v = q < G.N ? out[o] : 0.0f;
         unsigned long long todo = __ballot(not_finite(v));
         while (todo) {
@@ -425,10 +431,10 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
     const float far_box2 = far_box_dist2(sdf_clip);
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
                                     work->d_row_count, work->d_row_slots, work_near(work, mesh), work->d_code8, work->d_block_counts,
-                                    (unsigned long long *)work->d_grp_mask, far_box2);
+                                    (unsigned long long *)work->d_grp_mask, far_box2, (const int *)nullptr);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
                             (const int32_t *)nullptr, (const int32_t *)nullptr, work_near(work, mesh), work->d_code8, work->d_block_counts,
-                            (unsigned long long *)work->d_grp_mask, far_box2);
+                            (unsigned long long *)work->d_grp_mask, far_box2, work->q_n_dev);
     ICON_HIP(hipGetLastError());
     return ICON_OK;
 }
@@ -496,6 +502,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     ICON_ARG(N < (1ll << 31), "fused: more than 2^31 points in one call");
     G.N = N;
     G.near = work_near(work, mesh); G.code8 = work->d_code8;
+    if (!lattice) { G.n_dev = work->q_n_dev; G.out_map = work->q_map; }
     G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;

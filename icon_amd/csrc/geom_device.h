@@ -898,11 +898,15 @@ __device__ __forceinline__ void store_near(const NearRef &r, int64_t i, const Ne
     if (r.hi) r.hi[i] = (uint8_t)((uint32_t)nr.slot >> 15);   // wave-uniform: meshes with more than 32,768 slots only
     if (!far) r.d2[i] = nr.d2;
 }
-__device__ __forceinline__ bool near_is_far(const NearRef &r, int64_t i) { return (r.lo[i] & kNearFar) != 0; }
+// readers take the index of the point IN ITS CALL; a lattice-subset call (NearRef::map) finds its entry through the map
+__device__ __forceinline__ int64_t near_index(const NearRef &r, int64_t i) { return r.map ? (int64_t)r.map[i] : i; }
+__device__ __forceinline__ bool near_is_far(const NearRef &r, int64_t i) { return (r.lo[near_index(r, i)] & kNearFar) != 0; }
+__device__ __forceinline__ float near_d2(const NearRef &r, int64_t i) { return r.d2[near_index(r, i)]; }
 __device__ __forceinline__ int near_slot_of(const NearRef &r, int64_t i)
 {
-    uint32_t s = (uint32_t)r.lo[i] & 0x7fffu;
-    if (r.hi) s |= (uint32_t)r.hi[i] << 15;
+    const int64_t e = near_index(r, i);
+    uint32_t s = (uint32_t)r.lo[e] & 0x7fffu;
+    if (r.hi) s |= (uint32_t)r.hi[e] << 15;
     return (int)s;
 }
 // code byte of a point flagged kNearFar: what sign_code returns for |s| >= sdf_clip, s = +-dist, dist > 0

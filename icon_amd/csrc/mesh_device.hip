@@ -46,7 +46,7 @@ struct BuildCtx {
     int32_t *valence; uint8_t *leaf_cnt; BTask *tasks; uint32_t *hist; int32_t *cell_count, *cell_cursor;
     float *vnormals; BvhNode *nodes; LeafRec *leaves; TriRec *tris; TriAttr *attr; int32_t *slot2face, *face2slot;
     int32_t *bin_start, *bin_slots;
-    float *tbox, *cen; int32_t *order[2]; int32_t *adj; int32_t *chunkcnt; int32_t *subq; struct STask *sublist;
+    float *tbox, *cen; int32_t *order[2]; int32_t *adj; int32_t *chunkcnt; int32_t *subq; struct STask *sublist; uint32_t *bounds_part;
     int32_t nck; int64_t cells_cap, entries_cap;
 };
 
@@ -60,9 +60,15 @@ __device__ __forceinline__ float dec(uint32_t u) { return __uint_as_float((u & 0
 __device__ __forceinline__ uint32_t enc_min(float f) { return ~enc(f); }
 __device__ __forceinline__ float dec_min(uint32_t u) { return dec(~u); }
 
+// lanes of ONE wavefront hand data to each other through LDS: the LDS operations of a wave complete in order, so all that is
+// needed is their completion and a compiler barrier.  (A workgroup-scope fence also waits for the wave's outstanding GLOBAL
+// stores - the node links and leaf records of the node before - 1-2 us each time: ~190 us of k_bvh_sub.)  GLOBAL = true: the
+// data itself lives in global memory (subtrees too large for LDS): wait for those too.
+template <bool GLOBAL = false>
 __device__ __forceinline__ void wave_sync()
 {
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (GLOBAL) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -104,7 +110,9 @@ __global__ __launch_bounds__(256) void k_face_prep(BuildCtx c)
             }
         if (bf | bv) atomicOr(&c.dyn->status, (bf ? kMeshBadFace : 0) | (bv ? kMeshBadVertex : 0));
     }
-    // mesh bounds: wave reduction, one atomic per value and wave
+    // mesh bounds: wave reduction -> workgroup (LDS) -> this workgroup's row of the partial array, plain stores (216 waves x 12
+    // atomics on ONE cache line took 30 us: same-line device atomics serialise at ~12 ns each); k_vertex_normals reduces the rows
+    __shared__ uint32_t s_part[4][12];
     uint32_t u[12];
     for (int a = 0; a < 3; ++a) {
         u[a] = live ? enc_min(lo[a]) : 0u; u[3 + a] = live ? enc(hi[a]) : 0u;
@@ -114,7 +122,13 @@ __global__ __launch_bounds__(256) void k_face_prep(BuildCtx c)
     for (int k = 0; k < 12; ++k) {
         uint32_t v = u[k];
         for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = v > o ? v : o; }
-        if ((threadIdx.x & 63) == 0 && v) atomicMax(&c.hdr->mesh_ubox[k], v);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 12) {
+        const uint32_t a0 = s_part[0][threadIdx.x], a1 = s_part[1][threadIdx.x], a2 = s_part[2][threadIdx.x], a3 = s_part[3][threadIdx.x];
+        const uint32_t m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
+        c.bounds_part[(size_t)blockIdx.x * 12 + threadIdx.x] = m01 > m23 ? m01 : m23;
     }
 }
 
@@ -134,12 +148,29 @@ __device__ __forceinline__ void face_normal(const BuildCtx &c, int f, float n[3]
 __global__ __launch_bounds__(256) void k_vertex_normals(BuildCtx c)
 {
     const int v = blockIdx.x * 256 + threadIdx.x;
+    __shared__ uint32_t s_red[256];
+    if (blockIdx.x == 0) {
+        // workgroup 0 first reduces the per-workgroup bounds of k_face_prep (12 maxima over nbF rows)
+        const int nbF = (c.F + 255) / 256;
+        const int k = threadIdx.x % 12, r0 = threadIdx.x / 12;             // 21 row groups x 12 values (threads 252..255 idle)
+        uint32_t m = 0;
+        if (threadIdx.x < 252)
+            for (int r = r0; r < nbF; r += 21) { const uint32_t x = c.bounds_part[(size_t)r * 12 + k]; m = x > m ? x : m; }
+        s_red[threadIdx.x] = m;
+        __syncthreads();
+        uint32_t mm = 0;
+        if (threadIdx.x < 12)
+            for (int g = 0; g < 21; ++g) { const uint32_t x = s_red[g * 12 + threadIdx.x]; mm = x > mm ? x : mm; }
+        __syncthreads();
+        if (threadIdx.x < 12) s_red[threadIdx.x] = mm;
+        __syncthreads();
+    }
     if (v == 0) {
         // the root task and what the query kernels need of the bounding box
         float box[6], cb[6];
         for (int a = 0; a < 3; ++a) {
-            box[a] = dec_min(c.hdr->mesh_ubox[a]); box[3 + a] = dec(c.hdr->mesh_ubox[3 + a]);
-            cb[a] = dec_min(c.hdr->mesh_ubox[6 + a]); cb[3 + a] = dec(c.hdr->mesh_ubox[9 + a]);
+            box[a] = dec_min(s_red[a]); box[3 + a] = dec(s_red[3 + a]);
+            cb[a] = dec_min(s_red[6 + a]); cb[3 + a] = dec(s_red[9 + a]);
         }
         BTask &r = c.tasks[0];
         r.begin = 0; r.end = c.F; r.depth = 0; r.parent = -1; r.side = 0; r.buf = 0; r.from_atomics = 0;
@@ -232,35 +263,58 @@ __device__ __forceinline__ void hist_add(uint32_t *h, const float lo[3], const f
 // writes the decision and the children's bounds to *D.
 __device__ __forceinline__ void sah_choose(const uint32_t *h, const float ext[3], int lane, Decision *D)
 {
-    const int ax = lane / 15, b = lane - ax * 15;
-    double cost = INFINITY;
-    float bl[2][6], cl[2][6];
-    int cnt[2] = {0, 0};
-    for (int s = 0; s < 2; ++s)
-        for (int k = 0; k < 3; ++k) { bl[s][k] = INFINITY; bl[s][3 + k] = -INFINITY; cl[s][k] = INFINITY; cl[s][3 + k] = -INFINITY; }
-    if (lane < 45 && ext[ax] > 0.0f) {
-        for (int k = 0; k < kSahBins; ++k) {
-            const uint32_t *q = h + (ax * kSahBins + k) * 13;
-            const int n = (int)q[0];
-            if (!n) continue;
-            const int s = k <= b ? 0 : 1;
-            cnt[s] += n;
-            for (int a = 0; a < 3; ++a) {
-                bl[s][a] = fminf(bl[s][a], dec_min(q[1 + a])); bl[s][3 + a] = fmaxf(bl[s][3 + a], dec(q[4 + a]));
-                cl[s][a] = fminf(cl[s][a], dec_min(q[7 + a])); cl[s][3 + a] = fmaxf(cl[s][3 + a], dec(q[10 + a]));
+    // lane = axis * 16 + bin (48 lanes): every lane loads ITS bin, inclusive prefix (bins 0..b) and suffix (bins b..15) unions by
+    // log-step scans inside the 16-lane rows; candidate b of an axis = prefix[b] | suffix[b + 1].  (A lane per candidate that
+    // walked all 16 bins cost ~4 us per node - most of k_bvh_sub, whose nodes are mostly small.)
+    const int ax = lane >> 4, b = lane & 15;
+    const bool cell = lane < 48;
+    const uint32_t *q = h + (cell ? lane : 0) * 13;
+    int pc = cell ? (int)q[0] : 0;
+    float pb[6], pcb[6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        pb[a] = (cell && pc) ? dec_min(q[1 + a]) : INFINITY; pb[3 + a] = (cell && pc) ? dec(q[4 + a]) : -INFINITY;
+        pcb[a] = (cell && pc) ? dec_min(q[7 + a]) : INFINITY; pcb[3 + a] = (cell && pc) ? dec(q[10 + a]) : -INFINITY;
+    }
+    int sc = pc;
+    float sb[6], scb[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { sb[k] = pb[k]; scb[k] = pcb[k]; }
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const bool up = b >= d, dn = b + d < 16;
+        const int uc = __shfl_up(pc, d, 16), dc = __shfl_down(sc, d, 16);
+        pc += up ? uc : 0; sc += dn ? dc : 0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float ub = __shfl_up(pb[k], d, 16), ucb = __shfl_up(pcb[k], d, 16);
+            const float db = __shfl_down(sb[k], d, 16), dcb = __shfl_down(scb[k], d, 16);
+            if (k < 3) {
+                pb[k] = up ? fminf(pb[k], ub) : pb[k]; pcb[k] = up ? fminf(pcb[k], ucb) : pcb[k];
+                sb[k] = dn ? fminf(sb[k], db) : sb[k]; scb[k] = dn ? fminf(scb[k], dcb) : scb[k];
+            } else {
+                pb[k] = up ? fmaxf(pb[k], ub) : pb[k]; pcb[k] = up ? fmaxf(pcb[k], ucb) : pcb[k];
+                sb[k] = dn ? fmaxf(sb[k], db) : sb[k]; scb[k] = dn ? fmaxf(scb[k], dcb) : scb[k];
             }
         }
-        if (cnt[0] && cnt[1]) cost = box_area(bl[0], bl[0] + 3) * cnt[0] + box_area(bl[1], bl[1] + 3) * cnt[1];
     }
+    // right side of candidate b: the suffix of bin b + 1
+    const int cr = __shfl_down(sc, 1, 16);
+    float Rb[6], Rc[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) { Rb[k] = __shfl_down(sb[k], 1, 16); Rc[k] = __shfl_down(scb[k], 1, 16); }
+    double cost = INFINITY;
+    const float ext_ax = ax == 0 ? ext[0] : (ax == 1 ? ext[1] : ext[2]);
+    if (cell && b < 15 && ext_ax > 0.0f && pc && cr) cost = box_area(pb, pb + 3) * pc + box_area(Rb, Rb + 3) * cr;
     double best = cost;
     for (int d = 1; d < 64; d <<= 1) { const double o = __shfl_xor(best, d); best = o < best ? o : best; }
     const unsigned long long win = __ballot(cost == best && cost < (double)INFINITY);
     if (!win) { if (lane == 0) D->valid = 0; return; }
-    const int w = __ffsll((long long)win) - 1;
+    const int w = __ffsll((long long)win) - 1;                 // the first minimum in (axis, bin) order, as the host's sweep finds it
     if (lane == w) {
-        D->valid = 1; D->axis = ax; D->bin = b; D->nleft = cnt[0];
-        for (int s = 0; s < 2; ++s)
-            for (int k = 0; k < 6; ++k) { D->cbox[s][k] = bl[s][k]; D->ccb[s][k] = cl[s][k]; }
+        D->valid = 1; D->axis = ax; D->bin = b; D->nleft = pc;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { D->cbox[0][k] = pb[k]; D->cbox[1][k] = Rb[k]; D->ccb[0][k] = pcb[k]; D->ccb[1][k] = Rc[k]; }
     }
 }
 
@@ -277,12 +331,18 @@ __device__ __forceinline__ void link_node(const BuildCtx &c, int parent, int sid
 // (disjoint for the tasks of one level: they are in position order and every task adds one to the base)
 __device__ __forceinline__ bool find_chunk(const BTask *T, int nslots, int w, int &slot, int &k)
 {
-    for (int s = 0; s < nslots; ++s) {
+    const int lane = threadIdx.x & 63;
+    int found = -1, fk = 0;
+    for (int s = lane; s < nslots; s += 64) {                  // every wave scans the (<= 2^kTopLevels) slots with its 64 lanes
         if (T[s].kind != 1) continue;
         const int base = T[s].begin / kChunk + s, nc = (T[s].end - T[s].begin + kChunk - 1) / kChunk;
-        if (w >= base && w < base + nc) { slot = s; k = w - base; return true; }
+        if (w >= base && w < base + nc) { found = s; fk = w - base; }
     }
-    return false;
+    const unsigned long long hit = __ballot(found >= 0);
+    if (!hit) return false;
+    const int src = __ffsll((long long)hit) - 1;              // at most one slot owns workgroup w
+    slot = __shfl(found, src); k = __shfl(fk, src);
+    return true;
 }
 
 __global__ __launch_bounds__(kChunk) void k_bvh_bin(BuildCtx c, int L)
@@ -301,7 +361,7 @@ __global__ __launch_bounds__(kChunk) void k_bvh_bin(BuildCtx c, int L)
     __syncthreads();
     const int i = k * kChunk + (int)threadIdx.x;
     if (i < n) {
-        const int e = c.order[L & 1][P.begin + i];
+        const int e = ((L & 1) ? c.order[1] : c.order[0])[P.begin + i];
         const float *ce = c.cen + 3 * (size_t)e, *tb = c.tbox + 6 * (size_t)e;
         hist_add(h, lo, ext, [&](int a) { return ce[a]; }, [&](int q) { return tb[q]; });
     }
@@ -331,9 +391,15 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
     task_bounds(P, box, cb);
     for (int a = 0; a < 3; ++a) { lo[a] = cb[a]; ext[a] = cb[3 + a] - cb[a]; }
     const bool forced = force_median(P.depth, n, c.bound);
+    __shared__ uint32_t s_hist[kHistWords];
+    if (!forced) {                                             // the node's finished histogram: one coalesced read into LDS
+        const uint32_t *g = c.hist + (size_t)((1 << L) - 1 + s) * kHistWords;
+        for (int q = threadIdx.x; q < kHistWords; q += kChunk) s_hist[q] = g[q];
+    }
+    __syncthreads();
     if (wave == 0) {
         if (forced) { if (lane == 0) D.valid = 0; }
-        else sah_choose(c.hist + (size_t)((1 << L) - 1 + s) * kHistWords, ext, lane, &D);
+        else sah_choose(s_hist, ext, lane, &D);
     }
     __syncthreads();
     const bool valid = D.valid != 0;
@@ -354,7 +420,7 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
     }
     const int i = k * kChunk + (int)threadIdx.x;
     const bool act = i < n;
-    const int e = act ? c.order[L & 1][P.begin + i] : 0;
+    const int e = act ? ((L & 1) ? c.order[1] : c.order[0])[P.begin + i] : 0;
     const bool isl = act && (valid ? sah_bin(c.cen[3 * (size_t)e + axis], lo[axis], ext[axis]) <= bin : i < nleft);
     const unsigned long long bl = __ballot(isl);
     if (lane == 0) s_wcnt[wave] = __popcll(bl);
@@ -364,7 +430,7 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
     const int loff = s_loff;
     if (act) {
         const int dest = isl ? P.begin + loff + lrank : P.begin + nleft + (k * kChunk - loff) + ((int)threadIdx.x - lrank);
-        c.order[(L + 1) & 1][dest] = e;
+        (((L + 1) & 1) ? c.order[1] : c.order[0])[dest] = e;
     }
     BTask *C = c.tasks + ((1 << (L + 1)) - 1) + 2 * s;
     if (!valid && act) {                                      // positional split: the children's bounds are not in a histogram
@@ -397,7 +463,7 @@ __global__ __launch_bounds__(kChunk) void k_bvh_part(BuildCtx c, int L)
 // level's list (one LDS atomic per child), a barrier, the lists swap.  (A first version handed nodes from wave to wave
 // through a lock-protected pool with sleeping pollers: correct, and 16-43 SECONDS per mesh - seven idle waves per
 // workgroup kept the lock busy around the clock.  No locks, no polling now.)
-constexpr int kSubWaves = 8;
+constexpr int kSubWaves = 16;
 constexpr int kListCap = 256;          // nodes of one level: every pending node holds >= 5 of the subtree's <= kSubMax triangles
 struct STask { int32_t begin, end, depth, parent, side, buf; float box[6], cb[6]; int32_t pad[2]; };
 static_assert(sizeof(STask) == 80, "STask layout");
@@ -411,10 +477,13 @@ struct SubLds {
     Decision dec[kSubWaves];
     STask list[2][kListCap];
     int count[2];
+    int n_nodes, n_leaves, depth;      // this subtree's share of the statistics: ONE global atomic each at the end (13,500
+                                       // fire-and-forget atomics on one cache line of MeshDyn were ~160 us of the kernel)
 };
 
 // element access of a subtree: LDS-resident (local ids) or in global memory (face ids; a subtree too large for LDS)
 struct LdsAcc {
+    static constexpr bool kGlobal = false;
     SubLds *S; int sb;
     __device__ __forceinline__ int get(int buf, int pos) const { return S->ord[buf][pos - sb]; }
     __device__ __forceinline__ void put(int buf, int pos, int j) const { S->ord[buf][pos - sb] = (uint16_t)j; }
@@ -423,24 +492,25 @@ struct LdsAcc {
     __device__ __forceinline__ int face(int j) const { return S->gid[j]; }
 };
 struct GlbAcc {
+    static constexpr bool kGlobal = true;
     int32_t *ord[2]; const float *c3; const float *b6;
-    __device__ __forceinline__ int get(int buf, int pos) const { return ord[buf][pos]; }
-    __device__ __forceinline__ void put(int buf, int pos, int j) const { ord[buf][pos] = j; }
+    __device__ __forceinline__ int get(int buf, int pos) const { return (buf ? ord[1] : ord[0])[pos]; }
+    __device__ __forceinline__ void put(int buf, int pos, int j) const { (buf ? ord[1] : ord[0])[pos] = j; }
     __device__ __forceinline__ float cen(int j, int a) const { return c3[3 * (size_t)j + a]; }
     __device__ __forceinline__ float tb(int j, int q) const { return b6[6 * (size_t)j + q]; }
     __device__ __forceinline__ int face(int j) const { return j; }
 };
 
 template <class A>
-__device__ __forceinline__ void finalize_leaf(const BuildCtx &c, const A &acc, const STask &t, int lane)
+__device__ __forceinline__ void finalize_leaf(const BuildCtx &c, const A &acc, SubLds *S, const STask &t, int lane)
 {
     const int n = t.end - t.begin;
     if (lane < n) c.slot2face[t.begin + lane] = acc.face(acc.get(t.buf, t.begin + lane));
     if (lane == 0) {
         c.leaf_cnt[t.begin] = (uint8_t)n;
         link_node(c, t.parent, t.side, ~((t.begin << 2) | (n - 1)), t.box);
-        atomicAdd(&c.dyn->n_leaves, 1);
-        atomicMax(&c.dyn->depth, t.depth);
+        atomicAdd(&S->n_leaves, 1);
+        atomicMax(&S->depth, t.depth);
     }
 }
 
@@ -467,24 +537,24 @@ __device__ __forceinline__ void range_bounds(const A &acc, int buf, int a, int b
 // one node by one wavefront: a leaf is finished, anything else is split and its children that are not leaves are handed
 // to `emit` (all lanes call it with the same task)
 template <class A, class Emit>
-__device__ __forceinline__ void process_node(const BuildCtx &c, const A &acc, uint32_t *h /* LDS, this wave's */, Decision *D /* LDS, this wave's */,
+__device__ __forceinline__ void process_node(const BuildCtx &c, const A &acc, SubLds *S, uint32_t *h /* LDS, this wave's */, Decision *D /* LDS, this wave's */,
                                              const STask &t, int lane, Emit emit)
 {
     const int n = t.end - t.begin;
-    if (n <= kLeafMax) { finalize_leaf(c, acc, t, lane); return; }
+    if (n <= kLeafMax) { finalize_leaf(c, acc, S, t, lane); return; }
     float lo[3], ext[3];
     for (int a = 0; a < 3; ++a) { lo[a] = t.cb[a]; ext[a] = t.cb[3 + a] - t.cb[a]; }
     bool valid = false;
     if (!force_median(t.depth, n, c.bound) && (ext[0] > 0.0f || ext[1] > 0.0f || ext[2] > 0.0f)) {
         for (int i = lane; i < kHistWords; i += 64) h[i] = 0;
-        wave_sync();
+        wave_sync<A::kGlobal>();
         for (int i = lane; i < n; i += 64) {
             const int j = acc.get(t.buf, t.begin + i);
             hist_add(h, lo, ext, [&](int a) { return acc.cen(j, a); }, [&](int q) { return acc.tb(j, q); });
         }
-        wave_sync();
+        wave_sync<A::kGlobal>();
         sah_choose(h, ext, lane, D);
-        wave_sync();
+        wave_sync<A::kGlobal>();
         valid = D->valid != 0;
     }
     int nleft, cbuf;
@@ -496,11 +566,12 @@ __device__ __forceinline__ void process_node(const BuildCtx &c, const A &acc, ui
             for (int k = 0; k < 6; ++k) { cbox[s][k] = D->cbox[s][k]; ccb[s][k] = D->ccb[s][k]; }
         int lb = 0, rb = nleft;
         const unsigned long long lt = (1ull << lane) - 1ull;
+        const float lo_ax = axis == 0 ? lo[0] : (axis == 1 ? lo[1] : lo[2]), ext_ax = axis == 0 ? ext[0] : (axis == 1 ? ext[1] : ext[2]);
         for (int i0 = 0; i0 < n; i0 += 64) {
             const int i = i0 + lane;
             const bool act = i < n;
             const int j = act ? acc.get(t.buf, t.begin + i) : 0;
-            const bool isl = act && sah_bin(acc.cen(j, axis), lo[axis], ext[axis]) <= bin;
+            const bool isl = act && sah_bin(acc.cen(j, axis), lo_ax, ext_ax) <= bin;
             const unsigned long long bl = __ballot(isl), br = __ballot(act && !isl);
             if (isl) acc.put(t.buf ^ 1, t.begin + lb + __popcll(bl & lt), j);
             else if (act) acc.put(t.buf ^ 1, t.begin + rb + __popcll(br & lt), j);
@@ -508,21 +579,21 @@ __device__ __forceinline__ void process_node(const BuildCtx &c, const A &acc, ui
         }
         if (lb != nleft && lane == 0) atomicOr(&c.dyn->status, kMeshInternal);
         cbuf = t.buf ^ 1;
-        wave_sync();
+        wave_sync<A::kGlobal>();
     } else {
         nleft = n / 2; cbuf = t.buf;
         range_bounds(acc, t.buf, t.begin, t.begin + nleft, lane, cbox[0], ccb[0]);
         range_bounds(acc, t.buf, t.begin + nleft, t.end, lane, cbox[1], ccb[1]);
     }
     const int mid = t.begin + nleft, id = mid - 1;
-    if (lane == 0) { link_node(c, t.parent, t.side, id, t.box); atomicAdd(&c.dyn->n_nodes, 1); }
+    if (lane == 0) { link_node(c, t.parent, t.side, id, t.box); atomicAdd(&S->n_nodes, 1); }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         STask ch;
         ch.begin = s ? mid : t.begin; ch.end = s ? t.end : mid; ch.depth = t.depth + 1; ch.parent = id; ch.side = s; ch.buf = cbuf;
         for (int k = 0; k < 6; ++k) { ch.box[k] = cbox[s][k]; ch.cb[k] = ccb[s][k]; }
         ch.pad[0] = ch.pad[1] = 0;
-        if (ch.end - ch.begin <= kLeafMax) finalize_leaf(c, acc, ch, lane);
+        if (ch.end - ch.begin <= kLeafMax) finalize_leaf(c, acc, S, ch, lane);
         else emit(ch);
     }
 }
@@ -533,19 +604,21 @@ template <class A>
 __device__ __forceinline__ void sub_levels(const BuildCtx &c, const A &acc, SubLds *S, STask *list0, STask *list1, int cap,
                                            int wave, int lane, int nwaves)
 {
-    STask *lists[2] = {list0, list1};
     for (int lv = 0;; ++lv) {
         __syncthreads();                                       // the level's list is complete, the other count is 0
         const int cur = lv & 1, nc = S->count[cur];
         if (nc == 0) break;
+        // (selected, not indexed: a two-entry pointer array indexed by `cur` lives in scratch memory - a global-memory
+        //  round trip per access, several per node)
+        STask *const lcur = cur ? list1 : list0, *const lnext = cur ? list0 : list1;
         for (int i = wave; i < nc; i += nwaves) {
-            const STask t = lists[cur][i];                     // (a plain struct copy: punning it through int* broke under strict aliasing)
-            process_node(c, acc, S->hist[wave], &S->dec[wave], t, lane, [&](const STask &ch) {
+            const STask t = lcur[i];                     // (a plain struct copy: punning it through int* broke under strict aliasing)
+            process_node(c, acc, S, S->hist[wave], &S->dec[wave], t, lane, [&](const STask &ch) {
                 int idx = 0;
                 if (lane == 0) idx = atomicAdd(&S->count[cur ^ 1], 1);
                 idx = __builtin_amdgcn_readfirstlane(idx);
                 if (idx < cap) {
-                    if (lane == 0) lists[cur ^ 1][idx] = ch;
+                    if (lane == 0) lnext[idx] = ch;
                 } else if (lane == 0) {
                     atomicOr(&c.dyn->status, kMeshInternal);
                 }
@@ -573,10 +646,11 @@ __global__ __launch_bounds__(kSubWaves * 64) void k_bvh_sub(BuildCtx c)
         r.pad[0] = r.pad[1] = 0;
         (in_lds ? S->list[0] : c.sublist + (size_t)(T.begin / 5) * 2)[0] = r;
         S->count[0] = 1; S->count[1] = 0;
+        S->n_nodes = 0; S->n_leaves = 0; S->depth = 0;
     }
     if (in_lds) {
         for (int i = threadIdx.x; i < n; i += kSubWaves * 64) {
-            const int e = c.order[T.buf][T.begin + i];
+            const int e = (T.buf ? c.order[1] : c.order[0])[T.begin + i];
             S->gid[i] = e; S->ord[0][i] = (uint16_t)i;
             for (int a = 0; a < 3; ++a) S->cen[i * 3 + a] = c.cen[3 * (size_t)e + a];
             for (int q = 0; q < 6; ++q) S->tbox[i * 6 + q] = c.tbox[6 * (size_t)e + q];
@@ -590,6 +664,11 @@ __global__ __launch_bounds__(kSubWaves * 64) void k_bvh_sub(BuildCtx c)
         STask *base = c.sublist + (size_t)(T.begin / 5) * 2;
         const int cap = n / 5;                                  // pending nodes hold >= 5 triangles each; 2 * cap entries fit the slice
         sub_levels(c, acc, S, base, base + cap, cap, wave, lane, kSubWaves);
+    }
+    if (threadIdx.x == 0) {                                     // (sub_levels ends behind a barrier: the counts are final)
+        if (S->n_nodes) atomicAdd(&c.dyn->n_nodes, S->n_nodes);
+        atomicAdd(&c.dyn->n_leaves, S->n_leaves);
+        atomicMax(&c.dyn->depth, S->depth);
     }
 }
 
@@ -642,49 +721,83 @@ __global__ __launch_bounds__(256) void k_tri_records(BuildCtx c)
         for (int cy = cy0; cy <= cy1; ++cy) atomicAdd(&c.cell_count[(size_t)cz * g.gy + cy], 1);
 }
 
-// exclusive scan of the cell counts by one workgroup (every thread a contiguous segment)
+// exclusive scan of the cell counts by one workgroup: tiles of 4,096 cells (four per thread, coalesced), a running carry
 __global__ __launch_bounds__(1024) void k_scan_cells(BuildCtx c)
 {
-    __shared__ int64_t wtot[16];
-    __shared__ int64_t s_base[1024];
+    __shared__ int wtot[16];
     const BinGrid g = grid_of(c);
     const int n = g.gy * g.gz;
-    const int seg = (n + 1023) / 1024;
-    const int a = min((int)threadIdx.x * seg, n), b = min(a + seg, n);
-    int64_t sum = 0;
-    for (int i = a; i < b; ++i) sum += c.cell_count[i];
-    // block exclusive scan of the 1024 partial sums
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int64_t incl = sum;
-    for (int d = 1; d < 64; d <<= 1) { const int64_t up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-    if (lane == 63) wtot[w] = incl;
-    __syncthreads();
-    int64_t base = 0, all = 0;
-    for (int q = 0; q < 16; ++q) { const int64_t t = wtot[q]; if (q < w) base += t; all += t; }
-    s_base[threadIdx.x] = base + incl - sum;
-    __syncthreads();
-    const bool fits = all <= c.entries_cap;
-    int64_t run = s_base[threadIdx.x];
-    for (int i = a; i < b; ++i) { c.bin_start[i] = fits ? (int32_t)run : 0; run += c.cell_count[i]; }
+    int64_t carry = 0;
+    for (int base = 0; base < n; base += 4096) {
+        const int i = base + (int)threadIdx.x * 4;
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (i + k < n) ? c.cell_count[i + k] : 0;
+        const int mine = v[0] + v[1] + v[2] + v[3];
+        int incl = mine;
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        __syncthreads();                                       // (the previous tile's wtot has been read)
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        int before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const int t = wtot[q]; before += q < w ? t : 0; all += t; }
+        int64_t run = carry + before + incl - mine;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { if (i + k < n) c.bin_start[i + k] = (int32_t)run; run += v[k]; }
+        carry += all;
+    }
+    const bool fits = carry <= c.entries_cap;
+    __syncthreads();                                           // (every thread has written its last tile)
+    if (!fits)                                                  // as the host build: no lists at all (brute-force parity count)
+        for (int i = threadIdx.x; i <= n; i += 1024) c.bin_start[i] = 0;
     if (threadIdx.x == 0) {
-        c.bin_start[n] = fits ? (int32_t)all : 0;
-        c.dyn->bin_entries = fits ? (int32_t)all : 0;
+        if (fits) c.bin_start[n] = (int32_t)carry;
+        c.dyn->bin_entries = fits ? (int32_t)carry : 0;
         if (!fits) { c.dyn->gy = 0; c.dyn->gz = 0; atomicOr(&c.dyn->status, kMeshBinOverflow); }
     }
 }
 
 __global__ __launch_bounds__(256) void k_bin_fill(BuildCtx c)
 {
-    const int p = blockIdx.x * 256 + threadIdx.x;
+    // eight threads per triangle, the cells of its range dealt round-robin: ~3 returning atomics in a row per thread, not ~19
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int p = t >> 3, sub = t & 7;
     if (p >= c.F || (c.dyn->status & kMeshBinOverflow)) return;
     const BinGrid g = grid_of(c);
     int cy0, cy1, cz0, cz1;
     cell_range(g, c.tbox + 6 * (size_t)c.slot2face[p], cy0, cy1, cz0, cz1);
+    int q = 0;
     for (int cz = cz0; cz <= cz1; ++cz)
-        for (int cy = cy0; cy <= cy1; ++cy) {
+        for (int cy = cy0; cy <= cy1; ++cy, ++q) {
+            if ((q & 7) != sub) continue;
             const size_t cell = (size_t)cz * g.gy + cy;
             c.bin_slots[c.bin_start[cell] + atomicAdd(&c.cell_cursor[cell], 1)] = p;
         }
+}
+
+template <int N>
+__device__ __forceinline__ void sort_regs(int32_t *q, int len)
+{
+    int v[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = k < len ? q[k] : 0x7fffffff;
+    // Batcher's odd-even mergesort: every index below is a compile-time constant after unrolling
+#pragma unroll
+    for (int p = 1; p < N; p <<= 1)
+#pragma unroll
+        for (int k = p; k >= 1; k >>= 1)
+#pragma unroll
+            for (int j = k % p; j + k < N; j += 2 * k)
+#pragma unroll
+                for (int i = 0; i < k; ++i)
+                    if (i + j + k < N && (i + j) / (2 * p) == (i + j + k) / (2 * p)) {
+                        const int lo = min(v[i + j], v[i + j + k]), hi = max(v[i + j], v[i + j + k]);
+                        v[i + j] = lo; v[i + j + k] = hi;
+                    }
+#pragma unroll
+    for (int k = 0; k < N; ++k) if (k < len) q[k] = v[k];
 }
 
 __global__ __launch_bounds__(256) void k_bin_sort(BuildCtx c)
@@ -693,16 +806,27 @@ __global__ __launch_bounds__(256) void k_bin_sort(BuildCtx c)
     if (cell == 0) atomicOr(&c.dyn->status, kMeshBuilt);
     if (c.dyn->status & kMeshBinOverflow) return;
     const BinGrid g = grid_of(c);
-    if (cell >= (int64_t)g.gy * g.gz) return;
-    const int a = c.bin_start[cell], b = c.bin_start[cell + 1];
-    int32_t *q = c.bin_slots;
-    for (int i = a + 1; i < b; ++i) {                          // ascending slots inside every bin
-        const int key = q[i];
-        int j = i - 1;
-        while (j >= a && q[j] > key) { q[j + 1] = q[j]; --j; }
-        q[j + 1] = key;
+    const bool live = cell < (int64_t)g.gy * g.gz;
+    const int a = live ? c.bin_start[cell] : 0, b = live ? c.bin_start[cell + 1] : 0, len = b - a;
+    {   // longest list: one atomic per wavefront (27,648 atomics on one address were ~165 us of this kernel)
+        int m = len;
+        for (int d = 1; d < 64; d <<= 1) m = max(m, __shfl_xor(m, d));
+        if ((threadIdx.x & 63) == 0 && m > 0) atomicMax(&c.dyn->max_bin, m);
     }
-    if (b - a > 0) atomicMax(&c.dyn->max_bin, b - a);
+    int32_t *q = c.bin_slots + a;
+    // ascending slots inside every bin, as a sequential fill leaves them: the list in registers - ONE round of loads, Batcher's
+    // odd-even merge network, one round of stores.  (Sorting in place in global memory is a chain of dependent round trips:
+    // the few lists of 33..49 entries that took that path cost 170 us - the whole kernel.)
+    if (len > 1 && len <= 32) sort_regs<32>(q, len);
+    else if (len > 32 && len <= 64) sort_regs<64>(q, len);
+    else if (len > 64) {
+        for (int i = 1; i < len; ++i) {
+            const int key = q[i];
+            int j = i - 1;
+            while (j >= 0 && q[j] > key) { q[j + 1] = q[j]; --j; }
+            q[j + 1] = key;
+        }
+    }
 }
 
 // ---- pinned host mirrors of MeshDyn + events, pooled: nothing is allocated per image in the steady state --------------
@@ -789,7 +913,7 @@ int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces
     c.cen = reinterpret_cast<float *>(b + L.cen); c.order[0] = reinterpret_cast<int32_t *>(b + L.order0);
     c.order[1] = reinterpret_cast<int32_t *>(b + L.order1); c.adj = reinterpret_cast<int32_t *>(b + L.adj);
     c.chunkcnt = reinterpret_cast<int32_t *>(b + L.chunkcnt); c.subq = reinterpret_cast<int32_t *>(b + L.subq);
-    c.sublist = reinterpret_cast<STask *>(b + L.sublist);
+    c.sublist = reinterpret_cast<STask *>(b + L.sublist); c.bounds_part = reinterpret_cast<uint32_t *>(b + L.bounds_part);
     c.nck = (int32_t)L.nck; c.cells_cap = bin_cells_cap(m->F); c.entries_cap = bin_entries_cap(m->F);
 
     ICON_HIP(hipMemsetAsync(b + L.dyn, 0, L.zero_end - L.dyn, st));
@@ -816,7 +940,7 @@ int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces
     hipLaunchKernelGGL(k_tri_records, dim3(nbF), dim3(256), 0, st, c);
     debug_sync("k_tri_records", st);
     hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, st, c);
-    hipLaunchKernelGGL(k_bin_fill, dim3(nbF), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_bin_fill, dim3((unsigned)((m->F * 8 + 255) / 256)), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_bin_sort, dim3((unsigned)((c.cells_cap + 255) / 256)), dim3(256), 0, st, c);
     debug_sync("ray bins", st);
     ICON_HIP(hipGetLastError());

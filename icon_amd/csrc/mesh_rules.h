@@ -89,8 +89,10 @@ __host__ __device__ inline void tri_setup(const float *a, const float *b, const 
 }
 
 // ---- arena layout (one device allocation per mesh) ------------------------------------------------------------
-constexpr int kTopLevels = 5;          // BVH levels 0..4 are split by multi-workgroup kernels (k_bvh_bin / k_bvh_part)
-constexpr int kSubMax = 1024;          // subtrees of at most this many triangles are finished by ONE workgroup in LDS (k_bvh_sub)
+constexpr int kTopLevels = 7;          // BVH levels 0..6 are split by multi-workgroup kernels (k_bvh_bin / k_bvh_part)
+constexpr int kSubMax = 256;           // subtrees of at most this many triangles are finished by ONE workgroup in LDS (k_bvh_sub)
+// (measured on the SMPL-size body, MI355X: 5 levels / 1024 -> k_bvh_sub 257 us, the top levels 75 us; 7 / 256 -> 84 + 122 us:
+//  the subtree kernel pays a few microseconds per node PER WAVEFRONT, more, smaller subtrees spread the nodes over more CUs)
 constexpr int kChunk = 256;            // triangles per workgroup of the top-level kernels
 constexpr int kAdjCap = 16;            // incident (face, corner) entries kept per vertex (more: the vertex scans all faces)
 constexpr int kHistWords = 3 * kSahBins * 13;   // per node: [axis][bin][count, lo xyz, hi xyz (triangle boxes), lo xyz, hi xyz (centroids)] as ordered-uint codes
@@ -104,7 +106,6 @@ struct BTask {                         // one node of the top of the tree while 
 static_assert(sizeof(BTask) == 128, "BTask layout");
 
 struct BuildHdr {                      // zeroed before every build
-    uint32_t mesh_ubox[12];            // ordered-uint maxima (minima complemented): lo xyz, hi xyz of the vertices / of the triangle-box centroids
     int32_t n_sub;                     // entries of the subtree queue
     int32_t pad[3];
 };
@@ -112,7 +113,7 @@ struct BuildHdr {                      // zeroed before every build
 struct MeshLayout {
     size_t dyn, hdr, valence, leaf_cnt, tasks, hist, cell_count, cell_cursor, zero_end;   // [dyn, zero_end) is zeroed per build
     size_t vnormals, nodes, leaves, tris, attr, slot2face, face2slot, bin_start, bin_slots;
-    size_t tbox, cen, order0, order1, adj, chunkcnt, subq, sublist, total;
+    size_t tbox, cen, order0, order1, adj, chunkcnt, subq, sublist, bounds_part, total;
     int64_t nck;                       // chunk records per top level
 };
 inline size_t align_up(size_t v, size_t a = 256) { return (v + a - 1) / a * a; }
@@ -149,6 +150,7 @@ inline MeshLayout mesh_layout(int64_t V, int64_t F)
     L.chunkcnt = take(sizeof(int32_t) * 3 * kSahBins * L.nck * kTopLevels);
     L.subq = take(sizeof(int32_t) * (kTaskSlots + 1));
     L.sublist = take((size_t)80 * 2 * (F / 5 + 4));            // task lists of subtrees too large for LDS (mesh_device.hip: STask, 80 B)
+    L.bounds_part = take(sizeof(uint32_t) * 12 * ((size_t)F / 256 + 1));   // per-workgroup mesh bounds of k_face_prep
     L.total = o;
     return L;
 }

@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBlock) void k_features(MeshDev m, FeatDev f, Calib
             // (outlier / sign / inside / in_cube) and, for points inside the clip band only, d^2
             code = code8[i];
             nr.slot = near_slot_of(near, i); nr.face = 0;
-            nr.d2 = (code & kCodeOutlier) ? 0.0f : near.d2[i];
+            nr.d2 = (code & kCodeOutlier) ? 0.0f : near_d2(near, i);
             ins = (code & kCodeInside) != 0;
             o = sdf_attrs(m, p, nr, ins);
         }
@@ -346,9 +346,12 @@ __device__ __forceinline__ int64_t block_exclusive_scan_1024(int64_t v, int64_t 
     return base + incl - v;
 }
 
-__global__ __launch_bounds__(1024) void k_scan_local(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ local, int64_t *__restrict__ part)
+// n_points_dev (adaptive levels): the call's size lives on the device - n = its number of 256-point blocks
+__global__ __launch_bounds__(1024) void k_scan_local(const int32_t *__restrict__ counts, int64_t n, int32_t *__restrict__ local, int64_t *__restrict__ part,
+                                                     const int *__restrict__ n_points_dev)
 {
     __shared__ int64_t wtot[16];
+    if (n_points_dev) n = ((int64_t)*n_points_dev + kScanBlock - 1) / kScanBlock;
     const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
     const int64_t v = (i < n) ? counts[i] : 0;
     int64_t total;
@@ -358,9 +361,10 @@ __global__ __launch_bounds__(1024) void k_scan_local(const int32_t *__restrict__
 }
 
 __global__ __launch_bounds__(1024) void k_scan_apply(const int32_t *__restrict__ local, const int64_t *__restrict__ part, int64_t nchunks, int64_t n,
-                                                     int64_t *__restrict__ offsets, int64_t *__restrict__ total)
+                                                     int64_t *__restrict__ offsets, int64_t *__restrict__ total, const int *__restrict__ n_points_dev)
 {
     __shared__ int64_t wtot[16];
+    if (n_points_dev) n = ((int64_t)*n_points_dev + kScanBlock - 1) / kScanBlock;
     // sum of the chunk totals before this chunk (and of all chunks, for *total): nchunks <= a few hundred
     int64_t before = 0, all = 0;
     for (int64_t k = threadIdx.x; k < nchunks; k += 1024) { const int64_t t = part[k]; all += t; if (k < blockIdx.x) before += t; }
@@ -387,9 +391,10 @@ __device__ __forceinline__ int64_t outlier_rank(bool o, const int64_t *block_off
 }
 
 __global__ __launch_bounds__(kScanBlock) void k_outlier_compact(const uint8_t *__restrict__ code8, int64_t N,
-                                                                const int64_t *block_offsets, int8_t *signs)
+                                                                const int64_t *block_offsets, int8_t *signs, const int *__restrict__ n_dev)
 {
     __shared__ int wsum[kScanBlock / 64];
+    if (n_dev) { N = *n_dev; if ((int64_t)blockIdx.x * kScanBlock >= N) return; }
     const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
     const uint32_t code = (i < N) ? code8[i] : 0u;
     const bool o = code & kCodeOutlier;
@@ -595,6 +600,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
+    icon::adaptive_destroy(w->ad);
     delete w;
     return ICON_OK;
 }
@@ -796,13 +802,32 @@ int outlier_list(icon_work *w, int64_t N, int8_t *signs, bool counted, hipStream
     // `counted`: k_sign already left the outlier count of every 256-point block in d_block_counts
     if (!counted) hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
     const int64_t nchunks = (nblk + 1023) / 1024;
-    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total);
-    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs);
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part, (const int *)nullptr);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total, (const int *)nullptr);
+    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_offsets, signs, (const int *)nullptr);
     ICON_HIP(hipGetLastError());
     debug_sync("outlier scan + compact", st);
     return ICON_OK;
 }
+
+}  // namespace
+
+namespace icon {
+// the call's outlier sign list when its size is known on the device only (k_sign left the block counts): w->d_signs, w->d_total
+int outlier_list_dev(icon_work *w, const int *n_dev, int64_t n_max, hipStream_t st)
+{
+    const int64_t nblk = (n_max + kScanBlock - 1) / kScanBlock;
+    const int64_t nchunks = (nblk + 1023) / 1024;
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part, n_dev);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total, n_dev);
+    hipLaunchKernelGGL(k_outlier_compact, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, n_max, w->d_block_offsets, w->d_signs, n_dev);
+    ICON_HIP(hipGetLastError());
+    return ICON_OK;
+}
+int ensure_work_points(icon_work *w, int64_t n_points) { return ensure_work(w, n_points, false); }
+}  // namespace icon
+
+namespace {
 
 int patch_self(icon_work *w, int64_t N, int cmap_slot, hipStream_t st)
 {

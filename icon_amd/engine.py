@@ -775,6 +775,41 @@ class IconQueryEngine:
             self._work().h, _stream()), "icon_grid_eval_slab")
         return out
 
+    def native_schedule_reason(self, im_feat, regressor=None) -> Optional[str]:
+        """why the reference's coarse-to-fine schedule cannot run as ONE native call (icon_adaptive_eval) for the bound
+        regressor / settings - the host-driven schedule of recon.AdaptiveReconEngine takes over then - or None"""
+        reg = self._bound_regressor(regressor)
+        if self._composed_reason(reg, im_feat) is not None or self._callnorm_spec(reg) is not None:
+            return "regressor outside what the fused kernels carry"
+        if self.search != "bvh":
+            return "search != 'bvh'"
+        if self.tie_rule is not None:
+            return "diagnostics tie rule set"
+        self._mlp_handle(regressor)
+        if getattr(self, "_effective_precision", self.precision) != "f16x3":
+            return f"precision {getattr(self, '_effective_precision', self.precision)!r}"
+        return None
+
+    @_guarded
+    def adaptive_eval(self, im_feat, resolutions: Sequence[int], balance: float = 0.5, regressor=None, counts: bool = True):
+        """Seg3dLossless._forward_faster (lib/common/seg3d_lossless.py:152-265) as one native call (icon_adaptive_eval): ->
+        (volume [R,R,R] of the last resolution, points queried per level, bool: some voxel of the coarsest level > 0.5).
+        ``counts=False``: nothing is read back (the last two are None; Workspace counters hold them)."""
+        mesh, mlp, feat = self._mesh_handle(), self._mlp_handle(regressor), self._feat_handle(im_feat)
+        res = [int(r) for r in resolutions]
+        n = len(res)
+        out = torch.empty((res[-1],) * 3, dtype=torch.float32, device=im_feat.device)
+        arr = (C.c_int * n)(*res)
+        hc = (C.c_int64 * (n + 1))()
+        check(_lib.lib().icon_adaptive_eval(
+            mesh.h if mesh is not None else C.c_void_p(0), feat.h, mlp.h, C.c_int(_lib.PRIOR[self.prior_type]),
+            C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), arr, C.c_int(n), C.c_float(np.float32(balance)),
+            ptr(out), hc if counts else None, C.c_int(_lib.SEARCH[self.search]), C.c_int(self._precision()), self._work().h, _stream()),
+            "icon_adaptive_eval")
+        if not counts:
+            return out, None, None
+        return out, [int(hc[k]) for k in range(n)], bool(hc[n])
+
     @_guarded
     def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None, msg=None):
         """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device).  With ``msg`` (a

@@ -535,12 +535,17 @@ def export_mesh_numpy(occ: np.ndarray, level: float = 0.5):
 
 class AdaptiveReconEngine(DenseReconEngine):
     lattice_level0 = True      # answer the coarsest (dense) level with the lattice kernels; False: through query_func like the rest
+    native = True              # run the whole schedule as ONE native call (icon_adaptive_eval) where its conditions hold; False:
+                               # the host-driven schedule below (torch bookkeeping around HIP queries) - the two give the same volume
 
     """The reference's coarse-to-fine schedule (``Seg3dLossless._forward_faster``,
     lib/common/seg3d_lossless.py:152-265, the mode apps/ICON.py:89 selects) on top of the fast
     query: evaluate the coarsest lattice, then at every finer level only the voxels near the
     0.5 boundary of the trilinearly upsampled field (dilated by a 9^3 / 7^3 / 3^3 box), and only
-    interpolate at the last level.  ~1 % of the dense lattice is queried (SURVEY.md §0 finding 1), with
+    interpolate at the last level.  Since round 4 the schedule runs as ONE native call (``icon_adaptive_eval``,
+    csrc/adaptive.hip: every step a HIP kernel, nothing read back between the levels) whenever the standard box /
+    align_corners / doubling resolutions / fused f16x3 path hold; the code below is the host-driven form of the same
+    schedule for everything else (and the checker of the native one: tests compare the two volumes bit for bit).  ~1 % of the dense lattice is queried (SURVEY.md §0 finding 1), with
     exactly the reference's batches - same points, same order - so the result equals the
     reference's volume up to float rounding of the interpolation (tests compare against
     tests/golden/seg3d_body_adaptive_33_65.npz).  The grid bookkeeping is torch plumbing, as upstream;
@@ -588,6 +593,17 @@ class AdaptiveReconEngine(DenseReconEngine):
             cand = netG if isinstance(netG, IconQueryEngine) else (self.engine or getattr(netG, "icon_amd_engine", None))
             if isinstance(cand, IconQueryEngine) and self.query_func is not None and getattr(self.query_func, "__module__", "") == "icon_amd.engine":
                 lattice_engine = cand
+        # the whole schedule as kernels on the stream (csrc/adaptive.hip): boundary test, dilation, compaction in the reference's
+        # point order, one query per level, scatter, upsample - no torch op, no read-back between the levels
+        if (self.native and self.lattice_level0 and lattice_engine is not None and len(res_list) >= 1
+                and all(res_list[k] == 2 * res_list[k - 1] - 1 for k in range(1, len(res_list)))):
+            im_feat = feats[-1] if isinstance(feats, (list, tuple)) else feats
+            why = lattice_engine.native_schedule_reason(im_feat)
+            if why is None:
+                vol, counts, any_pos = lattice_engine.adaptive_eval(im_feat, res_list, float(self.balance_value))
+                self.last_stats = dict(queries=[counts[0]] + [c for c in counts[1:-1] if c > 0], native=True)
+                return vol if any_pos else None
+            self.last_stats = dict(native_refused=why)
         occupancys = done = None                     # done[z,y,x]: voxel already evaluated (the reference keeps a
         self.last_stats = dict(queries=[])           # sorted coordinate list, coords_accum, for the same purpose)
         for level, res in enumerate(res_list):

@@ -263,6 +263,24 @@ int icon_grid_slab_finish_gathered(const icon_mlp_t *mlp, int res, int z0, int z
                                    float *d_occ, int precision, icon_work_t *work, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * The reference's own schedule: Seg3dLossless._forward_faster (lib/common/seg3d_lossless.py:152-265, the mode
+ * apps/ICON.py:89 selects) - the coarsest lattice dense, every finer level only the voxels near the 0.5 boundary of the
+ * trilinearly upsampled field (dilated by a 9^3 / 7^3 / 3^3 box, minus what was evaluated before), the last level
+ * interpolated - entirely as kernels on `stream`: boundary test, dilation, compaction in the reference's point order,
+ * one query() call per level (own outlier sign list), scatter, upsample; nothing is read back between the levels.
+ * resolutions[n_levels]: ascending, odd, each 2 r - 1 of the one before (apps/ICON.py:62-66: 33, 65, 129, 257);
+ * standard box / align_corners=True / identity calibration as icon_grid_eval_slab.  d_out [res_last^3] f32, [z][y][x].
+ * h_counts [n_levels + 1] (host) or NULL: the points queried per level and, last, 1 when some voxel of the coarsest level
+ * exceeds 0.5 (otherwise the reference returns None, :173-177) - filling it synchronises the stream once, at the end;
+ * with NULL the call is asynchronous and icon_adaptive_counts reads them later.  ICON_PRECISION_F16X3 + ICON_SEARCH_BVH
+ * only (ICON_ERR_UNSUPPORTED otherwise: the host layer drives the schedule itself then).
+ * ------------------------------------------------------------------------------------------- */
+int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp, int prior_type, float sdf_clip,
+                       int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
+                       int search, int precision, icon_work_t *work, void *stream);
+int icon_adaptive_counts(icon_work_t *work, int n_levels, int64_t *h_counts, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * The MLP input rows of a call, materialised: what HGPIFuNet.query concatenates into point_feat before the regressor
  * (lib/net/HGPIFuNet.py:329-359), point-major d_rows [N,16] f32: slots [0,c0) in the reference's channel order, zeros,
  * slot 15 = integer bits, value 8 set = in_cube (:274-275).  For regressors whose normalisation runs over the points of the call

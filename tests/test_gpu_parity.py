@@ -770,6 +770,49 @@ def test_adaptive_recon_257_matches_reference_schedule(body):
     assert abs(int((v > 0.5).sum()) - int(g["inside"])) <= 8         # voxels within 1e-4 of the level may flip
 
 
+@pytest.mark.parametrize("res_list", [[33, 65], [17, 33, 65], [33, 65, 129, 257], [9, 17, 33, 65, 129]])
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+def test_native_schedule_equals_host_driven_schedule(body, res_list, cmap_mode):
+    """icon_adaptive_eval (csrc/adaptive.hip: the whole coarse-to-fine schedule of lib/common/seg3d_lossless.py:152-265 as
+    kernels on the stream) against the host-driven schedule (torch bookkeeping around HIP queries, the form pinned against
+    the reference's own volumes above): the same points per level, the same volume"""
+    from icon_amd.engine import query_func
+    from icon_amd.recon import AdaptiveReconEngine
+    from types import SimpleNamespace
+    eng = make_engine(body, cmap_mode=cmap_mode)
+    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=res_list, align_corners=True)
+    call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
+    nat = AdaptiveReconEngine(**kw).to(dev())
+    host = AdaptiveReconEngine(**kw).to(dev())
+    host.native = False
+    v1 = nat(**call)
+    assert nat.last_stats.get("native") is True, nat.last_stats
+    v2 = host(**call)
+    assert "native" not in host.last_stats
+    assert nat.last_stats["queries"] == host.last_stats["queries"], (nat.last_stats, host.last_stats)
+    d = (v1 - v2).abs().max().item()
+    print(f"{res_list} {cmap_mode}: queries {nat.last_stats['queries']}, max |native - host-driven| = {d:.3e}")
+    assert d <= 1e-6
+    v3 = nat(**call)                                   # buffers reused: the same bits again
+    assert torch.equal(v1, v3)
+
+
+def test_native_schedule_returns_none_like_the_reference(body):
+    """nothing above 0.5 on the coarsest lattice -> None (seg3d_lossless.py:173-177), native and host-driven alike"""
+    import copy
+    from icon_amd.engine import query_func
+    from icon_amd.recon import AdaptiveReconEngine
+    from types import SimpleNamespace
+    a = copy.copy(body)
+    a.state_dict = {k: v.copy() for k, v in body.state_dict.items()}
+    a.state_dict["filters.3.bias"] = a.state_dict["filters.3.bias"] - 100.0
+    eng = make_engine(a)
+    for native in (True, False):
+        r = AdaptiveReconEngine(query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
+        r.native = native
+        assert r(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None) is None
+
+
 def test_lattice_513_properties(body):
     """cfg 5 size (513^3 = 135,005,697 points, 8.6 GB of MLP input rows): 64-bit indexing, and
     the even sub-lattice IS the 257^3 lattice (identical float coordinates), so in the per-point

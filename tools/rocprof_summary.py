@@ -39,7 +39,7 @@ FETCH_CALIBRATION = {"k_fused_f16x3": 1.0, "k_outlier_compact": 1.33}
 
 
 def short(name):
-    name = name.replace("void ", "")
+    name = name.replace("void ", "").replace("(anonymous namespace)::", "")
     return name.split("(")[0]
 
 
