@@ -58,20 +58,33 @@ void adaptive_destroy(icon_adaptive *a)
 namespace {
 
 // ---- F.interpolate(mode='trilinear', align_corners=True): ATen's upsample_trilinear3d expression, term for term --------------
+// One thread = four consecutive x of one (z, y) row: the row's weights and the (up to) 4 x 3 source values are shared
+// (a thread per voxel spent its time on index arithmetic: 75 us for the 257^3 level, 68 MB of output).
 __global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r)
 {
+    const int gx = (r + 3) / 4;                                 // x-groups per row
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)r * r * r) return;
-    const int w2 = (int)(i % r), h2 = (int)((i / r) % r), t2 = (int)(i / ((int64_t)r * r));
+    if (i >= (int64_t)r * r * gx) return;
+    const int g = (int)(i % gx), h2 = (int)((i / gx) % r), t2 = (int)(i / ((int64_t)gx * r));
     const float scale = (r > 1) ? (float)(rp - 1) / (float)(r - 1) : 0.0f;      // area_pixel_compute_scale, align_corners
-    const float t1r = scale * t2, h1r = scale * h2, w1r = scale * w2;
-    const int t1 = (int)t1r, h1 = (int)h1r, w1 = (int)w1r;
-    const int t1p = (t1 < rp - 1) ? 1 : 0, h1p = (h1 < rp - 1) ? 1 : 0, w1p = (w1 < rp - 1) ? 1 : 0;
-    const float t1l = t1r - t1, t0l = 1.0f - t1l, h1l = h1r - h1, h0l = 1.0f - h1l, w1l = w1r - w1, w0l = 1.0f - w1l;
-    auto at = [&](int t, int h, int w) { return src[((int64_t)t * rp + h) * rp + w]; };
-    dst[i] = t0l * (h0l * (w0l * at(t1, h1, w1) + w1l * at(t1, h1, w1 + w1p)) + h1l * (w0l * at(t1, h1 + h1p, w1) + w1l * at(t1, h1 + h1p, w1 + w1p))) +
-             t1l * (h0l * (w0l * at(t1 + t1p, h1, w1) + w1l * at(t1 + t1p, h1, w1 + w1p)) +
-                    h1l * (w0l * at(t1 + t1p, h1 + h1p, w1) + w1l * at(t1 + t1p, h1 + h1p, w1 + w1p)));
+    const float t1r = scale * t2, h1r = scale * h2;
+    const int t1 = (int)t1r, h1 = (int)h1r;
+    const int t1p = (t1 < rp - 1) ? 1 : 0, h1p = (h1 < rp - 1) ? 1 : 0;
+    const float t1l = t1r - t1, t0l = 1.0f - t1l, h1l = h1r - h1, h0l = 1.0f - h1l;
+    const float *r00 = src + ((int64_t)t1 * rp + h1) * rp, *r01 = src + ((int64_t)t1 * rp + h1 + h1p) * rp;
+    const float *r10 = src + ((int64_t)(t1 + t1p) * rp + h1) * rp, *r11 = src + ((int64_t)(t1 + t1p) * rp + h1 + h1p) * rp;
+    float *out = dst + ((int64_t)t2 * r + h2) * r;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int w2 = g * 4 + k;
+        if (w2 >= r) break;
+        const float w1r = scale * w2;
+        const int w1 = (int)w1r;
+        const int w1p = (w1 < rp - 1) ? 1 : 0;
+        const float w1l = w1r - w1, w0l = 1.0f - w1l;
+        out[w2] = t0l * (h0l * (w0l * r00[w1] + w1l * r00[w1 + w1p]) + h1l * (w0l * r01[w1] + w1l * r01[w1 + w1p])) +
+                  t1l * (h0l * (w0l * r10[w1] + w1l * r10[w1 + w1p]) + h1l * (w0l * r11[w1] + w1l * r11[w1 + w1p]));
+    }
 }
 
 // [x][y][z] index of voxel (x, y, z)
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(1024) void k_ad_scan(const int32_t *__restrict__ cn
 }
 
 __global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ C, int r, const int32_t *__restrict__ blk_off,
-                                                   int32_t *__restrict__ map, float *__restrict__ pts, uint8_t *__restrict__ blk_flag, int nbk)
+                                                   int32_t *__restrict__ map, float *__restrict__ pts, uint8_t *__restrict__ blk_flag, int nbk, int shift)
 {
     __shared__ int ws[4];
     const int64_t n = (int64_t)r * r * r;
@@ -176,7 +189,7 @@ __global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ 
     map[k] = (int32_t)(((int64_t)z * r + y) * r + x);
     const f3 p = lattice_world(r, x, y, z);          // == batch_eval's mapping of (coords * stride), bit for bit (quotients of the same rationals)
     pts[3 * (int64_t)k] = p.x; pts[3 * (int64_t)k + 1] = p.y; pts[3 * (int64_t)k + 2] = p.z;
-    blk_flag[((int64_t)(z >> 2) * nbk + (y >> 2)) * nbk + (x >> 2)] = 1;
+    if (blk_flag) blk_flag[((int64_t)(z >> shift) * nbk + (y >> shift)) * nbk + (x >> shift)] = 1;
 }
 
 __global__ __launch_bounds__(256) void k_ad_blocks(const uint8_t *__restrict__ blk_flag, int nblocks, int32_t *__restrict__ list, int *n_blocks)
@@ -185,22 +198,36 @@ __global__ __launch_bounds__(256) void k_ad_blocks(const uint8_t *__restrict__ b
     if (i < nblocks && blk_flag[i]) list[atomicAdd(n_blocks, 1)] = i;          // any order: the blocks are independent
 }
 
-// the exact nearest triangle of every lattice point of the listed 4x4x4 blocks (one wavefront per block, the packet traversal)
-__global__ __launch_bounds__(256) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list, const int *__restrict__ n_blocks,
+// the exact nearest triangle of every lattice point of the listed P x P x P blocks (one wavefront per block, the packet
+// traversal; P = 4 on fine lattices, 2 / 1 on the coarse ones - common.h: coarse_packet, geom_device.h: lattice_point).
+// P == 1: the "blocks" are the candidates themselves (list = the compacted map, n = the level's point count).
+// These launches hold fewer packets than the GPU has wave slots: their time is the LATENCY of the longest traversal, not a
+// throughput - 4^3 packets on the 65^3 / 129^3 levels walked the union of 64 nearly unrelated searches, 390 us per level.
+template <int P>
+__global__ __launch_bounds__(256) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list, const int *__restrict__ n_list,
                                                    NearRef near, float sdf_clip)
 {
     __shared__ int lds[4 * kStackDepth];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nb = *n_blocks;
+    const int nb = *n_list;
     for (int b = blockIdx.x * 4 + wave; b < nb; b += gridDim.x * 4) {
-        const int blk = list[b];
-        const int bx = blk % nbk, by = (blk / nbk) % nbk, bz = blk / (nbk * nbk);
-        const int ix = bx * 4 + (lane & 3), iy = by * 4 + ((lane >> 2) & 3), iz = bz * 4 + (lane >> 4);
-        const bool live = ix < r && iy < r && iz < r;
+        const int e = list[b];
+        int ix, iy, iz;
+        bool live;
+        if (P == 1) {                                         // e = [z][y][x] linear index of ONE point
+            ix = e % r; iy = (e / r) % r; iz = e / (r * r);
+            live = true;
+        } else {
+            const int bx = e % nbk, by = (e / nbk) % nbk, bz = e / (nbk * nbk);
+            const bool used = lane < P * P * P;
+            const int l = used ? lane : 0;
+            ix = bx * P + l % P; iy = by * P + (l / P) % P; iz = bz * P + l / (P * P);
+            live = used && ix < r && iy < r && iz < r;
+        }
         const int cx = min(ix, r - 1), cy = min(iy, r - 1), cz = min(iz, r - 1);
         const f3 p = lattice_world(r, cx, cy, cz);
-        const Nearest nr = nearest_packet(m, p, live, lds + wave * kStackDepth);
-        if (live) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
+        const Nearest nr = nearest_packet(m, p, live, lds + wave * kStackDepth, nullptr, nullptr, INFINITY, nullptr, P == 4 ? 21 : 0);
+        if (live && (P > 1 || lane == 0)) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
     }
 }
 
@@ -270,7 +297,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             if ((rc = grow(&a->occ[l], n))) return rc;
             if (l >= 1 && (rc = grow(&a->D[l], n))) return rc;
         }
-        const int nbk = (rq + 3) / 4;
+        const int nbk = (rq + 1) / 2;                            // blocks of the finest granularity used (2^3)
         if ((rc = grow(&a->P, (size_t)a->cap)) || (rc = grow(&a->M0, (size_t)a->cap)) || (rc = grow(&a->M1, (size_t)a->cap)) ||
             (rc = grow(&a->map, (size_t)a->cap)) || (rc = grow(&a->pts, (size_t)a->cap * 3)) ||
             (rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256)) || (rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256)) ||
@@ -296,7 +323,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         const int r = resolutions[l], rp = resolutions[l - 1];
         const int64_t n = (int64_t)r * r * r;
         const unsigned nbv = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_ad_up, dim3(nbv), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r);
+        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)(((int64_t)r * r * ((r + 3) / 4) + 255) / 256)), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r);
         if (l == n_levels - 1) break;                           // "last step no examine": interpolate only
         // P holds (occ_{l-1} > balance): level 0's from above, later levels' from the end of the previous iteration
         hipLaunchKernelGGL(k_ad_boundary, dim3(nbv), dim3(256), 0, st, a->P, rp, a->M0, r);
@@ -305,11 +332,16 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M1, a->M0, r, 1, rad, 0, (const uint8_t *)nullptr, rp);
         hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 2, rad, 1, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp);
         uint8_t *C = a->M1;
-        const int nbk = (r + 3) / 4, nblocks = nbk * nbk * nbk;
-        ICON_HIP(hipMemsetAsync(a->blk_flag, 0, (size_t)nblocks, st));
+        static const int pk_env = getenv("ICON_AMD_PACKET") ? atoi(getenv("ICON_AMD_PACKET")) : 0;
+        const bool icon_prior = prior_type == ICON_PRIOR_ICON;
+        const int P = (pk_env == 1 || pk_env == 2 || pk_env == 4) ? pk_env : coarse_packet(r);
+        const int shift = P == 4 ? 2 : 1;
+        const int nbk = (r + P - 1) / P, nblocks = nbk * nbk * nbk;
+        const bool use_blocks = icon_prior && P > 1;
+        if (use_blocks) ICON_HIP(hipMemsetAsync(a->blk_flag, 0, (size_t)nblocks, st));
         hipLaunchKernelGGL(k_ad_count, dim3(nbv), dim3(256), 0, st, C, n, a->blk_count);
         hipLaunchKernelGGL(k_ad_scan, dim3(1), dim3(1024), 0, st, a->blk_count, (int)nbv, a->blk_off, a->counters + l);
-        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts, a->blk_flag, nbk);
+        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts, use_blocks ? a->blk_flag : (uint8_t *)nullptr, nbk, shift);
         ICON_HIP(hipGetLastError());
         debug_sync("adaptive: upsample + boundary + dilate + compact", st);
         // ---- the level's query: ONE call over the compacted points (count on the device) ---------------------------------
@@ -317,7 +349,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         work->q_map = a->map; work->q_n_dev = a->counters + l;
         Calib cal;
         memcpy(cal.m, ident, sizeof(ident)); cal.d = nullptr;
-        const bool icon = prior_type == ICON_PRIOR_ICON;
+        const bool icon = icon_prior;
         const bool needs_list = icon && cmap_mode == ICON_CMAP_REFERENCE && (feat->dev.smpl_mask & kSmplCmap);
         if (icon) {
             if (mesh->F > kNearLoSlots && work->cap_points_hi < work->cap_points) {
@@ -325,13 +357,19 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
                 ICON_HIP(hipMalloc((void **)&work->d_near_hi, (size_t)work->cap_points));
                 work->cap_points_hi = work->cap_points;
             }
-            ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
             NearRef raw = work_near(work, mesh);
             raw.map = nullptr;                                   // the search writes by lattice index
             int n_cu = 0;
             if ((rc = device_cu_count(&n_cu))) return rc;
-            hipLaunchKernelGGL(k_ad_nearest, dim3((unsigned)(n_cu * 8)), dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
+            const dim3 grid((unsigned)(n_cu * 8));
+            if (use_blocks) {
+                ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
+                hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
+                if (P == 4) hipLaunchKernelGGL(k_ad_nearest<4>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
+                else hipLaunchKernelGGL(k_ad_nearest<2>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
+            } else {
+                hipLaunchKernelGGL(k_ad_nearest<1>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->map, a->counters + l, raw, sdf_clip);
+            }
             ICON_HIP(hipGetLastError());
             debug_sync("adaptive: k_ad_nearest", st);
             if ((rc = launch_sign(mesh, cal, r, 0, a->pts, n, sdf_clip, work, false, st))) return rc;

@@ -171,6 +171,7 @@ struct LatticeMap {
     // (device-built mesh, no read-back).  Workgroups beyond the trimmed tiling exit at once.
     int trim;
     float trim_need;           // distance from the cube's boundary beyond which a face is "far" (from sdf_clip)
+    int pk;                    // points per wavefront of the search = pk^3 (4, 2 or 1; 0 = 4): see lattice_point
 };
 
 // inf or NaN, as a test on the bits of an OPAQUE copy: in a translation unit compiled with -fno-honor-nans a NaN result is
@@ -260,6 +261,11 @@ void mesh_bind_arena(icon_mesh *m, const MeshLayout &L);
 int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces, const float *d_cmap, const float *d_vis, hipStream_t st);
 // adaptive.hip
 void adaptive_destroy(icon_adaptive *a);
+// points per wavefront (pk^3) of the lattice search by resolution: see lattice_point (geom_device.h)
+// (measured on the reference's schedule [33, 65, 129, 257], MI355X, whole schedule per volume: 4^3 everywhere 2.00 ms, single
+//  points 1.62 ms, 2^3 1.42 ms - these launches hold fewer packets than the GPU has wave slots, their time is the latency of
+//  the longest traversal: 8 neighbours still share most of a walk, 64 points of a coarse lattice do not)
+inline int coarse_packet(int res) { return res >= 200 ? 4 : 2; }
 // query_kernels.hip: the outlier sign list of a point-mode call whose size is known on the device only (*n_dev <= n_max)
 int outlier_list_dev(icon_work *w, const int *n_dev, int64_t n_max, hipStream_t st);
 int ensure_work_points(icon_work *w, int64_t n_points);

@@ -257,7 +257,7 @@ __device__ __forceinline__ float prune_threshold(float best)
 template <bool STATS = false, bool TIES = false>
 __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
                                                   int *n_nodes = nullptr, int *n_tris = nullptr, float thr0 = INFINITY,
-                                                  unsigned long long *runner_up = nullptr)
+                                                  unsigned long long *runner_up = nullptr, int center_lane = 21)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
     unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
@@ -305,8 +305,8 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
             const bool v0 = __any(d0 <= thr), v1 = __any(d1 <= thr);
             if (v0 && v1) {
                 // order by the block's centre lane; non-negative floats order like their bit patterns
-                const int e0 = __builtin_amdgcn_readlane(__float_as_int(d0), 21);
-                const int e1 = __builtin_amdgcn_readlane(__float_as_int(d1), 21);
+                const int e0 = __builtin_amdgcn_readlane(__float_as_int(d0), center_lane);
+                const int e1 = __builtin_amdgcn_readlane(__float_as_int(d1), center_lane);
                 const bool first0 = e0 <= e1;
                 wstack[sp++] = first0 ? c1 : c0;
                 cur = first0 ? c0 : c1;
@@ -766,7 +766,8 @@ __device__ __forceinline__ LatticeMap lattice_trim(LatticeMap L, const MeshDev &
     L.sx0 = lo[0]; L.sx1 = hi[0]; L.sy0 = lo[1]; L.sy1 = hi[1];
     L.sz0 = max(z0, lo[2]) - z0; L.sz1 = min(z1, hi[2]) - z0;
     if (L.sz1 < L.sz0) L.sz1 = L.sz0;
-    L.tx = (L.sx1 - L.sx0 + 15) / 16; L.ty = (L.sy1 - L.sy0 + 3) / 4; L.tz = (L.sz1 - L.sz0 + 3) / 4;
+    const int P = L.pk ? L.pk : 4;
+    L.tx = (L.sx1 - L.sx0 + 4 * P - 1) / (4 * P); L.ty = (L.sy1 - L.sy0 + P - 1) / P; L.tz = (L.sz1 - L.sz0 + P - 1) / P;
     L.trim = 0;
     return L;
 }
@@ -797,12 +798,20 @@ __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int 
     // x-position by the row number keeps the mapping a bijection and hands every XCD every column in turn.
     if (L.remap == 0) btx = (btx + btz + bty * L.tz) % L.tx;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    // tiles cover the search region [sx0, sx1) x [sy0, sy1) x planes [sz0, sz1) (iz is relative to the slab)
-    ix = L.sx0 + btx * 16 + wave * 4 + (lane & 3);
-    iy = L.sy0 + bty * 4 + ((lane >> 2) & 3);
-    iz = L.sz0 + btz * 4 + (lane >> 4);
-    return ix < L.sx1 && iy < L.sy1 && iz < L.sz1;
+    // tiles cover the search region [sx0, sx1) x [sy0, sy1) x planes [sz0, sz1) (iz is relative to the slab).  A wavefront owns
+    // a P x P x P block of points, P = L.pk: 4 on the fine lattices; on a COARSE lattice (the first levels of the reference's
+    // schedule: spacing 2-8x the triangle size) the 64 points of a 4^3 block have little of their search in common and the
+    // packet walks the union - 2^3 or single points per wavefront there (the lanes beyond P^3 are parked on point 0 of the block)
+    const int P = L.pk ? L.pk : 4;
+    const bool used = lane < P * P * P;
+    const int l = used ? lane : 0;
+    ix = L.sx0 + (btx * 4 + wave) * P + l % P;
+    iy = L.sy0 + bty * P + (l / P) % P;
+    iz = L.sz0 + btz * P + l / (P * P);
+    return used && ix < L.sx1 && iy < L.sy1 && iz < L.sz1;
 }
+// the lane whose box distances order the two children of a node: the block's centre (4^3), its first point otherwise
+__device__ __forceinline__ int packet_center_lane(const LatticeMap &L) { return (L.pk == 0 || L.pk == 4) ? 21 : 0; }
 
 // a padding lane of a boundary tile works on a clamped copy of a real point of the region
 __device__ __forceinline__ void lattice_clamp(const LatticeMap &L, int ix, int iy, int iz, int &cx, int &cy, int &cz)

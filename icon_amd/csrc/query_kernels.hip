@@ -109,7 +109,8 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         if (perm) i = perm[i];          // Morton order: the wave's 64 points are neighbours (sort_points.hip)
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
     }
-    Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth);
+    Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, nullptr, nullptr, INFINITY, nullptr,
+                                LATTICE ? packet_center_lane(L) : 21);
     if (ALT) nr = nearest_packet_alt(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, (uint32_t)__float_as_int(nr.d2), (uint32_t)tie_ulps);
     // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
     //  writes but the block-wide barrier costs 0.14 ms; not kept)
@@ -777,7 +778,7 @@ int launch_features(const icon_mesh_t *mesh, const icon_feat_t *feat, int prior,
     const int skip_shell = L.off;
     if (LATTICE) {
         Lf.sx0 = Lf.sy0 = Lf.sz0 = 0; Lf.sx1 = Lf.sy1 = L.res; Lf.sz1 = L.nz;
-        Lf.tx = (L.res + 15) / 16; Lf.ty = (L.res + 3) / 4; Lf.tz = (L.nz + 3) / 4;
+        Lf.tx = (L.res + 15) / 16; Lf.ty = (L.res + 3) / 4; Lf.tz = (L.nz + 3) / 4; Lf.pk = 4; Lf.trim = 0;
     }
     int64_t nb;
     if (LATTICE) nb = (int64_t)Lf.tx * Lf.ty * Lf.tz; else nb = (N + kBlock - 1) / kBlock;
@@ -1022,7 +1023,11 @@ static int lattice_map(int res, int z0, int z1, const icon_mesh_t *mesh, float s
     // search region: the whole slab here - the kernel itself leaves out the far faces (lattice_trim: the body's box is
     // known on the device only) and workgroups beyond the trimmed tiling exit at once
     L->sx0 = 0; L->sx1 = res; L->sy0 = 0; L->sy1 = res; L->sz0 = 0; L->sz1 = z1 - z0;
-    L->tx = (L->sx1 - L->sx0 + 15) / 16; L->ty = (L->sy1 - L->sy0 + 3) / 4; L->tz = (L->sz1 - L->sz0 + 3) / 4;
+    // points per wavefront of the search: 4^3 blocks where the lattice is fine (257^3: the packet's 64 searches nearly coincide),
+    // 2^3 / single points on the coarse lattices of the reference's schedule (see lattice_point); ICON_AMD_PACKET overrides
+    static const int pk_env = getenv("ICON_AMD_PACKET") ? atoi(getenv("ICON_AMD_PACKET")) : 0;
+    L->pk = (pk_env == 1 || pk_env == 2 || pk_env == 4) ? pk_env : coarse_packet(res);
+    L->tx = (L->sx1 - L->sx0 + 4 * L->pk - 1) / (4 * L->pk); L->ty = (L->sy1 - L->sy0 + L->pk - 1) / L->pk; L->tz = (L->sz1 - L->sz0 + L->pk - 1) / L->pk;
     L->trim = (off && mesh) ? 1 : 0;
     L->trim_need = std::sqrt(far_box_dist2(sdf_clip)) * 1.001f + 1e-5f;
     const char *e = getenv("ICON_AMD_XCD_REMAP");

@@ -12,13 +12,18 @@ eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
 eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
 feats = [T(a.features)]; opt = SimpleNamespace(num_views=1)
 kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[33, 65, 129, 257], align_corners=True)
-for name, cls in (("dense", DenseReconEngine), ("adaptive", AdaptiveReconEngine)):
+which = os.environ.get("WHICH", "dense,adaptive,host").split(",")
+for name, cls in (("dense", DenseReconEngine), ("adaptive", AdaptiveReconEngine), ("host", AdaptiveReconEngine)):
+    if name not in which:
+        continue
     rec = cls(**kw).cuda()
+    if name == "host":
+        rec.native = False                       # the host-driven schedule (torch bookkeeping around HIP queries)
     f = lambda: rec(opt=opt, netG=eng, features=feats, proj_matrix=None)
-    f(); torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(5): occ = f()
+    f(); f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(10): occ = f()
     torch.cuda.synchronize()
-    print(f"{name}: {(time.perf_counter() - t) * 200:.2f} ms per volume", getattr(rec, "last_stats", None))
+    print(f"{name}: {(time.perf_counter() - t) * 100:.3f} ms per volume", getattr(rec, "last_stats", None))
 
 if os.environ.get("PROFILE"):
     from torch.profiler import profile, ProfilerActivity
