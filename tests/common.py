@@ -129,3 +129,58 @@ def variant_state_dict(name, a):
     elif norm in ("group", "instance"):
         sd = callnorm_state_dict(sd, norm)
     return c0, sd
+
+
+def volume_encoder_replica(num_in=3, num_out=7, num_stacks=2):
+    """A test-local module with EXACTLY the layer list of the reference's VolumeEncoder (lib/net/VE.py:114-183; Residual3D
+    :55-111) - same attribute names, so the reference's state_dict loads with strict=True (tests/test_oracle_vs_reference.py
+    checks that, and that both produce the same output) - for driving the real 128^3 -> 32^3 x 7 stack (k5 s2 d2 3-D
+    convolutions, BatchNorm3d, two residual blocks with a dilated k3 convolution) through MIOpen on the GPU box, where
+    /root/reference does not exist.  Call contract of HGPIFuNet.query: ve(vol, intermediate_output=False)[-1]."""
+    import torch
+    import torch.nn as nn
+
+    class Residual3D(nn.Module):
+        def __init__(self, n_in, n_out):
+            super().__init__()
+            self.numIn, self.numOut = n_in, n_out
+            self.bn = nn.BatchNorm3d(n_in)                                   # constructed, never applied (VE.py:97-98)
+            self.relu = nn.ReLU(inplace=True)
+            self.conv1 = nn.Conv3d(n_in, n_out, kernel_size=3, stride=1, padding=2, dilation=2)
+            self.bn1 = nn.BatchNorm3d(n_out)
+            self.conv2 = nn.Conv3d(n_out, n_out, kernel_size=3, stride=1, padding=1)
+            self.bn2 = nn.BatchNorm3d(n_out)
+            self.conv3 = nn.Conv3d(n_out, n_out, kernel_size=3, stride=1, padding=1)      # constructed, never applied (:105-106)
+            if n_in != n_out:
+                self.conv4 = nn.Conv3d(n_in, n_out, kernel_size=1)
+
+        def forward(self, x):
+            out = self.bn2(self.conv2(self.relu(self.bn1(self.conv1(x)))))
+            return out + (self.conv4(x) if self.numIn != self.numOut else x)
+
+    class VolumeEncoder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.num_stacks = num_stacks
+            self.relu = nn.ReLU(inplace=True)
+            self.conv1 = nn.Conv3d(num_in, 8, kernel_size=5, stride=2, padding=4, dilation=2)
+            self.bn1 = nn.BatchNorm3d(8)
+            self.conv2 = nn.Conv3d(8, num_out, kernel_size=5, stride=2, padding=4, dilation=2)
+            self.bn2 = nn.BatchNorm3d(num_out)
+            self.conv_out1 = nn.Conv3d(num_out, num_out, kernel_size=3, stride=1, padding=1)   # constructed, never applied
+            self.conv_out2 = nn.Conv3d(num_out, num_out, kernel_size=3, stride=1, padding=1)
+            for idx in range(num_stacks):
+                self.add_module("res" + str(idx), Residual3D(num_out, num_out))
+            self.calls = 0
+
+        def forward(self, x, intermediate_output=True):
+            self.calls += 1
+            out = self.relu(self.bn1(self.conv1(x)))
+            out = self.relu(self.bn2(self.conv2(out)))
+            outs = []
+            for idx in range(self.num_stacks):
+                out = self._modules["res" + str(idx)](out)
+                outs.append(out)
+            return outs if intermediate_output else [outs[-1]]
+
+    return VolumeEncoder()

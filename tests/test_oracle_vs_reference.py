@@ -379,3 +379,40 @@ def test_attach_reads_the_reference_network(ref):
         with pytest.raises(IconAmdError):
             netG.query(features=[T(a.features)], points=T(np.zeros((1, 3, 4), np.float32)), calibs=torch.eye(4)[None],
                        regressor=netG.if_regressor)
+
+
+def test_pamir_fixture_is_the_reference_with_its_real_encoder():
+    """tests/golden/query_pamir_real_ve.npz is the reference's own HGPIFuNet(prior_type='pamir').query - its Voxelization
+    wrapper (lib/net/voxelize.py:64-137) and its VolumeEncoder (lib/net/VE.py:114-183) as they are, the voxelize_cuda wheel
+    replaced by the checker's voxeliser at the leaf (tools/make_golden.py: pamir_reference_net).  Re-run it: same answers.
+    And the test-local replica of the encoder (common.volume_encoder_replica, what the GPU box runs where the reference
+    tree does not exist) loads the reference encoder's state_dict strictly and computes the same volume features."""
+    import sys
+    from common import ROOT, golden, volume_encoder_replica
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_golden as mg
+    g = golden("query_pamir_real_ve.npz")
+    a = synth.make_assets("body", prior_type="pamir")
+    netG, cfg, (vv, tets, code) = mg.pamir_reference_net(a)
+    for k, v in netG.ve.state_dict().items():
+        if "num_batches_tracked" not in k:
+            assert np.array_equal(v.numpy(), g["ve." + k]), k
+    rep = volume_encoder_replica().eval()
+    rep.load_state_dict(netG.ve.state_dict(), strict=True)
+    pad_v, pad_f = int(g["pad_v"]), int(g["pad_f"])
+    vverts = torch.from_numpy(np.concatenate([vv, np.zeros((pad_v, 3), np.float32)]))[None]
+    vfaces = torch.from_numpy(np.concatenate([tets, np.zeros((pad_f, 4), np.int64)]))[None]
+    netG.smpl_feat_dict = {"voxel_verts": vverts, "voxel_faces": vfaces, "pad_v_num": torch.tensor([pad_v]), "pad_f_num": torch.tensor([pad_f])}
+    sd = synth.make_mlp_state_dict(synth.SEED + 1, sdf_channel=None)
+    netG.if_regressor.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    feat = synth.make_feature_planes(6, 128, synth.SEED)
+    ref = ref_loader.load()
+    with torch.no_grad():
+        occ = ref.query_func(cfg, netG, [torch.from_numpy(feat)], torch.from_numpy(g["points"])[None])[0, 0].numpy()
+        netG.voxelization.update_param(batch_size=1, smpl_tetra=tets)
+        vol = netG.voxelization(vverts[:, :-pad_v])
+        f_ref = netG.ve(vol, intermediate_output=False)[-1]
+        f_rep = rep(vol, intermediate_output=False)[-1]
+    assert np.abs(occ - g["occ"]).max() <= 1e-6
+    assert torch.equal(f_ref, f_rep)
+    assert np.abs(f_ref[0, :, ::4, ::4, ::4].numpy() - g["vol_feat_sample"]).max() <= 1e-6

@@ -172,3 +172,47 @@ def test_pamir_uses_the_reference_voxeliser_when_its_wheel_imports(monkeypatch):
     got = run(net_a); run(net_a)
     assert net_a.voxelization.calls == [("update_param", 1, tuple(tets.shape)), ("forward", (1, len(vv), 3))]   # once per image, stripped tensors
     assert torch.equal(got, want)
+
+
+@pytest.mark.gpu
+def test_pamir_with_the_reference_volume_encoder_stack():
+    """cfg 4 end to end with the REAL encoder stack: the fixture is the reference's own HGPIFuNet(prior_type='pamir').query run
+    on CPU (tools/make_golden.py section j: its Voxelization wrapper and VolumeEncoder as they are, the voxelize_cuda wheel
+    replaced by the checker's voxeliser at the leaf) - here the same voxel tensors, the same encoder weights in a module with
+    VE.py's exact layer list (common.volume_encoder_replica; 128^3 -> 32^3 x 7 through MIOpen's k5 / d2 3-D convolutions),
+    the HIP voxeliser and the fused query: padding strip, update_param, ve(vol, intermediate_output=False)[-1] as
+    lib/net/HGPIFuNet.py:314-325, once per image."""
+    from common import golden, volume_encoder_replica
+    from icon_amd.engine import IconQueryEngine
+    from oracle.query_torch import TorchMLP
+    g = golden("query_pamir_real_ve.npz")
+    a, (vv, tets, code) = _tetra()
+    dev = torch.device("cuda:0")
+    feat, _, sd = vol_assets("pamir")
+    ve = volume_encoder_replica().eval()
+    ve.load_state_dict({k[3:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("ve.")}, strict=False)
+    missing = [k for k in ve.state_dict() if "num_batches_tracked" not in k and "ve." + k not in g.files]
+    assert not missing, missing
+    reg = TorchMLP().eval()
+    reg.norm, reg.last_op = "batch", None
+    reg.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    pad_v, pad_f = int(g["pad_v"]), int(g["pad_f"])
+    vverts = torch.from_numpy(np.concatenate([vv, np.zeros((pad_v, 3), np.float32)]))[None].to(dev)
+    vfaces = torch.from_numpy(np.concatenate([tets, np.zeros((pad_f, 4), np.int64)]))[None].to(dev)
+    netG = SimpleNamespace(prior_type="pamir", sdf_clip=0.05, smpl_feats=["sdf", "norm", "vis", "cmap"], if_regressor=reg.to(dev),
+                           voxelization=SimpleNamespace(smpl_vertex_code=code, volume_res=128, sigma=0.05), ve=ve.to(dev),
+                           smpl_feat_dict=dict(voxel_verts=vverts, voxel_faces=vfaces,
+                                               pad_v_num=torch.tensor([pad_v], device=dev), pad_f_num=torch.tensor([pad_f], device=dev)))
+    eng = IconQueryEngine.attach(netG, voxelizer="hip")
+    T = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    eye = torch.eye(4, device=dev)[None]
+    pts = g["points"]
+    occ = netG.query(features=[T(feat)], points=T(pts.T)[None], calibs=eye, regressor=netG.if_regressor)[0][0, 0].cpu().numpy()
+    vf = eng._vol_cached
+    assert tuple(vf.shape) == (1, 7, 32, 32, 32)
+    dv = np.abs(vf[0, :, ::4, ::4, ::4].cpu().numpy() - g["vol_feat_sample"]).max()
+    d = np.abs(occ - g["occ"]).max()
+    print(f"real VolumeEncoder stack: max |vol_feat - reference| = {dv:.2e} (|max| {float(g['vol_feat_absmax']):.2f}), max |occ - reference| = {d:.2e}")
+    assert dv <= 1e-4 and d <= 1e-4
+    netG.query(features=[T(feat)], points=T(pts.T)[None], calibs=eye, regressor=netG.if_regressor)
+    assert ve.calls == 1                                                # hoisted: one voxelise + encode per image

@@ -185,8 +185,87 @@ def section_i_variants():
     np.savez_compressed(os.path.join(OUT, "variants.npz"), **out)
 
 
+def pamir_reference_net(a, ve_gain=1.0):
+    """The reference's OWN HGPIFuNet with prior_type='pamir' on CPU: its Voxelization wrapper (lib/net/voxelize.py:64-137) and
+    its VolumeEncoder (lib/net/VE.py:114-183) as they are, with what cannot exist here replaced at the LEAF only:
+      * read_smpl_constants (asset files, lib/dataset/mesh_util.py:240) -> the synthetic tetrahedralised body's constants;
+      * voxelize_cuda.forward_semantic_voxelization (external CUDA wheel, voxelize.py:57) -> the checker's voxeliser
+        (oracle/icon_accel.c: orc_semantic_voxelize) behind the wheel's signature - PARITY UNPINNED for this leaf;
+      * torch.cuda.FloatTensor / Voxelization.check_input (device assertions, voxelize.py:41-49,191-197) -> CPU.
+    Everything between - padding strip, update_param, vertices_to_tetrahedrons, the (b,z,y,x,c) -> (b,c,d,h,w) permute, the
+    VolumeEncoder stack, ve(vol, intermediate_output=self.training), index(vol_feat, xyz), the MLP - is reference code."""
+    from oracle import oracle as orc
+    ref = ref_loader.load()
+    vv, tets, code = synth.make_tetra_body(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0])
+    faces32 = a.smpl_faces[0].astype(np.int32)
+    face_code = (code[faces32[:, 0]] + code[faces32[:, 1]] + code[faces32[:, 2]]) / 3.0
+    mod = sys.modules["lib.net.HGPIFuNet"]
+    mod.read_smpl_constants = lambda folder: (code, face_code.astype(np.float32), faces32, tets.astype(np.int32))
+
+    def leaf(smpl_vertices, smpl_vertex_code, smpl_tetrahedrons, occ_volume, semantic_volume, weight_sum_volume, sigma):
+        # wheel signature (voxelize.py:57-59): surface vertices [B,Vs,3], their codes [B,Vs,3], tetrahedra as POSITIONS [B,T,4,3]
+        assert smpl_vertices.shape[0] == 1
+        vs = smpl_vertices[0].numpy().astype(np.float32)
+        tp = smpl_tetrahedrons[0].numpy().astype(np.float32).reshape(-1, 3)
+        allv = np.concatenate([vs, tp], 0)
+        tidx = (len(vs) + np.arange(len(tp), dtype=np.int64)).reshape(-1, 4)
+        res = semantic_volume.shape[1]
+        out = orc.semantic_voxelize(allv, len(vs), smpl_vertex_code[0].numpy().astype(np.float32), tidx, res=res, sigma=float(sigma))
+        semantic_volume.copy_(torch.from_numpy(out)[None])
+        return occ_volume, semantic_volume, weight_sum_volume
+    sys.modules["voxelize_cuda"].forward_semantic_voxelization = leaf
+    import lib.net.voxelize as vz
+    vz.Voxelization.check_input = lambda self, x: None
+    torch.cuda.FloatTensor = lambda *shape: torch.zeros(*shape, dtype=torch.float32)
+    cfg = ref_loader.make_cfg("pamir")
+    torch.manual_seed(1993)
+    netG = ref.HGPIFuNet(cfg)
+    netG.eval()
+    netG.voxelization.device = torch.device("cpu")
+    # the constructor's weights are xavier with gain 0.02 (VE.py:27-52): volume features of 1e-6 would pin nothing - the
+    # reference's own initialiser with gain 1, and BatchNorm statistics that are not the identity
+    netG.ve.init_weights(init_type="xavier", gain=ve_gain)
+    for r in (netG.ve.res0, netG.ve.res1):
+        r.init_weights(init_type="xavier", gain=ve_gain)
+    g = torch.Generator().manual_seed(7)
+    for m in netG.ve.modules():
+        if isinstance(m, torch.nn.BatchNorm3d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+    return netG, cfg, (vv, tets, code)
+
+
+def section_j_pamir_real_ve():
+    """cfg 4 with the reference's REAL Voxelization wrapper + VolumeEncoder"""
+    ref = ref_loader.load()
+    a = synth.make_assets("body", prior_type="pamir")
+    netG, cfg, (vv, tets, code) = pamir_reference_net(a)
+    feat = synth.make_feature_planes(6, 128, synth.SEED)
+    sd = synth.make_mlp_state_dict(synth.SEED + 1, sdf_channel=None)
+    missing, unexpected = netG.if_regressor.load_state_dict({k: T(v) for k, v in sd.items()}, strict=False)
+    assert not unexpected, unexpected
+    pad_v, pad_f = 5, 9
+    vverts = np.concatenate([vv, np.zeros((pad_v, 3), np.float32)])[None]
+    vfaces = np.concatenate([tets, np.zeros((pad_f, 4), np.int64)])[None]
+    netG.smpl_feat_dict = {"voxel_verts": T(vverts), "voxel_faces": T(vfaces), "pad_v_num": torch.tensor([pad_v]), "pad_f_num": torch.tensor([pad_f])}
+    rng = np.random.RandomState(11)
+    pts = rng.uniform(-1.05, 1.05, (4000, 3)).astype(np.float32)
+    with torch.no_grad():
+        occ = ref.query_func(cfg, netG, [T(feat)], T(pts)[None])[0, 0].numpy()
+        vol = netG.voxelization(T(vverts)[:, :-pad_v])                    # what query() fed the encoder
+        vol_feat = netG.ve(vol, intermediate_output=False)[-1]
+    ve_sd = {"ve." + k: v.numpy() for k, v in netG.ve.state_dict().items() if "num_batches_tracked" not in k}
+    np.savez_compressed(os.path.join(OUT, "query_pamir_real_ve.npz"), points=pts, occ=occ, pad_v=pad_v, pad_f=pad_f,
+                        vol_feat_sample=vol_feat[0, :, ::4, ::4, ::4].numpy(), vol_sum=np.float64(vol.double().sum().item()),
+                        vol_feat_absmax=np.float32(vol_feat.abs().max().item()), **ve_sd)
+    print("query_pamir_real_ve: occ range", occ.min(), occ.max(), "vol_feat |max|", float(vol_feat.abs().max()), "std", float(vol_feat.std()),
+          "vol occupied", int((vol.abs().sum(1) > 0).sum()))
+
+
 if __name__ == "__main__":
-    only = [s for s in ("--display", "--adaptive257", "--variants") if s in sys.argv]
+    only = [s for s in ("--display", "--adaptive257", "--variants", "--pamir-real") if s in sys.argv]
     if not only:
         main()
     if not only or "--display" in only:
@@ -195,3 +274,5 @@ if __name__ == "__main__":
         section_h_adaptive_257()
     if not only or "--variants" in only:
         section_i_variants()
+    if not only or "--pamir-real" in only:
+        section_j_pamir_real_ve()
