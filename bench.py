@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one image per GPU, every rank evaluates a whole volume, no data-path collective (BASELINE.json "
                          "configs[4]: 513^3 x 8 images); default: ONE image, Z-slabs sharded over the ranks (configs[2])")
+    ap.add_argument("--reserve-cus", type=int, default=0,
+                    help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine reserve_cus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the post-timing legs (mx6 fast path, reference schedule, parity sample, mesh Chamfer): "
@@ -315,7 +317,7 @@ def main():
     feats = [T(a.features)]
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions=[33, 65, 129, res] if res == 257 else [res], align_corners=True,
-                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas).to(dev)
+                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=args.reserve_cus).to(dev)
     opt = SimpleNamespace(num_views=1)
 
     def step(r=recon, e=eng):
@@ -497,6 +499,23 @@ def main():
             extras["cold_image_ms"] = cold_cfg
         except Exception as ex:
             extras["cold_image_ms"] = {"error": repr(ex)}
+        # (2c) what leaving CUs to a collective would cost the dense step (multi-GPU knob reserve_cus, measured on ONE GPU: the
+        #      persistent MLP kernel's grid shrinks by k workgroups)
+        try:
+            cost = {}
+            for k in (0, 8, 16, 32):
+                eng._work().set_reserve_cus(k)
+                step(); torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    step()
+                torch.cuda.synchronize()
+                cost[str(k)] = (time.perf_counter() - t1) / 5 * 1e3
+            eng._work().set_reserve_cus(0)
+            extras["reserve_cus_cost"] = {"ms_per_step": cost, "note": "dense 257^3 step on one GPU with the MLP kernel's persistent grid "
+                                          "k workgroups smaller (k CUs left to RCCL when sharded; DenseReconEngine(reserve_cus=k))"}
+        except Exception as ex:
+            extras["reserve_cus_cost"] = {"error": repr(ex)}
         # (4) live parity sample against the checker
         try:
             extras["parity"] = parity_sample(a, res, occ, args.cmap_mode, eng=eng)

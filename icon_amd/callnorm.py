@@ -96,7 +96,7 @@ def _group_stats(mean_c: torch.Tensor, ey2_c: torch.Tensor, groups: int):
 
 @torch.no_grad()
 def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequence[bool], spec: CallNormSpec, rows: torch.Tensor,
-                    c0: int, chunk: int = 1 << 20, keep_bytes: int = 48 << 30):
+                    c0: int, chunk: int = 1 << 20, keep_bytes: int = None):
     """mean / biased variance per channel (expanded from the groups) of every hidden layer's pre-norm output over the call:
     ``rows`` [N,16] device f32 (slots [0,c0) are the MLP input), ``W[l]`` [Cout,Cin] / ``b[l]`` device f32.  -> two lists of
     float64 device tensors."""
@@ -105,6 +105,10 @@ def call_statistics(W: List[torch.Tensor], b: List[torch.Tensor], is_res: Sequen
     n_hidden = len(W) - 1
     if n_pts == 0:
         raise IconAmdError("group / instance norm over an empty call")
+    if keep_bytes is None:
+        # the kept pre-norm outputs are an optimisation (they save recomputing the layers below): at most half of what is
+        # free right now - a device with less head room recomputes instead of running out of memory
+        keep_bytes = (torch.cuda.mem_get_info(dev)[0] // 2) if dev.type == "cuda" else (8 << 30)
     if is_res[0]:
         raise IconAmdError("the first layer cannot be a res layer")
     means, variances = [], []

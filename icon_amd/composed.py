@@ -141,7 +141,7 @@ def query_composed(eng, features, points: torch.Tensor, calibs: torch.Tensor, re
         per_call_norm = regressor.kind in ("group", "instance")
     else:
         per_call_norm = getattr(regressor, "norm", None) in ("group", "instance") and len(getattr(regressor, "norms", ())) > 0
-    step = n if per_call_norm else CHUNK          # Group / InstanceNorm: the statistics are the call's - no chunking
+    step = max(n, 1) if per_call_norm else CHUNK  # Group / InstanceNorm: the statistics are the call's - no chunking (an empty call: no pass)
     preds = []
     for im_feat in features:
         im_feat = im_feat.to(torch.float32)

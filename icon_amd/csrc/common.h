@@ -321,6 +321,9 @@ struct icon_work {
     int8_t *d_signs = nullptr;            // compacted outlier signs of the call
     int64_t cap_signs = 0;
     int64_t *d_total = nullptr;           // device scalar: number of outliers
+    int *d_flag = nullptr;                // "a split-precision launch of THIS workspace produced a non-finite in-cube result" (k_rescue_fused
+                                          //   redoes those points in f32): per workspace, so that launches sharing one MLP handle on different
+                                          //   streams / threads cannot clear each other's flag
     int64_t *d_seg = nullptr;             // [kMaxWorld + 1] prefix of the per-rank counts of a gathered exchange
     int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
     int32_t *d_row_slots = nullptr;       // [rows][kRowCap]
@@ -350,6 +353,7 @@ struct icon_work {
     // between the levels), the search results are indexed through q_map, the occupancies go to d_occ[q_map[i]]
     const int32_t *q_map = nullptr;
     const int *q_n_dev = nullptr;
+    int reserve_cus = 0;                  // the persistent MLP kernel leaves this many CUs free (icon_work_set_reserve_cus)
     struct icon_adaptive *ad = nullptr;   // level buffers of icon_adaptive_eval
     icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done

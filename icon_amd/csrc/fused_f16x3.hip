@@ -516,16 +516,20 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     w.side = reinterpret_cast<const float *>(mlp->d_f16 + kImageBytes);
     w.b3 = mlp->b3; w.inv0 = mlp->f16_inv[0]; w.inv1 = mlp->f16_inv[1]; w.inv2 = mlp->f16_inv[2]; w.c0 = mlp->c0; w.last_op = mlp->last_op;
     w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
-    w.flag = reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
+    // the range flag of THIS workspace (the handle's own word serves icon_mlp_forward, which has no workspace)
+    w.flag = work->d_flag ? work->d_flag : reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
 
     int n_cu = 0;
     int rc = device_cu_count(&n_cu);
     if (rc) return rc;
-    if ((rc = mlp_flag_reset(mlp, st))) return rc;
+    if (work->d_flag) ICON_HIP(hipMemsetAsync(work->d_flag, 0, sizeof(int), st));
+    else if ((rc = mlp_flag_reset(mlp, st))) return rc;
     const MlpPlain plain = mlp_plain_of(mlp);
     const int64_t n_resc = std::min<int64_t>((N + 63) / 64, 2048);
     const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
-    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, n_cu);   // one persistent workgroup per CU (LDS-bound)
+    // one persistent workgroup per CU (LDS-bound: 132 KiB, all registers).  Multi-GPU: a collective's kernels cannot co-reside
+    // with it on a CU - icon_work_set_reserve_cus leaves some CUs to them
+    const unsigned grid = (unsigned)std::min<int64_t>(ntiles, std::max(n_cu - work->reserve_cus, 1));
 #define ICON_FUSED(P, L_, ID)                                                                                              \
     do {                                                                                                                   \
         if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),   \

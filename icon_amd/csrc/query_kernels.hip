@@ -597,12 +597,19 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_grp_mask); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_flag); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
     icon::adaptive_destroy(w->ad);
     delete w;
+    return ICON_OK;
+}
+
+extern "C" int icon_work_set_reserve_cus(icon_work_t *w, int n)
+{
+    ICON_ARG(w != nullptr && n >= 0, "icon_work_set_reserve_cus: bad argument");
+    w->reserve_cus = n;
     return ICON_OK;
 }
 
@@ -692,6 +699,7 @@ int ensure_work(icon_work *w, int64_t n_points, bool need_x)
         w->cap_signs = n_points;
     }
     if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
+    if (!w->d_flag) ICON_HIP(hipMalloc((void **)&w->d_flag, sizeof(int)));
     if (!w->d_seg) ICON_HIP(hipMalloc((void **)&w->d_seg, (kMaxWorld + 1) * sizeof(int64_t)));
     return ICON_OK;
 }

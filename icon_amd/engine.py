@@ -315,6 +315,10 @@ class Workspace(_Handle):
     def set_tie_rule(self, rule: int, ulps: int = 0) -> None:
         check(_lib.lib().icon_work_set_tie_rule(self.h, C.c_int(rule), C.c_int(ulps)), "icon_work_set_tie_rule")
 
+    def set_reserve_cus(self, n: int) -> None:
+        """leave ``n`` CUs free of the persistent MLP kernel (for the RCCL kernels of an overlapped all_gather)"""
+        check(_lib.lib().icon_work_set_reserve_cus(self.h, C.c_int(int(n))), "icon_work_set_reserve_cus")
+
     def profile(self, enable: bool = True) -> None:
         check(_lib.lib().icon_work_profile(self.h, C.c_int(int(enable))), "icon_work_profile")
 
@@ -572,6 +576,21 @@ class IconQueryEngine:
     def _composed_reason(self, reg, im_feat) -> Optional[str]:
         """why this regressor / feature layout is outside what the fused kernels carry (icon_amd/composed.py evaluates it from
         the HIP geometry leaf + PyTorch-ROCm operators instead), or None"""
+        from . import composed
+        # cached per (regressor tensors, feature width): walking a weight-normed state_dict copies it to the host - not per query
+        try:
+            tens = list(reg.values()) if isinstance(reg, dict) else list(reg.parameters())
+            ck = (tuple((id(t), getattr(t, "_version", 0)) for t in tens), int(im_feat.shape[-3]), self.last_op, self.res_layers,
+                  self.smpl_feats, self.prior_type, id(getattr(reg, "last_op", None)))
+        except Exception:
+            ck = None
+        if ck is not None and getattr(self, "_composed_key", None) == ck:
+            return self._composed_val
+        val = self._composed_reason_uncached(reg, im_feat)
+        self._composed_key, self._composed_val, self._composed_src = ck, val, tens if ck is not None else None
+        return val
+
+    def _composed_reason_uncached(self, reg, im_feat) -> Optional[str]:
         from . import composed
         if isinstance(reg, dict):
             sd = effective_filters(reg)

@@ -95,6 +95,9 @@ class DenseReconEngine(nn.Module):
     shard         False -> every rank evaluates the whole lattice (replicas, no collectives)
     balance_slabs cost-weighted Z-slab cut (far-field planes count 1.1; see plane_weights); False -> equal plane counts
     overlap_gather  the volume all_gather in two halves, the first overlapping the second half of the slab's MLP kernel
+    reserve_cus   sharded only: the persistent MLP kernel (one workgroup per CU, the whole CU) leaves this many CUs free so
+                  that RCCL's kernels can run beside it (the overlap is otherwise a hope: they cannot co-reside on a CU);
+                  costs reserve_cus / CUs of the MLP time (bench.py: config.reserve_cus_cost)
     backend       object providing eval_slab / slab_features / slab_finish (tests inject a CPU
                   checker here; the default is the HIP engine)
     """
@@ -102,7 +105,7 @@ class DenseReconEngine(nn.Module):
     def __init__(self, query_func=None, b_min=((-1.0, 1.0, -1.0),), b_max=((1.0, -1.0, 1.0),), resolutions=(257,),
                  channels=1, balance_value=0.5, align_corners=False, visualize=False, debug=False,
                  use_cuda_impl=False, faster=False, use_shadow=False, engine=None, process_group=None,
-                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, **kwargs):
+                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, reserve_cus=0, **kwargs):
         super().__init__()
         self.query_func = query_func
         self.register_buffer("b_min", torch.tensor(b_min).float().unsqueeze(1))   # [1,1,3]
@@ -130,6 +133,7 @@ class DenseReconEngine(nn.Module):
         self.shard = shard
         self.balance_slabs = balance_slabs
         self.overlap_gather = overlap_gather
+        self.reserve_cus = int(reserve_cus)      # CUs the persistent MLP kernel leaves to the collective's kernels when sharded (0: none)
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------
@@ -249,6 +253,9 @@ class DenseReconEngine(nn.Module):
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
         dev = im_feat.device
+        if hasattr(be, "_work") and getattr(self, "_reserved", None) != self.reserve_cus:
+            be._work().set_reserve_cus(self.reserve_cus)
+            self._reserved = self.reserve_cus
         parts = self._slab_cuts(be, res, dist, world, rank, dev)
         z0, z1 = parts[rank]
         per = max(b - a for a, b in parts)

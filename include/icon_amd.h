@@ -180,6 +180,10 @@ int icon_work_destroy(icon_work_t *work);
  *       out_ms[1] = row materialisation + outlier cmap patch (0 on the fused path),
  *       out_ms[2] = the MLP kernel alone (fused path: k_fused_f16x3, which also assembles the rows). */
 int icon_work_profile(icon_work_t *work, int enable);
+/* The fused MLP kernel is a persistent grid of one workgroup per CU that takes a CU whole (132 KiB of LDS, every register):
+ * the kernels of a collective enqueued on another stream (the all_gather of the first half of a Z-slab, recon.py) cannot run
+ * beside it.  n > 0 makes its grid n CUs smaller - the collective gets them; the MLP pays n / CUs.  Default 0. */
+int icon_work_set_reserve_cus(icon_work_t *work, int n);
 int icon_work_stage_ms(icon_work_t *work, float out_ms[3]);
 
 /* ---------------------------------------------------------------------------------------------

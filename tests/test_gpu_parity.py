@@ -1106,6 +1106,32 @@ def test_non_finite_points_are_far_outside_not_a_fault(body, n):
         MeshHandle(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
 
 
+def test_sdf_leaf_and_chamfer_in_voxel_units(body):
+    """the raw cal_sdf_batch leaf (icon_sdf_query) and metrics.chamfer_p2s take meshes in whatever units the caller has them -
+    export_mesh hands out voxel units (0..256), scans come in centimetres: coordinates beyond +-64 must NOT be clamped (round 3
+    clamped them in the leaf; only what cannot be searched - NaN / Inf / beyond 1e18 - is changed).  The body scaled by 128
+    and shifted by 128: same nearest faces as the unit body, distances x128; Chamfer / P2S of two meshes scale with the units."""
+    from icon_amd import metrics
+    from icon_amd.engine import MeshHandle
+    v1, f = body.smpl_verts[0], body.smpl_faces[0]
+    vv = (v1 * 128.0 + 128.0).astype(np.float32)
+    pts1 = synth.stratified_points(v1, f, 4000, seed=21)
+    pts = (pts1 * 128.0 + 128.0).astype(np.float32)
+    h = MeshHandle(T(vv[None]), T(f[None]), T(body.smpl_cmap), T(body.smpl_vis))
+    for n in (pts, np.concatenate([pts] * 30)):                    # wave per point, and the Morton-packet path (> 98,304 points)
+        g = {k: t.cpu().numpy() for k, t in h.sdf_query(T(n)).items()}
+        d2, idx = orc.nearest_brute(vv, f, n[:4000])
+        assert np.array_equal(g["face"][:4000], idx)
+        want = np.sqrt(d2) / np.sqrt(3.0)
+        assert np.abs(np.abs(g["sdf"][:4000]) - want).max() <= 1e-4 * max(1.0, want.max())
+        assert np.abs(g["sdf"][:4000]).max() > 64.0 / np.sqrt(3.0) * 0.5      # distances that a +-64 clamp would have cut
+    # Chamfer in voxel units == 128 x Chamfer in cube units (same samples: the sampler is scale-free)
+    v2 = (v1 * np.float32(1.01)).astype(np.float32)
+    c1, p1 = metrics.chamfer_p2s(T(v1), T(f), T(v2), T(f), n=20000)
+    c128, p128 = metrics.chamfer_p2s(T(vv), T(f), T((v2 * 128.0 + 128.0).astype(np.float32)), T(f), n=20000)
+    assert abs(c128 / c1 - 128.0) <= 0.02 * 128.0 and abs(p128 / p1 - 128.0) <= 0.02 * 128.0, (c1, c128, p1, p128)
+
+
 @pytest.mark.parametrize("case", ["clip0", "clip_tiny", "clip_huge", "scale3", "scale0.01", "shifted", "outside", "flat", "planes_2x2", "planes_64x96"])
 def test_extreme_inputs_vs_oracle(body, case):
     """the corners of the input space: clip bands of 0 / 1e-6 / 100 (every point / no point an outlier), bodies three times
