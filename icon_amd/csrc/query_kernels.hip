@@ -269,6 +269,7 @@ __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMa
         atomicAdd(&out[0], 1ull); atomicAdd(&out[1], (unsigned long long)nn); atomicAdd(&out[2], (unsigned long long)nt);
     }
     if (live && nr.slot < 0) atomicAdd(&out[3], 1ull);
+    if ((threadIdx.x & 63) == 0) atomicMax(&out[4], (unsigned long long)(nn + nt));      // the longest walk: what a latency-bound launch waits for
 }
 
 // one thread per (y, z) row of the slab: triangles whose (y,z) projection covers the row
@@ -1194,22 +1195,22 @@ extern "C" int icon_grid_rows(const icon_mesh_t *mesh, const icon_feat_t *feat, 
     return copy_rows_out(work, d_rows, st);
 }
 
-extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3])
+extern "C" int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[4])
 {
     ICON_ARG(mesh && out, "icon_debug_traversal_stats: null argument");
     LatticeMap L;
     int rc = lattice_map(res, z0, z1, mesh, 0.05f, true, &L);
     if (rc) return rc;
     unsigned long long *d = nullptr;
-    ICON_HIP(hipMalloc((void **)&d, 4 * sizeof(unsigned long long)));
-    ICON_HIP(hipMemset(d, 0, 4 * sizeof(unsigned long long)));
+    ICON_HIP(hipMalloc((void **)&d, 8 * sizeof(unsigned long long)));
+    ICON_HIP(hipMemset(d, 0, 8 * sizeof(unsigned long long)));
     hipLaunchKernelGGL(k_traversal_stats, dim3((unsigned)(L.tx * L.ty * L.tz)), dim3(kBlock), 0, 0, mesh->dev, L, d,
                        getenv("ICON_AMD_STATS_SEEDED") ? atoi(getenv("ICON_AMD_STATS_SEEDED")) : 0);
-    unsigned long long h[4];
+    unsigned long long h[8];
     hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return fail(ICON_ERR_HIP, std::string("traversal stats: ") + hipGetErrorString(e));
-    out[0] = h[0]; out[1] = h[1]; out[2] = h[2];
+    out[0] = h[0]; out[1] = h[1]; out[2] = h[2]; out[3] = h[4];
     return ICON_OK;
 }
 

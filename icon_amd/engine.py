@@ -127,11 +127,11 @@ class MeshHandle(_Handle):
         return dict(nodes=arr[0], depth=arr[1], bin_entries=arr[2], max_bin=arr[3], leaves=arr[4], slots=arr[5])
 
     def traversal_stats(self, res: int, z0: int = 0, z1: Optional[int] = None) -> dict:
-        arr = (C.c_uint64 * 3)()
+        arr = (C.c_uint64 * 4)()
         check(_lib.lib().icon_debug_traversal_stats(self.h, C.c_int(res), C.c_int(z0), C.c_int(res if z1 is None else z1), arr),
               "icon_debug_traversal_stats")
         return dict(waves=arr[0], nodes=arr[1], tris=arr[2], nodes_per_wave=arr[1] / max(arr[0], 1),
-                    tris_per_wave=arr[2] / max(arr[0], 1))
+                    tris_per_wave=arr[2] / max(arr[0], 1), longest_walk=arr[3])
 
     def sdf_query(self, points: torch.Tensor, search: str = "bvh"):
         """cal_sdf_batch (lib/dataset/mesh_util.py:357-396) for points [N,3] ->

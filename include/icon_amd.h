@@ -332,9 +332,10 @@ int icon_sdf_query_ties(const icon_mesh_t *mesh, const float *d_points, int64_t 
 int icon_work_set_tie_rule(icon_work_t *work, int rule, int ulps);
 
 /* Diagnostics (synchronises): BVH work of the lattice traversal over planes [z0,z1):
- * out[0] = wavefronts (4x4x4 point blocks), out[1] = BVH nodes visited, out[2] = triangles tested,
- * both summed over wavefronts (every visit serves all 64 lanes of the wavefront). */
-int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[3]);
+ * out[0] = wavefronts (point blocks: 4^3 on fine lattices, 2^3 on coarse ones), out[1] = BVH nodes visited, out[2] = triangles
+ * tested, both summed over wavefronts (every visit serves all lanes of the wavefront), out[3] = nodes + triangles of the
+ * LONGEST walk (what a latency-bound launch - fewer packets than wave slots - waits for). */
+int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[4]);
 
 /* ---------------------------------------------------------------------------------------------
  * Seg3dLossless.export_mesh (lib/common/seg3d_lossless.py:583-604): marching cubes at 0.5 on
