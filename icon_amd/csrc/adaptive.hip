@@ -198,36 +198,32 @@ __global__ __launch_bounds__(256) void k_ad_blocks(const uint8_t *__restrict__ b
     if (i < nblocks && blk_flag[i]) list[atomicAdd(n_blocks, 1)] = i;          // any order: the blocks are independent
 }
 
-// the exact nearest triangle of every lattice point of the listed P x P x P blocks (one wavefront per block, the packet
-// traversal; P = 4 on fine lattices, 2 / 1 on the coarse ones - common.h: coarse_packet, geom_device.h: lattice_point).
-// P == 1: the "blocks" are the candidates themselves (list = the compacted map, n = the level's point count).
-// These launches hold fewer packets than the GPU has wave slots: their time is the LATENCY of the longest traversal, not a
-// throughput - 4^3 packets on the 65^3 / 129^3 levels walked the union of 64 nearly unrelated searches, 390 us per level.
-template <int P>
-__global__ __launch_bounds__(256) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list, const int *__restrict__ n_list,
-                                                   NearRef near, float sdf_clip)
+// the exact nearest triangle of every lattice point of the listed P x P x P blocks: the packet traversal of k_nearest<lattice>,
+// one block per WORKGROUP, its walk shared by the NW wavefronts (nearest_shared; NW == 1: one block per wavefront).
+// A level's few thousand blocks do not fill the wave slots: with one wavefront per block the launch lasted as long as its
+// longest walk (4^3 blocks: 390 us per level; 2^3 blocks, 8 of 64 lanes at work: 270 us; shared 4^3 blocks: ~100 us).
+template <int P, int NW>
+__global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list,
+                                                                       const int *__restrict__ n_list, NearRef near, float sdf_clip)
 {
-    __shared__ int lds[4 * kStackDepth];
+    constexpr int kWaves = NW == 1 ? 4 : NW;
+    __shared__ int lds[kWaves * kStackDepth];
+    __shared__ __attribute__((aligned(16))) char smem[share_lds_bytes(NW)];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = *n_list;
-    for (int b = blockIdx.x * 4 + wave; b < nb; b += gridDim.x * 4) {
+    for (int b = NW == 1 ? blockIdx.x * 4 + wave : blockIdx.x; b < nb; b += NW == 1 ? gridDim.x * 4 : gridDim.x) {
         const int e = list[b];
-        int ix, iy, iz;
-        bool live;
-        if (P == 1) {                                         // e = [z][y][x] linear index of ONE point
-            ix = e % r; iy = (e / r) % r; iz = e / (r * r);
-            live = true;
-        } else {
-            const int bx = e % nbk, by = (e / nbk) % nbk, bz = e / (nbk * nbk);
-            const bool used = lane < P * P * P;
-            const int l = used ? lane : 0;
-            ix = bx * P + l % P; iy = by * P + (l / P) % P; iz = bz * P + l / (P * P);
-            live = used && ix < r && iy < r && iz < r;
-        }
+        const int bx = e % nbk, by = (e / nbk) % nbk, bz = e / (nbk * nbk);
+        const bool used = lane < P * P * P;
+        const int l = used ? lane : 0;
+        const int ix = bx * P + l % P, iy = by * P + (l / P) % P, iz = bz * P + l / (P * P);
+        const bool live = used && ix < r && iy < r && iz < r;
         const int cx = min(ix, r - 1), cy = min(iy, r - 1), cz = min(iz, r - 1);
         const f3 p = lattice_world(r, cx, cy, cz);
-        const Nearest nr = nearest_packet(m, p, live, lds + wave * kStackDepth, nullptr, nullptr, INFINITY, nullptr, P == 4 ? 21 : 0);
-        if (live && (P > 1 || lane == 0)) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
+        Nearest nr;
+        if (NW == 1) nr = nearest_packet(m, p, live, lds + wave * kStackDepth, nullptr, nullptr, INFINITY, nullptr, P == 4 ? 21 : 0);
+        else nr = nearest_shared<NW>(m, p, live, lds + wave * kStackDepth, smem, P == 4 ? 21 : 0);
+        if (live && (NW == 1 || wave == 0)) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
     }
 }
 
@@ -332,12 +328,11 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M1, a->M0, r, 1, rad, 0, (const uint8_t *)nullptr, rp);
         hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 2, rad, 1, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp);
         uint8_t *C = a->M1;
-        static const int pk_env = getenv("ICON_AMD_PACKET") ? atoi(getenv("ICON_AMD_PACKET")) : 0;
         const bool icon_prior = prior_type == ICON_PRIOR_ICON;
-        const int P = (pk_env == 1 || pk_env == 2 || pk_env == 4) ? pk_env : coarse_packet(r);
+        const int P = lattice_packet();
         const int shift = P == 4 ? 2 : 1;
         const int nbk = (r + P - 1) / P, nblocks = nbk * nbk * nbk;
-        const bool use_blocks = icon_prior && P > 1;
+        const bool use_blocks = icon_prior;
         if (use_blocks) ICON_HIP(hipMemsetAsync(a->blk_flag, 0, (size_t)nblocks, st));
         hipLaunchKernelGGL(k_ad_count, dim3(nbv), dim3(256), 0, st, C, n, a->blk_count);
         hipLaunchKernelGGL(k_ad_scan, dim3(1), dim3(1024), 0, st, a->blk_count, (int)nbv, a->blk_off, a->counters + l);
@@ -361,15 +356,20 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             raw.map = nullptr;                                   // the search writes by lattice index
             int n_cu = 0;
             if ((rc = device_cu_count(&n_cu))) return rc;
-            const dim3 grid((unsigned)(n_cu * 8));
-            if (use_blocks) {
-                ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
-                hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
-                if (P == 4) hipLaunchKernelGGL(k_ad_nearest<4>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
-                else hipLaunchKernelGGL(k_ad_nearest<2>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip);
-            } else {
-                hipLaunchKernelGGL(k_ad_nearest<1>, grid, dim3(256), 0, st, mesh->dev, r, nbk, a->map, a->counters + l, raw, sdf_clip);
-            }
+            // the number of blocks is known on the device only: a grid that fills the wave slots, every workgroup loops
+            static const int share_env = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;   // diagnostics: 1 = one wave per block
+            const int nw = (share_env == 1 || share_env == 8 || share_env == 16) ? share_env : kShareWavesMany;
+            ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
+            hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
+#define ICON_AD_NEAREST(PP, NW) hipLaunchKernelGGL((k_ad_nearest<PP, NW>), dim3((unsigned)(n_cu * 32 / (NW == 1 ? 4 : NW))), dim3(NW == 1 ? 256 : NW * 64), 0, st, \
+                                                   mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip)
+            if (P == 4 && nw == 16) ICON_AD_NEAREST(4, 16);
+            else if (P == 4 && nw == 8) ICON_AD_NEAREST(4, 8);
+            else if (P == 4) ICON_AD_NEAREST(4, 1);
+            else if (nw == 16) ICON_AD_NEAREST(2, 16);
+            else if (nw == 8) ICON_AD_NEAREST(2, 8);
+            else ICON_AD_NEAREST(2, 1);
+#undef ICON_AD_NEAREST
             ICON_HIP(hipGetLastError());
             debug_sync("adaptive: k_ad_nearest", st);
             if ((rc = launch_sign(mesh, cal, r, 0, a->pts, n, sdf_clip, work, false, st))) return rc;

@@ -84,6 +84,12 @@ struct alignas(32) LeafRec {
 static_assert(sizeof(LeafRec) == 384, "LeafRec must be 384 bytes");
 
 constexpr int kLeafMax = 4;        // triangle slots per BVH leaf (short leaves are padded)
+// wavefronts sharing ONE packet's search (geom_device.h: nearest_shared) by the packets of the launch - a launch with fewer
+// packets than the GPU has wave slots lasts as long as its longest walk.  Measured on whole-slab calls, MI355X (search + MLP,
+// 4^3 packets; one wave per packet / 8 / 16 waves): 33^3 (972 packets) 0.58 / 0.20 / 0.18 ms, 65^3 (5,780) 0.66 / 0.48 /
+// 0.65 ms, 129^3 (39,204) 2.31 / 2.97 / 4.49 ms.
+constexpr int kShareWavesMany = 8, kShareWavesFew = 16;
+inline int share_waves(int64_t packets) { return packets <= 1500 ? kShareWavesFew : (packets <= 8000 ? kShareWavesMany : 1); }
 constexpr int kStackDepth = 48;    // per-wave traversal stack entries (LDS)
 constexpr int kXRow = 16;          // floats per point row of the MLP input buffer
 constexpr int kCodeSlot = 15;      // row slot holding the per-point code word
@@ -261,11 +267,15 @@ void mesh_bind_arena(icon_mesh *m, const MeshLayout &L);
 int mesh_build_device(icon_mesh *m, const float *d_verts, const int64_t *d_faces, const float *d_cmap, const float *d_vis, hipStream_t st);
 // adaptive.hip
 void adaptive_destroy(icon_adaptive *a);
-// points per wavefront (pk^3) of the lattice search by resolution: see lattice_point (geom_device.h)
-// (measured on the reference's schedule [33, 65, 129, 257], MI355X, whole schedule per volume: 4^3 everywhere 2.00 ms, single
-//  points 1.62 ms, 2^3 1.42 ms - these launches hold fewer packets than the GPU has wave slots, their time is the latency of
-//  the longest traversal: 8 neighbours still share most of a walk, 64 points of a coarse lattice do not)
-inline int coarse_packet(int res) { return res >= 200 ? 4 : 2; }
+// points per wavefront (pk^3) of the lattice search: 4^3 blocks; ICON_AMD_PACKET=2 (diagnostics) makes them 2^3.
+// (Round-4 history: 2^3 packets were the choice for the coarse lattices of the reference's schedule while a packet was ONE
+//  wavefront's walk - fewer points, shorter union walk, but 8 of 64 lanes at work; with the walk shared by the workgroup
+//  (share_waves) the 4^3 packet wins at every resolution: 33^3 0.35 -> 0.18 ms, 129^3 4.3 -> 2.3 ms per slab call.)
+inline int lattice_packet()
+{
+    static const int pk_env = getenv("ICON_AMD_PACKET") ? atoi(getenv("ICON_AMD_PACKET")) : 0;
+    return pk_env == 2 ? 2 : 4;
+}
 // query_kernels.hip: the outlier sign list of a point-mode call whose size is known on the device only (*n_dev <= n_max)
 int outlier_list_dev(icon_work *w, const int *n_dev, int64_t n_max, hipStream_t st);
 int ensure_work_points(icon_work *w, int64_t n_points);

@@ -324,6 +324,141 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
     return nr;
 }
 
+// ONE packet searched by the NW wavefronts of a workgroup.  The coarse lattices of the reference's schedule hold fewer packets
+// than the GPU has wave slots, so a launch lasts as long as its LONGEST walk - ~1,100 - 2,500 dependent steps, five times the
+// mean, and a perfect starting bound shortens it by 10 % only: the walk is verification, not search.  Every wave holds the
+// same 64 points and the waves share the walk NODE BY NODE (handing each wave one of the 32 subtrees five levels down was
+// measured first: no gain - a packet inside the body finds nearly all of its walk in one or two of them).
+// Every wave runs the depth-first walk on its own LDS stack; when it has to postpone
+// a far child and the workgroup's shared queue is short (fewer entries than waves), the child goes to the queue instead, and
+// a wave whose stack runs empty takes its next subtree from there.  Queue: a ring with tickets (tail / head by LDS atomics),
+// a count of completed pushes (avail) and a ready value per slot; `active` counts the waves that may still push - a wave
+// leaves when it reads avail == 0 and THEN active == 0 (a pop attempt counts as active, so a transiently negative `avail`
+// cannot hide an entry from every wave at once).  The waves share the pruning bound per lane (an LDS minimum of the d^2 bit
+// patterns after every leaf): a subtree is skipped when it cannot tie or beat the best distance ANY wave has found - the
+// triangle that set it stays with that wave, and the keys are merged at the end, so the result is the minimum of (d^2, face)
+// over a superset of the faces within the final bound: the same key as nearest_packet, bit for bit.
+// All NW waves must call this together (workgroup barriers).  The result is valid in wave 0 only.
+constexpr int kRing = 64, kRingEmpty = 0x7fffffff;
+struct ShareLds {
+    unsigned thr[64];
+    int head, tail, avail, active;
+    int pad[12];
+    int ring[kRing];
+    unsigned long long keys[1];           // [NW][64]
+};
+__host__ __device__ constexpr size_t share_lds_bytes(int nw) { return sizeof(ShareLds) + (size_t)nw * 64 * 8; }
+
+__device__ __forceinline__ int share_pop(ShareLds &S, int lane)
+{
+    int t = 0;
+    if (lane == 0) t = atomicSub(&S.avail, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t <= 0) { if (lane == 0) atomicAdd(&S.avail, 1); return kRingEmpty; }
+    int i = 0;
+    if (lane == 0) i = atomicAdd(&S.head, 1);
+    i = __builtin_amdgcn_readfirstlane(i);
+    volatile int *slot = &S.ring[i & (kRing - 1)];
+    int v;
+    do { v = __builtin_amdgcn_readfirstlane(*slot); } while (v == kRingEmpty);      // the push that owns this ticket is completing
+    if (lane == 0) *slot = kRingEmpty;
+    return v;
+}
+__device__ __forceinline__ void share_push(ShareLds &S, int lane, int node)
+{
+    if (lane == 0) {
+        const int i = atomicAdd(&S.tail, 1);
+        while (atomicCAS(&S.ring[i & (kRing - 1)], kRingEmpty, node) != kRingEmpty) {}     // (a full turn of the ring behind: never in practice)
+        atomicAdd(&S.avail, 1);
+    }
+}
+
+template <int NW>
+__device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool live, int *wstack, char *smem /* share_lds_bytes(NW) */, int center_lane)
+{
+    ShareLds &S = *reinterpret_cast<ShareLds *>(smem);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();                                             // (the previous packet's keys have been read)
+    if (threadIdx.x < 64) { S.thr[lane] = 0x7f800000u; S.ring[lane] = lane == 0 ? mesh_root(m) : kRingEmpty; }
+    if (threadIdx.x == 0) { S.head = 0; S.tail = 1; S.avail = 1; S.active = NW; }
+    __syncthreads();
+    unsigned long long key = 0x7f8000007fffffffull;
+    float thr = live ? INFINITY : -INFINITY;
+    int sp = 0;
+    while (true) {
+        int cur;
+        if (sp > 0) cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
+        else {
+            cur = share_pop(S, lane);
+            if (cur == kRingEmpty) {                             // nothing to take: idle until an entry appears or every wave is idle
+                if (lane == 0) atomicSub(&S.active, 1);
+                int spins = 0;
+                while (true) {
+                    const int av = __builtin_amdgcn_readfirstlane(*(volatile int *)&S.avail);
+                    const int ac = __builtin_amdgcn_readfirstlane(*(volatile int *)&S.active);
+                    if (av > 0) {
+                        if (lane == 0) atomicAdd(&S.active, 1);
+                        cur = share_pop(S, lane);
+                        if (cur != kRingEmpty) break;
+                        if (lane == 0) atomicSub(&S.active, 1);
+                    } else if (ac <= 0) break;
+                    if (++spins > (1 << 16)) break;              // (never: ~10 ms; leaving early costs parallelism, not correctness)
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (cur == kRingEmpty) break;
+            }
+            thr = live ? prune_threshold(__uint_as_float(S.thr[lane])) : thr;
+        }
+        while (true) {
+            if (cur < 0) {
+                const int code = ~cur;
+                const int leaf = code >> 2, cnt = (code & 3) + 1;
+                const int npairs = __builtin_amdgcn_readfirstlane((cnt + 1) >> 1);
+                for (int pr = 0; pr < npairs; ++pr) {
+                    cf2 *q = reinterpret_cast<cf2 *>(as_const(&m.leaves[leaf].pair[pr]));
+                    const f2 d2 = tri_dist2_pair(p, q);
+                    const f2 fc = q[22];
+                    const unsigned long long k0 = ((unsigned long long)(unsigned)__float_as_int(d2.x) << 32) | (unsigned)__float_as_int(fc.x);
+                    const unsigned long long k1 = ((unsigned long long)(unsigned)__float_as_int(d2.y) << 32) | (unsigned)__float_as_int(fc.y);
+                    key = (k0 < key) ? k0 : key;
+                    key = (k1 < key) ? k1 : key;
+                }
+                const unsigned mine = (unsigned)(key >> 32);
+                const unsigned old = atomicMin(&S.thr[lane], mine);            // d^2 >= +0: the bit patterns order like the values
+                thr = live ? prune_threshold(__uint_as_float(min(old, mine))) : thr;
+                break;
+            }
+            cf2 *q = reinterpret_cast<cf2 *>(as_const(m.nodes + cur));
+            const f2 dd = box_dist2_pair(q, p);
+            const float d0 = dd.x, d1 = dd.y;
+            const f2 ids = q[6];
+            const int c0 = __float_as_int(ids.x), c1 = __float_as_int(ids.y);
+            const bool v0 = __any(d0 <= thr), v1 = __any(d1 <= thr);
+            if (v0 && v1) {
+                const int e0 = __builtin_amdgcn_readlane(__float_as_int(d0), center_lane);
+                const int e1 = __builtin_amdgcn_readlane(__float_as_int(d1), center_lane);
+                const bool first0 = e0 <= e1;
+                const int far = first0 ? c1 : c0;
+                const int av = __builtin_amdgcn_readfirstlane(*(volatile int *)&S.avail);
+                if (av < NW) share_push(S, lane, far); else wstack[sp++] = far;
+                cur = first0 ? c0 : c1;
+            } else if (v0) cur = c0;
+            else if (v1) cur = c1;
+            else break;
+        }
+    }
+    S.keys[wave * 64 + lane] = key;
+    __syncthreads();
+    Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
+    if (wave == 0) {
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const unsigned long long k = S.keys[w * 64 + lane]; key = (k < key) ? k : key; }
+        nr.d2 = __int_as_float((int)(key >> 32)); nr.face = (int)(key & 0xffffffffu);
+        nr.slot = (nr.face != 0x7fffffff) ? m.face2slot[nr.face] : 0;
+    }
+    return nr;
+}
+
 // Diagnostics - the ALTERNATIVE tie rule: among the faces whose d^2 lies within `ulps` float32 ulps of the minimum
 // `best_bits` (found by a first nearest_packet pass), the one with the HIGHEST face index, together with its own
 // d^2.  ulps = 0 is "highest index on exact ties" - the mirror image of S3; ulps >= 1 stands for any other
@@ -772,10 +907,10 @@ __device__ __forceinline__ LatticeMap lattice_trim(LatticeMap L, const MeshDev &
     return L;
 }
 
-__device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
+// tile t of the (trimmed) tiling, packet `wave` (0..3) of the tile, lane of the packet
+__device__ __forceinline__ bool lattice_point_at(const LatticeMap &L, int t, int wave, int lane, int &ix, int &iy, int &iz)
 {
     const int nb = L.tx * L.ty * L.tz;
-    int t = (int)blockIdx.x;
     if (t >= nb) { ix = iy = iz = 0x3fffffff; return false; }     // a workgroup beyond the (trimmed) tiling
     if (L.remap == 1) t = xcd_remap(t, nb);
     else if (L.remap == 2) {
@@ -797,7 +932,6 @@ __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int 
     // the ones through the body, and the launch waits for the slowest XCD (measured 3.57 vs 3.00 ms).  Rotating the
     // x-position by the row number keeps the mapping a bijection and hands every XCD every column in turn.
     if (L.remap == 0) btx = (btx + btz + bty * L.tz) % L.tx;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     // tiles cover the search region [sx0, sx1) x [sy0, sy1) x planes [sz0, sz1) (iz is relative to the slab).  A wavefront owns
     // a P x P x P block of points, P = L.pk: 4 on the fine lattices; on a COARSE lattice (the first levels of the reference's
     // schedule: spacing 2-8x the triangle size) the 64 points of a 4^3 block have little of their search in common and the
@@ -809,6 +943,10 @@ __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int 
     iy = L.sy0 + bty * P + (l / P) % P;
     iz = L.sz0 + btz * P + l / (P * P);
     return used && ix < L.sx1 && iy < L.sy1 && iz < L.sz1;
+}
+__device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int &iy, int &iz)
+{
+    return lattice_point_at(L, (int)blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, ix, iy, iz);
 }
 // the lane whose box distances order the two children of a node: the block's centre (4^3), its first point otherwise
 __device__ __forceinline__ int packet_center_lane(const LatticeMap &L) { return (L.pk == 0 || L.pk == 4) ? 21 : 0; }

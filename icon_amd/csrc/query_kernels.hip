@@ -117,6 +117,24 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
     if (live) store_near(near, i, nr, sdf_clip);
 }
 
+// Lattices of few packets (33^3 .. 65^3 slabs: the first level of the reference's schedule): one PACKET per workgroup, its walk
+// shared by the NW wavefronts (nearest_shared) - such a launch lasts as long as its longest walk, and this divides the walk.
+// Workgroup b serves packet b & 3 of tile b >> 2 of k_nearest's tiling.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_nearest_shared(MeshDev m, LatticeMap L, NearRef near, float sdf_clip)
+{
+    __shared__ int lds[NW * kStackDepth];
+    __shared__ __attribute__((aligned(16))) char smem[share_lds_bytes(NW)];
+    L = lattice_trim(L, m);
+    if ((int)(blockIdx.x >> 2) >= L.tx * L.ty * L.tz) return;
+    int ix, iy, iz, cx, cy, cz;
+    const bool live = lattice_point_at(L, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), threadIdx.x & 63, ix, iy, iz);
+    lattice_clamp(L, ix, iy, iz, cx, cy, cz);
+    const f3 p = lattice_world(L.res, cx, cy, cz + L.z0);
+    const Nearest nr = nearest_shared<NW>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, smem, packet_center_lane(L));
+    if (live && threadIdx.x < 64) store_near(near, ((int64_t)cz * L.res + cy) * L.res + cx, nr, sdf_clip);
+}
+
 // Diagnostics (icon_sdf_query_ties): winner, runner-up and the ulp gap between their squared distances
 __global__ __launch_bounds__(kBlock) void k_nearest_ties(MeshDev m, const float *__restrict__ pts, int64_t N, const int32_t *__restrict__ perm,
                                                          int32_t *__restrict__ face, int32_t *__restrict__ face2, uint8_t *__restrict__ ulps)
@@ -766,7 +784,11 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps);
+        static const int share_env = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;      // diagnostics: 1 = never, 8 / 16
+        const int nw = (!LATTICE || alt) ? 1 : ((share_env == 1 || share_env == 8 || share_env == 16) ? share_env : share_waves(nb * 4));
+        if (nw == 16) hipLaunchKernelGGL(k_nearest_shared<16>, dim3((unsigned)nb * 4), dim3(16 * 64), 0, st, mesh->dev, L, near, sdf_clip);
+        else if (nw == 8) hipLaunchKernelGGL(k_nearest_shared<8>, dim3((unsigned)nb * 4), dim3(8 * 64), 0, st, mesh->dev, L, near, sdf_clip);
+        else if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps);
         else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0);
     }
     ICON_HIP(hipGetLastError());
@@ -1032,10 +1054,8 @@ static int lattice_map(int res, int z0, int z1, const icon_mesh_t *mesh, float s
     // search region: the whole slab here - the kernel itself leaves out the far faces (lattice_trim: the body's box is
     // known on the device only) and workgroups beyond the trimmed tiling exit at once
     L->sx0 = 0; L->sx1 = res; L->sy0 = 0; L->sy1 = res; L->sz0 = 0; L->sz1 = z1 - z0;
-    // points per wavefront of the search: 4^3 blocks where the lattice is fine (257^3: the packet's 64 searches nearly coincide),
-    // 2^3 / single points on the coarse lattices of the reference's schedule (see lattice_point); ICON_AMD_PACKET overrides
-    static const int pk_env = getenv("ICON_AMD_PACKET") ? atoi(getenv("ICON_AMD_PACKET")) : 0;
-    L->pk = (pk_env == 1 || pk_env == 2 || pk_env == 4) ? pk_env : coarse_packet(res);
+    // points per wavefront of the search: 4^3 blocks (common.h: lattice_packet)
+    L->pk = lattice_packet();
     L->tx = (L->sx1 - L->sx0 + 4 * L->pk - 1) / (4 * L->pk); L->ty = (L->sy1 - L->sy0 + L->pk - 1) / L->pk; L->tz = (L->sz1 - L->sz0 + L->pk - 1) / L->pk;
     L->trim = (off && mesh) ? 1 : 0;
     L->trim_need = std::sqrt(far_box_dist2(sdf_clip)) * 1.001f + 1e-5f;

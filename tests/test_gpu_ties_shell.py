@@ -658,6 +658,24 @@ def test_rows_entry_points_vs_oracle(body):
     assert np.abs(rows33[shell, :13]).max() > 0.5 and ((rows33[:, 15].view(np.int32) & 8) != 0).tolist() == (~shell).tolist()
 
 
+@pytest.mark.parametrize("mesh", ["body", "ico"])
+@pytest.mark.parametrize("res", [17, 33, 65])
+def test_shared_walk_lattice_rows_equal_point_rows(mesh, res):
+    """the lattices of few packets (<= 65^3) search with ONE packet per workgroup, the walk shared by 8 / 16 wavefronts through an
+    LDS queue (geom_device.h: nearest_shared); explicit points go through the one-wave-per-point / one-wave-per-packet
+    searches.  Same points -> the same nearest faces -> the same feature rows, BIT FOR BIT (sdf, cmap, normals, vis, code).
+    Repeated: the sharing is timing dependent, the answer must not be."""
+    a = assets(mesh)
+    eng = make_engine(a)
+    feat = T(a.features)
+    pts = synth.lattice_points(res)
+    want = eng._rows(feat, points=T(pts), calib12=np.eye(4, dtype=np.float32)[:3].copy()).cpu().numpy()
+    for rep in range(4):
+        got = eng._rows(feat, lattice=(res, 0, res)).cpu().numpy()
+        bad = np.nonzero((got.view(np.uint32) != want.view(np.uint32)).any(1))[0]
+        assert len(bad) == 0, f"{mesh} {res}^3 pass {rep}: {len(bad)} rows differ, first {bad[:5]}"
+
+
 # ---------------------------------------------------------------------------------------------
 # the reference's own answers for the configurations outside configs/*.yaml (tests/golden/variants.npz)
 # ---------------------------------------------------------------------------------------------

@@ -20,10 +20,21 @@ for name, cls in (("dense", DenseReconEngine), ("adaptive", AdaptiveReconEngine)
     if name == "host":
         rec.native = False                       # the host-driven schedule (torch bookkeeping around HIP queries)
     f = lambda: rec(opt=opt, netG=eng, features=feats, proj_matrix=None)
-    f(); f(); torch.cuda.synchronize(); t = time.perf_counter()
-    for _ in range(10): occ = f()
-    torch.cuda.synchronize()
-    print(f"{name}: {(time.perf_counter() - t) * 100:.3f} ms per volume", getattr(rec, "last_stats", None))
+    f(); f()
+    for rep in range(int(os.environ.get("REPEAT", "1"))):       # (the first timed loop of the first process on a box runs slow)
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(10): occ = f()
+        torch.cuda.synchronize()
+        print(f"{name}: {(time.perf_counter() - t) * 100:.3f} ms per volume", getattr(rec, "last_stats", None))
+
+if os.environ.get("PERCALL"):                  # every call on its own (the stream drained in between): where do slow loops come from?
+    rec = AdaptiveReconEngine(**kw).cuda()
+    f = lambda: rec(opt=opt, netG=eng, features=feats, proj_matrix=None)
+    f(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(60):
+        t = time.perf_counter(); f(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
+    print("per call ms:", " ".join(f"{x:.2f}" for x in ts))
 
 if os.environ.get("PROFILE"):
     from torch.profiler import profile, ProfilerActivity
