@@ -32,13 +32,13 @@ struct icon_adaptive {
     int res[kAdMaxLevels] = {0};
     float *occ[kAdMaxLevels] = {nullptr};      // level volumes [z][y][x] (the last one is the caller's buffer, not owned)
     uint8_t *P = nullptr;                      // (occ_{l-1} > balance) as bytes, [x][y][z]
-    uint8_t *M0 = nullptr, *M1 = nullptr;      // mask ping-pong, [x][y][z]
+    uint8_t *M1 = nullptr;                     // the level's candidate mask, [x][y][z]
     uint8_t *D[kAdMaxLevels] = {nullptr};      // voxels evaluated up to and including level l, [x][y][z] (level 0: all - not stored)
     int32_t *map = nullptr;                    // compacted candidates: [z][y][x] linear index, in the reference's order
     float *pts = nullptr;                      // their world positions [n][3]
     int32_t *blk_count = nullptr, *blk_off = nullptr;   // compaction scratch (per 256 voxels)
-    uint8_t *blk_flag = nullptr;               // 4x4x4 blocks holding a candidate
-    int32_t *blk_list = nullptr;
+    int32_t *blk_list = nullptr;               // the 4x4x4 blocks holding a candidate (any order; count in counters[8])
+    int *h_counters = nullptr;                 // pinned mirror of `counters` (one direct copy at the end of a schedule, no staging)
     int *counters = nullptr;                   // device: [0..levels) points queried per level, [8] n_blocks, [9] any-positive flag of level 0
     int64_t cap = 0;                           // voxels of the largest queried level
 };
@@ -50,22 +50,24 @@ void adaptive_destroy(icon_adaptive *a)
     if (!a) return;
     for (int l = 0; l + 1 < a->n_levels; ++l) (void)hipFree(a->occ[l]);
     for (int l = 1; l < kAdMaxLevels; ++l) (void)hipFree(a->D[l]);
-    (void)hipFree(a->P); (void)hipFree(a->M0); (void)hipFree(a->M1); (void)hipFree(a->map); (void)hipFree(a->pts);
-    (void)hipFree(a->blk_count); (void)hipFree(a->blk_off); (void)hipFree(a->blk_flag); (void)hipFree(a->blk_list); (void)hipFree(a->counters);
+    (void)hipFree(a->P); (void)hipFree(a->M1); (void)hipFree(a->map); (void)hipFree(a->pts);
+    (void)hipFree(a->blk_count); (void)hipFree(a->blk_off); (void)hipFree(a->blk_list); (void)hipHostFree(a->h_counters); (void)hipFree(a->counters);
     delete a;
 }
 
 namespace {
 
 // ---- F.interpolate(mode='trilinear', align_corners=True): ATen's upsample_trilinear3d expression, term for term --------------
-// One thread = four consecutive x of one (z, y) row: the row's weights and the (up to) 4 x 3 source values are shared
-// (a thread per voxel spent its time on index arithmetic: 75 us for the 257^3 level, 68 MB of output).
-__global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r)
+// One WAVEFRONT = one (z, y) row of the output: the row's weights and source rows are wave-uniform, the lanes take consecutive
+// x (coalesced 256-byte stores; the 257^3 level is 68 MB of output).  History: a thread per voxel spent its time on index
+// arithmetic (75 us for the 257^3 level); four consecutive x per thread shared the row's setup but stored 4 B at a 16 B stride.
+__global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r, int *__restrict__ n_blocks)
 {
-    const int gx = (r + 3) / 4;                                 // x-groups per row
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)r * r * gx) return;
-    const int g = (int)(i % gx), h2 = (int)((i / gx) % r), t2 = (int)(i / ((int64_t)gx * r));
+    if (blockIdx.x == 0 && threadIdx.x == 0) *n_blocks = 0;     // the block list of the level that starts here (k_ad_mask fills it)
+    const int row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (row >= r * r) return;
+    const int lane = threadIdx.x & 63;
+    const int h2 = row % r, t2 = row / r;
     const float scale = (r > 1) ? (float)(rp - 1) / (float)(r - 1) : 0.0f;      // area_pixel_compute_scale, align_corners
     const float t1r = scale * t2, h1r = scale * h2;
     const int t1 = (int)t1r, h1 = (int)h1r;
@@ -73,11 +75,8 @@ __global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, in
     const float t1l = t1r - t1, t0l = 1.0f - t1l, h1l = h1r - h1, h0l = 1.0f - h1l;
     const float *r00 = src + ((int64_t)t1 * rp + h1) * rp, *r01 = src + ((int64_t)t1 * rp + h1 + h1p) * rp;
     const float *r10 = src + ((int64_t)(t1 + t1p) * rp + h1) * rp, *r11 = src + ((int64_t)(t1 + t1p) * rp + h1 + h1p) * rp;
-    float *out = dst + ((int64_t)t2 * r + h2) * r;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int w2 = g * 4 + k;
-        if (w2 >= r) break;
+    float *out = dst + (int64_t)row * r;
+    for (int w2 = lane; w2 < r; w2 += 64) {
         const float w1r = scale * w2;
         const int w1 = (int)w1r;
         const int w1p = (w1 < rp - 1) ? 1 : 0;
@@ -105,37 +104,133 @@ __global__ __launch_bounds__(256) void k_ad_pbits(const float *__restrict__ occ,
     if (any_pos && __any(pos) && (threadIdx.x & 63) == 0) atomicOr(any_pos, 1);
 }
 
-// boundary voxels of level l from the parents' bits (see the header)
-__global__ __launch_bounds__(256) void k_ad_boundary(const uint8_t *__restrict__ P, int rp, uint8_t *__restrict__ B, int r)
+// The candidate mask of level l in ONE pass over 16 x 16 x 32 tiles (x, y, z) with a halo of 4: rows along z are 64-bit masks in
+// LDS, so the boundary test, the three 1-D passes of the box dilation and the removal of the voxels evaluated before are a few
+// word operations per row (four separate kernels over bytes before: 37 us per level, most of it launch floor and strided bytes).
+//   boundary(v)  = the 8 parent corners of v (P at [c >> 1] and [(c >> 1) + (c & 1)] per axis) are not all equal
+//   dilation     = box of radius `rad` per axis, zeros outside the lattice (SmoothConv3D's padding, seg3d_lossless.py:105-112)
+//   done(v)      = all coordinates even and D_prev[v / 2] (level 1: every such voxel) - coords_accum * 2, seg3d_lossless.py:230-234
+constexpr int kMaskTX = 16, kMaskTY = 16, kMaskTZ = 32, kMaskH = 4;
+constexpr int kMaskRX = kMaskTX + 2 * kMaskH, kMaskRY = kMaskTY + 2 * kMaskH, kMaskRZ = kMaskTZ + 2 * kMaskH;      // 24 x 24 x 40
+constexpr int kMaskPX = kMaskRX / 2 + 2, kMaskPY = kMaskRY / 2 + 2, kMaskPZ = kMaskRZ / 2 + 2;                   // parents: 14 x 14 x 22
+__device__ __forceinline__ unsigned long long dup_bits(unsigned long long x)      // bit q -> bits 2q and 2q + 1 (q < 32)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)r * r * r) return;
-    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
-    const int x0 = x >> 1, y0 = y >> 1, z0 = z >> 1, x1 = x0 + (x & 1), y1 = y0 + (y & 1), z1 = z0 + (z & 1);
-    const uint8_t a = P[xyz(rp, x0, y0, z0)];
-    const int diff = (int)(P[xyz(rp, x0, y0, z1)] != a) | (int)(P[xyz(rp, x0, y1, z0)] != a) | (int)(P[xyz(rp, x0, y1, z1)] != a) |
-                     (int)(P[xyz(rp, x1, y0, z0)] != a) | (int)(P[xyz(rp, x1, y0, z1)] != a) | (int)(P[xyz(rp, x1, y1, z0)] != a) | (int)(P[xyz(rp, x1, y1, z1)] != a);
-    B[i] = diff ? 1 : 0;
+    x = (x | (x << 16)) & 0x0000ffff0000ffffull;
+    x = (x | (x << 8)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x << 4)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x | (x << 1);
 }
-
-// one 1-D pass of the box dilation along `axis` (0 x, 1 y, 2 z); the LAST pass drops the voxels that were evaluated before:
-// done(v) = all coordinates even and D_prev[v / 2] (level 0: every voxel) - coords_accum * 2, seg3d_lossless.py:230-234
-__global__ __launch_bounds__(256) void k_ad_dilate(const uint8_t *__restrict__ in, uint8_t *__restrict__ out, int r, int axis, int rad,
-                                                  int last, const uint8_t *__restrict__ Dprev, int rp)
+// Also lists the P x P x P blocks of the search that hold a candidate (shift = log2 P; tiles are whole blocks): one atomic per
+// tile reserves the tile's run of the list (any order: the blocks are independent).
+__global__ __launch_bounds__(256) void k_ad_mask(const uint8_t *__restrict__ P, int rp, const uint8_t *__restrict__ Dprev, uint8_t *__restrict__ C, int r, int rad,
+                                                int shift, int nbk, int32_t *__restrict__ blk_list, int *__restrict__ n_blocks)
 {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)r * r * r) return;
-    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
-    const int c = axis == 0 ? x : (axis == 1 ? y : z);
-    const int64_t stride = axis == 0 ? (int64_t)r * r : (axis == 1 ? r : 1);
-    uint8_t m = 0;
-    for (int d = -rad; d <= rad; ++d)
-        if (c + d >= 0 && c + d < r) m |= in[i + d * stride];
-    if (last && m && !((x | y | z) & 1)) {
-        const bool done = Dprev ? Dprev[xyz(rp, x >> 1, y >> 1, z >> 1)] != 0 : true;
-        if (done) m = 0;
+    __shared__ int wcnt[4], lbase;
+    __shared__ unsigned pm[kMaskPX * kMaskPY];                  // parent rows: bit c = P[x][y][pz0 + c]
+    __shared__ unsigned long long ma[kMaskRX * kMaskRY], mb[kMaskRX * kMaskRY];
+    const int ntx = (r + kMaskTX - 1) / kMaskTX, nty = (r + kMaskTY - 1) / kMaskTY;
+    const int tx = blockIdx.x % ntx, ty = (blockIdx.x / ntx) % nty, tz = blockIdx.x / (ntx * nty);
+    const int ox = tx * kMaskTX - kMaskH, oy = ty * kMaskTY - kMaskH, oz = tz * kMaskTZ - kMaskH;      // region origin (even)
+    const int px0 = ox >> 1, py0 = oy >> 1, pz0 = oz >> 1;       // (arithmetic shifts: -4 -> -2)
+    const int t = threadIdx.x;
+    if (t < kMaskPX * kMaskPY) {
+        const int a = t / kMaskPY, b = t % kMaskPY;
+        const int x = px0 + a, y = py0 + b;
+        unsigned m = 0;
+        if (x >= 0 && x < rp && y >= 0 && y < rp) {
+            const uint8_t *row = P + ((int64_t)x * rp + y) * rp;
+            for (int c = 0; c < kMaskPZ; ++c) { const int z = pz0 + c; if (z >= 0 && z < rp && row[z]) m |= 1u << c; }
+        }
+        pm[t] = m;
     }
-    out[i] = m;
+    __syncthreads();
+    // boundary rows; bit k of a region row = voxel z = oz + k
+    const int zlo = max(0, -oz), zhi = min(kMaskRZ, r - oz);     // region z inside the lattice: [zlo, zhi)
+    const unsigned long long zmask = zhi > zlo ? ((zhi >= 64 ? ~0ull : ((1ull << zhi) - 1ull)) & ~((1ull << zlo) - 1ull)) : 0ull;
+    for (int q = t; q < kMaskRX * kMaskRY; q += 256) {
+        const int i = q / kMaskRY, j = q % kMaskRY;
+        const int x = ox + i, y = oy + j;
+        unsigned long long bm = 0;
+        if (x >= 0 && x < r && y >= 0 && y < r) {
+            const int a0 = (x >> 1) - px0, a1 = a0 + (x & 1), b0 = (y >> 1) - py0, b1 = b0 + (y & 1);
+            const unsigned m00 = pm[a0 * kMaskPY + b0], m01 = pm[a0 * kMaskPY + b1], m10 = pm[a1 * kMaskPY + b0], m11 = pm[a1 * kMaskPY + b1];
+            const unsigned long long o = dup_bits(m00 | m01 | m10 | m11), n = dup_bits(m00 & m01 & m10 & m11);
+            // voxel k: parents k >> 1 and (k + 1) >> 1 = bits k and k + 1 of the duplicated masks
+            bm = ((o | (o >> 1)) & ~(n & (n >> 1))) & zmask;
+        }
+        unsigned long long mz = bm;                              // z pass
+        for (int d = 1; d <= rad; ++d) mz |= (bm << d) | (bm >> d);
+        ma[q] = mz & zmask;
+    }
+    __syncthreads();
+    for (int q = t; q < kMaskRX * kMaskRY; q += 256) {           // y pass
+        const int i = q / kMaskRY, j = q % kMaskRY;
+        unsigned long long m = 0;
+        for (int d = -rad; d <= rad; ++d) if (j + d >= 0 && j + d < kMaskRY) m |= ma[i * kMaskRY + j + d];
+        mb[q] = m;
+    }
+    __syncthreads();
+    {                                                            // x pass: one core row per thread
+        const int i = kMaskH + t / kMaskTY, j = kMaskH + t % kMaskTY;
+        unsigned long long m = 0;
+        for (int d = -rad; d <= rad; ++d) m |= mb[(i + d) * kMaskRY + j];
+        ma[i * kMaskRY + j] = m;                                 // (core rows of `ma` are read by the y pass only, which is over)
+    }
+    __syncthreads();
+    {                                                            // drop what was evaluated before (this thread's own row)
+        const int i = kMaskH + t / kMaskTY, j = kMaskH + t % kMaskTY;
+        const int x = ox + i, y = oy + j;
+        unsigned long long m = (x < r && y < r) ? ma[i * kMaskRY + j] : 0ull;
+        if (m && !((x | y) & 1)) {
+            unsigned long long dm = 0;
+            if (!Dprev) dm = 0x5555555555555555ull;              // region bit k = voxel z = oz + k, oz even
+            else {
+                const uint8_t *drow = Dprev + ((int64_t)(x >> 1) * rp + (y >> 1)) * rp;
+                for (int k = kMaskH; k < kMaskH + kMaskTZ; k += 2) { const int z = oz + k; if (z < r && drow[z >> 1]) dm |= 1ull << k; }
+            }
+            m &= ~dm;
+        }
+        ma[i * kMaskRY + j] = m;
+    }
+    __syncthreads();
+    // store: 32 consecutive z per 32 lanes
+    for (int it = 0; it < 32; ++it) {
+        const int row = it * 8 + (t >> 5), k = t & 31;
+        const int i = kMaskH + row / kMaskTY, j = kMaskH + row % kMaskTY;
+        const int x = ox + i, y = oy + j, z = oz + kMaskH + k;
+        if (x >= r || y >= r || z >= r) continue;
+        C[xyz(r, x, y, z)] = (uint8_t)((ma[i * kMaskRY + j] >> (kMaskH + k)) & 1ull);
+    }
+    if (!blk_list) return;
+    // the search's blocks with a candidate
+    const int bs = 1 << shift, nbx = kMaskTX >> shift, nby = kMaskTY >> shift, nbz = kMaskTZ >> shift;
+    for (int b0 = 0; b0 < nbx * nby * nbz; b0 += 256) {
+        const int b = b0 + t;
+        bool has = false;
+        int id = 0;
+        if (b < nbx * nby * nbz) {
+            const int bz = b % nbz, by = (b / nbz) % nby, bx = b / (nbz * nby);
+            unsigned long long m = 0;
+            for (int di = 0; di < bs; ++di)
+                for (int dj = 0; dj < bs; ++dj) m |= ma[(kMaskH + bx * bs + di) * kMaskRY + kMaskH + by * bs + dj];
+            has = ((m >> (kMaskH + bz * bs)) & ((1ull << bs) - 1ull)) != 0;
+            id = ((((oz + kMaskH) >> shift) + bz) * nbk + (((oy + kMaskH) >> shift) + by)) * nbk + (((ox + kMaskH) >> shift) + bx);
+        }
+        const unsigned long long bal = __ballot(has);
+        const int lane = t & 63, w = t >> 6;
+        __syncthreads();                                         // (lbase / wcnt of the round before have been read)
+        if (lane == 0) wcnt[w] = __popcll(bal);
+        __syncthreads();
+        if (t == 0) { const int tot = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3]; lbase = tot ? atomicAdd(n_blocks, tot) : 0; }
+        __syncthreads();
+        if (has) {
+            int at = lbase + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int q = 0; q < w; ++q) at += wcnt[q];
+            blk_list[at] = id;
+        }
+    }
 }
 
 // compaction in linear ([x][y][z]) order = the reference's nonzero() order: counts per 256 voxels, scan, scatter
@@ -154,10 +249,12 @@ __global__ __launch_bounds__(1024) void k_ad_scan(const int32_t *__restrict__ cn
     __shared__ int wtot[16];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     int carry = 0;
-    for (int base = 0; base < nb; base += 1024) {
-        const int i = base + (int)threadIdx.x;
-        const int v = i < nb ? cnt[i] : 0;
-        int incl = v;
+    for (int base = 0; base < nb; base += 8192) {               // eight consecutive counts per thread (129^3: 8,385 counts, two rounds)
+        const int i = base + (int)threadIdx.x * 8;
+        int v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = i + k < nb ? cnt[i + k] : 0; sum += v[k]; }
+        int incl = sum;
         for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
         __syncthreads();
         if (lane == 63) wtot[w] = incl;
@@ -165,14 +262,16 @@ __global__ __launch_bounds__(1024) void k_ad_scan(const int32_t *__restrict__ cn
         int before = 0, all = 0;
 #pragma unroll
         for (int q = 0; q < 16; ++q) { const int t = wtot[q]; before += q < w ? t : 0; all += t; }
-        if (i < nb) off[i] = carry + before + incl - v;
+        int run = carry + before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { if (i + k < nb) off[i + k] = run; run += v[k]; }
         carry += all;
     }
     if (threadIdx.x == 0) *total = carry;
 }
 
 __global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ C, int r, const int32_t *__restrict__ blk_off,
-                                                   int32_t *__restrict__ map, float *__restrict__ pts, uint8_t *__restrict__ blk_flag, int nbk, int shift)
+                                                   int32_t *__restrict__ map, float *__restrict__ pts)
 {
     __shared__ int ws[4];
     const int64_t n = (int64_t)r * r * r;
@@ -189,22 +288,16 @@ __global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ 
     map[k] = (int32_t)(((int64_t)z * r + y) * r + x);
     const f3 p = lattice_world(r, x, y, z);          // == batch_eval's mapping of (coords * stride), bit for bit (quotients of the same rationals)
     pts[3 * (int64_t)k] = p.x; pts[3 * (int64_t)k + 1] = p.y; pts[3 * (int64_t)k + 2] = p.z;
-    if (blk_flag) blk_flag[((int64_t)(z >> shift) * nbk + (y >> shift)) * nbk + (x >> shift)] = 1;
 }
 
-__global__ __launch_bounds__(256) void k_ad_blocks(const uint8_t *__restrict__ blk_flag, int nblocks, int32_t *__restrict__ list, int *n_blocks)
-{
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nblocks && blk_flag[i]) list[atomicAdd(n_blocks, 1)] = i;          // any order: the blocks are independent
-}
-
-// the exact nearest triangle of every lattice point of the listed P x P x P blocks: the packet traversal of k_nearest<lattice>,
-// one block per WORKGROUP, its walk shared by the NW wavefronts (nearest_shared; NW == 1: one block per wavefront).
+// the exact nearest triangle of the CANDIDATES of the listed P x P x P blocks (the other lanes are parked: the packet walks the
+// union of its lanes' searches, and a block holds ~15 candidates of 64 points): the packet traversal of k_nearest<lattice>,
+// one block per WORKGROUP (a grid that fills the wave slots strides over the list), its walk shared by the NW wavefronts (nearest_shared; NW == 1: one block per wavefront).
 // A level's few thousand blocks do not fill the wave slots: with one wavefront per block the launch lasted as long as its
 // longest walk (4^3 blocks: 390 us per level; 2^3 blocks, 8 of 64 lanes at work: 270 us; shared 4^3 blocks: ~100 us).
 template <int P, int NW>
 __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list,
-                                                                       const int *__restrict__ n_list, NearRef near, float sdf_clip)
+                                                                       const int *__restrict__ n_list, const uint8_t *__restrict__ C, NearRef near, float sdf_clip)
 {
     constexpr int kWaves = NW == 1 ? 4 : NW;
     __shared__ int lds[kWaves * kStackDepth];
@@ -217,8 +310,8 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev 
         const bool used = lane < P * P * P;
         const int l = used ? lane : 0;
         const int ix = bx * P + l % P, iy = by * P + (l / P) % P, iz = bz * P + l / (P * P);
-        const bool live = used && ix < r && iy < r && iz < r;
         const int cx = min(ix, r - 1), cy = min(iy, r - 1), cz = min(iz, r - 1);
+        const bool live = used && ix < r && iy < r && iz < r && C[xyz(r, cx, cy, cz)] != 0;
         const f3 p = lattice_world(r, cx, cy, cz);
         Nearest nr;
         if (NW == 1) nr = nearest_packet(m, p, live, lds + wave * kStackDepth, nullptr, nullptr, INFINITY, nullptr, P == 4 ? 21 : 0);
@@ -227,8 +320,9 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev 
     }
 }
 
-// voxels evaluated up to and including this level
-__global__ __launch_bounds__(256) void k_ad_done(const uint8_t *__restrict__ C, const uint8_t *__restrict__ Dprev, int rp, uint8_t *__restrict__ D, int r)
+// end of a level that another queried level follows: D = voxels evaluated up to and including this level, P = this level's bits
+__global__ __launch_bounds__(256) void k_ad_next(const uint8_t *__restrict__ C, const uint8_t *__restrict__ Dprev, int rp, uint8_t *__restrict__ D, int r,
+                                                const float *__restrict__ occ, float balance, uint8_t *__restrict__ P)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (int64_t)r * r * r) return;
@@ -236,6 +330,7 @@ __global__ __launch_bounds__(256) void k_ad_done(const uint8_t *__restrict__ C, 
     bool d = C[i] != 0;
     if (!d && !((x | y | z) & 1)) d = Dprev ? Dprev[xyz(rp, x >> 1, y >> 1, z >> 1)] != 0 : true;
     D[i] = d ? 1 : 0;
+    P[i] = occ[((int64_t)z * r + y) * r + x] > balance ? 1 : 0;
 }
 
 template <class T>
@@ -294,12 +389,13 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             if (l >= 1 && (rc = grow(&a->D[l], n))) return rc;
         }
         const int nbk = (rq + 1) / 2;                            // blocks of the finest granularity used (2^3)
-        if ((rc = grow(&a->P, (size_t)a->cap)) || (rc = grow(&a->M0, (size_t)a->cap)) || (rc = grow(&a->M1, (size_t)a->cap)) ||
+        if ((rc = grow(&a->P, (size_t)a->cap)) || (rc = grow(&a->M1, (size_t)a->cap)) ||
             (rc = grow(&a->map, (size_t)a->cap)) || (rc = grow(&a->pts, (size_t)a->cap * 3)) ||
             (rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256)) || (rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256)) ||
-            (rc = grow(&a->blk_flag, (size_t)nbk * nbk * nbk)) || (rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk)) ||
+            (rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk)) ||
             (rc = grow(&a->counters, (size_t)16)))
             return rc;
+        ICON_HIP(hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocDefault));
     }
     a->occ[n_levels - 1] = d_out;
     ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
@@ -319,24 +415,21 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         const int r = resolutions[l], rp = resolutions[l - 1];
         const int64_t n = (int64_t)r * r * r;
         const unsigned nbv = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)(((int64_t)r * r * ((r + 3) / 4) + 255) / 256)), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r);
+        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)(((int64_t)r * r + 3) / 4)), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r, a->counters + 8);
         if (l == n_levels - 1) break;                           // "last step no examine": interpolate only
         // P holds (occ_{l-1} > balance): level 0's from above, later levels' from the end of the previous iteration
-        hipLaunchKernelGGL(k_ad_boundary, dim3(nbv), dim3(256), 0, st, a->P, rp, a->M0, r);
         const int rad = l == 1 ? 4 : (l == 2 ? 3 : 1);           // SmoothConv3D 9 / 7 / 3 (seg3d_lossless.py:105-112, 219-226)
-        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 0, rad, 0, (const uint8_t *)nullptr, rp);
-        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M1, a->M0, r, 1, rad, 0, (const uint8_t *)nullptr, rp);
-        hipLaunchKernelGGL(k_ad_dilate, dim3(nbv), dim3(256), 0, st, a->M0, a->M1, r, 2, rad, 1, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp);
+        const unsigned nt = (unsigned)((r + kMaskTX - 1) / kMaskTX) * (unsigned)((r + kMaskTY - 1) / kMaskTY) * (unsigned)((r + kMaskTZ - 1) / kMaskTZ);
         uint8_t *C = a->M1;
         const bool icon_prior = prior_type == ICON_PRIOR_ICON;
         const int P = lattice_packet();
         const int shift = P == 4 ? 2 : 1;
-        const int nbk = (r + P - 1) / P, nblocks = nbk * nbk * nbk;
-        const bool use_blocks = icon_prior;
-        if (use_blocks) ICON_HIP(hipMemsetAsync(a->blk_flag, 0, (size_t)nblocks, st));
+        const int nbk = (r + P - 1) / P;
+        hipLaunchKernelGGL(k_ad_mask, dim3(nt), dim3(256), 0, st, a->P, rp, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), C, r, rad,
+                           shift, nbk, icon_prior ? a->blk_list : (int32_t *)nullptr, a->counters + 8);
         hipLaunchKernelGGL(k_ad_count, dim3(nbv), dim3(256), 0, st, C, n, a->blk_count);
         hipLaunchKernelGGL(k_ad_scan, dim3(1), dim3(1024), 0, st, a->blk_count, (int)nbv, a->blk_off, a->counters + l);
-        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts, use_blocks ? a->blk_flag : (uint8_t *)nullptr, nbk, shift);
+        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts);
         ICON_HIP(hipGetLastError());
         debug_sync("adaptive: upsample + boundary + dilate + compact", st);
         // ---- the level's query: ONE call over the compacted points (count on the device) ---------------------------------
@@ -358,13 +451,12 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             if ((rc = device_cu_count(&n_cu))) return rc;
             // the number of blocks is known on the device only: a grid that fills the wave slots, every workgroup loops
             static const int share_env = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;   // diagnostics: 1 = one wave per block
-            const int nw = (share_env == 1 || share_env == 8 || share_env == 16) ? share_env : kShareWavesMany;
-            ICON_HIP(hipMemsetAsync(a->counters + 8, 0, sizeof(int), st));
-            hipLaunchKernelGGL(k_ad_blocks, dim3((unsigned)((nblocks + 255) / 256)), dim3(256), 0, st, a->blk_flag, nblocks, a->blk_list, a->counters + 8);
+            const int nw = (share_env == 1 || share_env == 4 || share_env == 8 || share_env == 16) ? share_env : kShareWavesMany;
 #define ICON_AD_NEAREST(PP, NW) hipLaunchKernelGGL((k_ad_nearest<PP, NW>), dim3((unsigned)(n_cu * 32 / (NW == 1 ? 4 : NW))), dim3(NW == 1 ? 256 : NW * 64), 0, st, \
-                                                   mesh->dev, r, nbk, a->blk_list, a->counters + 8, raw, sdf_clip)
+                                                   mesh->dev, r, nbk, a->blk_list, a->counters + 8, C, raw, sdf_clip)
             if (P == 4 && nw == 16) ICON_AD_NEAREST(4, 16);
             else if (P == 4 && nw == 8) ICON_AD_NEAREST(4, 8);
+            else if (P == 4 && nw == 4) ICON_AD_NEAREST(4, 4);
             else if (P == 4) ICON_AD_NEAREST(4, 1);
             else if (nw == 16) ICON_AD_NEAREST(2, 16);
             else if (nw == 8) ICON_AD_NEAREST(2, 8);
@@ -386,15 +478,15 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         debug_sync("adaptive: sign + list + fused", st);
         // ---- bookkeeping for the next level -------------------------------------------------------------------------------
         if (l + 1 < n_levels - 1) {                              // a further queried level follows
-            hipLaunchKernelGGL(k_ad_done, dim3(nbv), dim3(256), 0, st, C, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp, a->D[l], r);
-            hipLaunchKernelGGL(k_ad_pbits, dim3(nbv), dim3(256), 0, st, a->occ[l], r, balance, a->P, (int *)nullptr);
+            hipLaunchKernelGGL(k_ad_next, dim3(nbv), dim3(256), 0, st, C, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp, a->D[l], r,
+                               a->occ[l], balance, a->P);
         }
         ICON_HIP(hipGetLastError());
     }
     ICON_HIP(hipGetLastError());
     if (h_counts) {
-        int host[16];
-        ICON_HIP(hipMemcpyAsync(host, a->counters, sizeof(host), hipMemcpyDeviceToHost, st));
+        int *host = a->h_counters;                              // pinned: one direct copy (a pageable target is staged: two copies and a wait, ~70 us)
+        ICON_HIP(hipMemcpyAsync(host, a->counters, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
         ICON_HIP(hipStreamSynchronize(st));
         for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
         h_counts[0] = (int64_t)r0 * r0 * r0;                    // level 0 evaluates every voxel
@@ -408,8 +500,8 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
 extern "C" int icon_adaptive_counts(icon_work_t *work, int n_levels, int64_t *h_counts, void *stream)
 {
     ICON_ARG(work && work->ad && h_counts && n_levels == work->ad->n_levels, "icon_adaptive_counts: no matching icon_adaptive_eval on this workspace");
-    int host[16];
-    ICON_HIP(hipMemcpyAsync(host, work->ad->counters, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    int *host = work->ad->h_counters;
+    ICON_HIP(hipMemcpyAsync(host, work->ad->counters, 16 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     ICON_HIP(hipStreamSynchronize((hipStream_t)stream));
     for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
     h_counts[0] = (int64_t)work->ad->res[0] * work->ad->res[0] * work->ad->res[0];

@@ -334,6 +334,7 @@ struct icon_work {
     int *d_flag = nullptr;                // "a split-precision launch of THIS workspace produced a non-finite in-cube result" (k_rescue_fused
                                           //   redoes those points in f32): per workspace, so that launches sharing one MLP handle on different
                                           //   streams / threads cannot clear each other's flag
+    mutable bool flag_clean = false;      // k_sign of the call in progress has cleared d_flag (no memset launch before the fused kernel)
     int64_t *d_seg = nullptr;             // [kMaxWorld + 1] prefix of the per-rank counts of a gathered exchange
     int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
     int32_t *d_row_slots = nullptr;       // [rows][kRowCap]

@@ -91,9 +91,10 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
                                               float sdf_clip, const int32_t *__restrict__ row_count, const int32_t *__restrict__ row_slots,
                                               NearRef near, uint8_t *__restrict__ code8,
                                               int32_t *__restrict__ block_counts, unsigned long long *__restrict__ grp_mask, float far_box2,
-                                              const int *__restrict__ n_dev)
+                                              const int *__restrict__ n_dev, int *__restrict__ range_flag)
 {
     __shared__ int wsum[4];
+    if (range_flag && blockIdx.x == 0 && threadIdx.x == 0) *range_flag = 0;      // the fused kernel's range flag (it runs after this one): no memset launch
     if (n_dev) { N = *n_dev; if ((int64_t)blockIdx.x * 256 >= N) return; }      // the call's size is on the device (adaptive levels)
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const bool live = i < N;
@@ -125,6 +126,64 @@ __global__ __launch_bounds__(256) void k_sign(MeshDev m, Calib cal, int res, int
     }
     __syncthreads();
     if (threadIdx.x == 0) block_counts[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Point mode, calls of few points (the levels of the reference's schedule): FOUR lanes per point walk the point's ray-bin list
+// (every 4th entry each; the parities add up) - one thread per point was a ~30 us launch of pure latency (a chain of ~100
+// dependent load pairs).  A workgroup is still one 256-point block of the outlier scan / one tile of the fused kernel.
+__global__ __launch_bounds__(1024) void k_sign_wide(MeshDev m, Calib cal, const float *__restrict__ pts, int64_t N, float sdf_clip, NearRef near,
+                                                    uint8_t *__restrict__ code8, int32_t *__restrict__ block_counts,
+                                                    unsigned long long *__restrict__ grp_mask, float far_box2, const int *__restrict__ n_dev,
+                                                    int *__restrict__ range_flag)
+{
+    __shared__ unsigned long long gm[4];
+    if (range_flag && blockIdx.x == 0 && threadIdx.x == 0) *range_flag = 0;
+    if (n_dev) { N = *n_dev; if ((int64_t)blockIdx.x * 256 >= N) return; }
+    if (threadIdx.x < 4) gm[threadIdx.x] = 0ull;
+    __syncthreads();
+    const int s = threadIdx.x & 3, pt = threadIdx.x >> 2;        // point of the block, lane of the point
+    const int64_t i = (int64_t)blockIdx.x * 256 + pt;
+    const bool live = i < N;
+    uint32_t code = 0;
+    const MeshDyn &d = *m.dyn;
+    f3 p = mk3(0.f, 0.f, 0.f);
+    int beg = 0, end = 0;
+    bool brute = false;
+    if (live) {
+        p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        if (d.gy == 0) brute = true;
+        else if (p.y >= d.bin_y0 && p.y <= d.bin_y1 && p.z >= d.bin_z0 && p.z <= d.bin_z1) {
+            const int cy = bin_cell(p.y, d.bin_y0, d.bin_inv_y, d.gy);
+            const int cz = bin_cell(p.z, d.bin_z0, d.bin_inv_z, d.gz);
+            const int cell = cz * d.gy + cy;
+            beg = m.bin_start[cell]; end = m.bin_start[cell + 1];
+        }
+    }
+    int cnt = 0;
+    for (int k = beg + s; k < end; k += 4) {
+        f3 a, b, c; int ia, ib, ic;
+        load_tri_full(m.tris + m.bin_slots[k], a, b, c, ia, ib, ic);
+        cnt += ray_hit(p, a, b, c, ia, ib, ic);
+    }
+    cnt += __shfl_xor(cnt, 1);
+    cnt += __shfl_xor(cnt, 2);
+    if (live) {
+        const bool ins = brute ? inside_brute(m, p) : ((cnt & 1) != 0);
+        const bool far = box_dist2(d.box_lo[0], d.box_lo[1], d.box_lo[2], d.box_hi[0], d.box_hi[1], d.box_hi[2], p) > far_box2 || near_is_far(near, i);
+        code = far ? sign_code_far(p, ins) : sign_code(p, near_d2(near, i), ins, sdf_clip);
+        if (s == 0) code8[i] = (uint8_t)code;
+    }
+    // the outliers of the block's four 64-point groups as masks (the fused kernel derives a point's outlier rank from them)
+    unsigned long long x = __ballot(live && s == 0 && (code & kCodeOutlier));      // bit 4 j = point j of this wave's 16
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000f000f000f000full;
+    x = (x | (x >> 12)) & 0x000000ff000000ffull;
+    x = (x | (x >> 24)) & 0xffffull;
+    const int wave = threadIdx.x >> 6;                           // points 16 wave .. 16 wave + 15 of the block
+    if ((threadIdx.x & 63) == 0 && x) atomicOr(&gm[wave >> 2], x << (16 * (wave & 3)));
+    __syncthreads();
+    if (threadIdx.x < 4) grp_mask[(int64_t)blockIdx.x * 4 + threadIdx.x] = gm[threadIdx.x];
+    if (threadIdx.x == 0) block_counts[blockIdx.x] = __popcll(gm[0]) + __popcll(gm[1]) + __popcll(gm[2]) + __popcll(gm[3]);
 }
 
 // the shell of the planes [za, zb) of a slab whose MLP tiles skipped it: exact zeros (in_cube * pred, HGPIFuNet.py:363)
@@ -431,11 +490,15 @@ int launch_sign(const icon_mesh *mesh, const Calib &cal, int res, int z0, const 
     const float far_box2 = far_box_dist2(sdf_clip);
     if (lattice) hipLaunchKernelGGL(k_sign<true>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
                                     work->d_row_count, work->d_row_slots, work_near(work, mesh), work->d_code8, work->d_block_counts,
-                                    (unsigned long long *)work->d_grp_mask, far_box2, (const int *)nullptr);
+                                    (unsigned long long *)work->d_grp_mask, far_box2, (const int *)nullptr, work->d_flag);
+    else if (work->q_n_dev || N <= 262144)        // few points (a level of the schedule: the size on the device is a few percent of N)
+        hipLaunchKernelGGL(k_sign_wide, dim3((unsigned)nb), dim3(1024), 0, st, mesh->dev, cal, d_points, N, sdf_clip, work_near(work, mesh), work->d_code8,
+                           work->d_block_counts, (unsigned long long *)work->d_grp_mask, far_box2, work->q_n_dev, work->d_flag);
     else hipLaunchKernelGGL(k_sign<false>, dim3((unsigned)nb), dim3(256), 0, st, mesh->dev, cal, res, z0, d_points, N, sdf_clip,
                             (const int32_t *)nullptr, (const int32_t *)nullptr, work_near(work, mesh), work->d_code8, work->d_block_counts,
-                            (unsigned long long *)work->d_grp_mask, far_box2, work->q_n_dev);
+                            (unsigned long long *)work->d_grp_mask, far_box2, work->q_n_dev, work->d_flag);
     ICON_HIP(hipGetLastError());
+    work->flag_clean = work->d_flag != nullptr;
     return ICON_OK;
 }
 
@@ -522,8 +585,9 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     int n_cu = 0;
     int rc = device_cu_count(&n_cu);
     if (rc) return rc;
-    if (work->d_flag) ICON_HIP(hipMemsetAsync(work->d_flag, 0, sizeof(int), st));
+    if (work->d_flag) { if (!work->flag_clean) ICON_HIP(hipMemsetAsync(work->d_flag, 0, sizeof(int), st)); }    // (k_sign of this call cleared it)
     else if ((rc = mlp_flag_reset(mlp, st))) return rc;
+    work->flag_clean = false;
     const MlpPlain plain = mlp_plain_of(mlp);
     const int64_t n_resc = std::min<int64_t>((N + 63) / 64, 2048);
     const int64_t ntiles = (N + kTilePts - 1) / kTilePts;

@@ -343,6 +343,43 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_count(const uint8_t *__r
     }
 }
 
+// The same with 16 lanes per row (slabs of few rows - the coarse lattices: 33^2 = 1,089 threads walking ~100-entry bin lists one
+// after the other were a 28 us launch of pure latency): the lanes of a group take every 16th entry of the bin list, the hits are
+// appended in list order through a ballot (the same row_slots as the one-thread version, entry for entry).
+__global__ __launch_bounds__(kBlock) void k_row_crossings_wide(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots)
+{
+    const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
+    const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
+    const bool have = row < (int64_t)L.nz * L.res;
+    const MeshDyn &d = *m.dyn;
+    if (d.gy == 0) { if (have && s == 0) row_count[row] = -1; return; }
+    const int iy = have ? (int)(row % L.res) : 0, iz = have ? (int)(row / L.res) : 0;
+    const f3 p = lattice_world(L.res, 0, iy, iz + L.z0);
+    int beg = 0, end = 0;
+    if (have && p.y >= d.bin_y0 && p.y <= d.bin_y1 && p.z >= d.bin_z0 && p.z <= d.bin_z1) {
+        const int cy = bin_cell(p.y, d.bin_y0, d.bin_inv_y, d.gy);
+        const int cz = bin_cell(p.z, d.bin_z0, d.bin_inv_z, d.gz);
+        const int cell = cz * d.gy + cy;
+        beg = m.bin_start[cell]; end = m.bin_start[cell + 1];
+    }
+    int n = 0;
+    for (int k = beg + s; __any(k - s < end); k += 16) {
+        bool hit = false;
+        int slot = 0;
+        if (k < end) {
+            slot = m.bin_slots[k];
+            f3 a, b, c; int ia, ib, ic;
+            load_tri_full(m.tris + slot, a, b, c, ia, ib, ic);
+            hit = ray_covers(p, a, b, c, ia, ib, ic);
+        }
+        const unsigned grp = (unsigned)(__ballot(hit) >> (16 * g)) & 0xffffu;
+        const int at = n + __popc(grp & ((1u << s) - 1u));
+        if (hit && at < kRowCap) row_slots[row * kRowCap + at] = slot;
+        n += __popc(grp);
+    }
+    if (have && s == 0) row_count[row] = (n <= kRowCap) ? n : -1;
+}
+
 // Exclusive scan of the per-tile outlier counts (66,308 entries for a 257^3 call; int64 offsets: a 513^3
 // lattice has 1.35e8 points) in two coalesced passes: k_scan_local scans 1,024 consecutive counts per
 // workgroup (wave shuffles + one LDS hop) and records the chunk total, k_scan_apply adds the sum of the
@@ -421,6 +458,41 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_compact(const uint8_t *_
     const int64_t r = outlier_rank(o, block_offsets, wsum);
     if (o) signs[r] = (int8_t)((int)((code >> kCodeSignShift) & 3u) - 1);
 }
+
+// scan + compact in ONE launch for calls of few blocks (the levels of the reference's schedule: 20,000 - 60,000 points, 80 - 250
+// blocks): every workgroup sums the counts before its own block itself (a few hundred ints from L2) instead of waiting for two
+// scan launches - three launches of ~5 us each were the launch floor, not work.  O(blocks^2) reads: the host picks it by size.
+__global__ __launch_bounds__(kScanBlock) void k_outlier_small(const int32_t *__restrict__ counts, const uint8_t *__restrict__ code8, int64_t N,
+                                                              int64_t *__restrict__ block_offsets, int64_t *__restrict__ total, int8_t *__restrict__ signs,
+                                                              const int *__restrict__ n_dev)
+{
+    __shared__ int wsum[kScanBlock / 64];
+    __shared__ int64_t red[2][kScanBlock / 64];
+    if (n_dev) N = *n_dev;
+    const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nblk == 0) *total = 0;
+    if ((int64_t)blockIdx.x >= nblk) return;
+    int64_t before = 0, all = 0;
+    const bool want_all = blockIdx.x == 0;                       // block 0 also publishes the call's total
+    for (int64_t k = threadIdx.x; k < (want_all ? nblk : (int64_t)blockIdx.x); k += kScanBlock) { const int64_t t = counts[k]; all += t; if (k < blockIdx.x) before += t; }
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = before; red[1][w] = all; }
+    __syncthreads();
+    before = 0; all = 0;
+    for (int k = 0; k < kScanBlock / 64; ++k) { before += red[0][k]; all += red[1][k]; }
+    if (threadIdx.x == 0) { block_offsets[blockIdx.x] = before; if (want_all) *total = all; }
+    const int64_t i = (int64_t)blockIdx.x * kScanBlock + threadIdx.x;
+    const uint32_t code = (i < N) ? code8[i] : 0u;
+    const bool o = code & kCodeOutlier;
+    const unsigned long long b = __ballot(o);
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int64_t r = before + __popcll(b & ((1ull << lane) - 1ull));
+    for (int k = 0; k < w; ++k) r += wsum[k];
+    if (o) signs[r] = (int8_t)((int)((code >> kCodeSignShift) & 3u) - 1);
+}
+constexpr int64_t kSmallListBlocks = 16384;      // up to this many blocks (4.2 M points) the one-launch list; worst case 1 GB of L2 reads
 
 // cmap[j][k] = s[(3j + k) mod K]  with j = global outlier rank = rank_offset + local rank
 __global__ __launch_bounds__(kScanBlock) void k_outlier_patch(float *__restrict__ X, const uint8_t *__restrict__ code8, int64_t N, int cmap_slot,
@@ -758,8 +830,12 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
             ICON_HIP(hipMalloc((void **)&work->d_row_slots, (size_t)rows * kRowCap * sizeof(int32_t)));
             work->cap_rows = rows;
         }
-        hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
-                           work->d_row_count, work->d_row_slots);
+        if (rows <= 20000)                       // up to 129^2 rows: 16 lanes per row
+            hipLaunchKernelGGL(k_row_crossings_wide, dim3((unsigned)((rows * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
+                               work->d_row_count, work->d_row_slots);
+        else
+            hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
+                               work->d_row_count, work->d_row_slots);
     }
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
@@ -833,6 +909,13 @@ int outlier_list(icon_work *w, int64_t N, int8_t *signs, bool counted, hipStream
     const int64_t nblk = (N + kScanBlock - 1) / kScanBlock;
     // `counted`: k_sign already left the outlier count of every 256-point block in d_block_counts
     if (!counted) hipLaunchKernelGGL(k_outlier_count, dim3((unsigned)nblk), dim3(kScanBlock), 0, st, w->d_code8, N, w->d_block_counts);
+    if (nblk <= 1024) {                           // a small call (host-known size): one launch
+        hipLaunchKernelGGL(k_outlier_small, dim3((unsigned)std::max<int64_t>(nblk, 1)), dim3(kScanBlock), 0, st, w->d_block_counts, w->d_code8, N, w->d_block_offsets, w->d_total,
+                           signs, (const int *)nullptr);
+        ICON_HIP(hipGetLastError());
+        debug_sync("outlier list (one launch)", st);
+        return ICON_OK;
+    }
     const int64_t nchunks = (nblk + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part, (const int *)nullptr);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total, (const int *)nullptr);
@@ -849,6 +932,12 @@ namespace icon {
 int outlier_list_dev(icon_work *w, const int *n_dev, int64_t n_max, hipStream_t st)
 {
     const int64_t nblk = (n_max + kScanBlock - 1) / kScanBlock;
+    if (nblk <= kSmallListBlocks) {               // (the size on the device is a few percent of n_max: see k_outlier_small)
+        hipLaunchKernelGGL(k_outlier_small, dim3((unsigned)std::max<int64_t>(nblk, 1)), dim3(kScanBlock), 0, st, w->d_block_counts, w->d_code8, n_max, w->d_block_offsets,
+                           w->d_total, w->d_signs, n_dev);
+        ICON_HIP(hipGetLastError());
+        return ICON_OK;
+    }
     const int64_t nchunks = (nblk + 1023) / 1024;
     hipLaunchKernelGGL(k_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_block_counts, nblk, w->d_scan_local, w->d_scan_part, n_dev);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, w->d_scan_local, w->d_scan_part, nchunks, nblk, w->d_block_offsets, w->d_total, n_dev);

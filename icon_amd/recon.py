@@ -568,9 +568,12 @@ class AdaptiveReconEngine(DenseReconEngine):
         feats = kwargs.get("features")
         dev = (feats[-1] if isinstance(feats, (list, tuple)) else feats).device
         b_min, b_max = self.b_min.to(dev), self.b_max.to(dev)
-        rr = torch.tensor([last, last, last], device=dev)
+        rr_cache = []
 
         def batch_eval(coords):                      # coords [1,N,3] in finest-lattice index units (x,y,z)
+            if not rr_cache:                         # (made on first use: a host-to-device copy the native schedule never needs)
+                rr_cache.append(torch.tensor([last, last, last], device=dev))
+            rr = rr_cache[0]
             if self.align_corners:
                 c = coords.float() / (rr - 1)
             else:

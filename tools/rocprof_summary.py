@@ -1,5 +1,6 @@
 """Summaries of rocprofv3 result databases for profiles/ (the .db files themselves stay in gpurun_out/).
   kernel stats : python tools/rocprof_summary.py stats <results.db> > profiles/rNN_kernel_stats_X.csv
+  timeline     : python tools/rocprof_summary.py timeline <results.db> <last N dispatches>
   HBM traffic  : python tools/rocprof_summary.py traffic <fetch.db> <write.db> > profiles/traffic.json
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports
 half of the bytes of a wide (16 B/lane) coalesced streaming read; other access widths and WRITE_SIZE are
@@ -51,6 +52,26 @@ def stats(path):
         print(f"\"{short(n)}\",{c},{t:.1f},{a:.2f},{p:.2f}")      # top_kernels reports microseconds
 
 
+def timeline(path, last):
+    """the last `last` kernel dispatches in launch order: start (us from the first of them), duration, gap to the one before"""
+    con = sqlite3.connect(path)
+    cur = con.cursor()
+    try:
+        rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    except sqlite3.Error as e:
+        names = [r[0] for r in cur.execute("select name from sqlite_master").fetchall()]
+        print("no `kernels` view:", e, names)
+        return
+    rows = rows[-last:]
+    t0 = rows[0][1]
+    print("kernel,start_us,dur_us,gap_us")
+    prev_end = None
+    for n, s_, e_ in rows:
+        gap = (s_ - prev_end) / 1e3 if prev_end is not None else 0.0
+        print(f"\"{short(n)}\",{(s_ - t0) / 1e3:.1f},{(e_ - s_) / 1e3:.2f},{gap:.2f}")
+        prev_end = e_
+
+
 def counters(path, counter):
     cur = sqlite3.connect(path).cursor()
     q = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name",
@@ -92,5 +113,7 @@ def traffic(fetch_db, write_db):
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2], int(sys.argv[3]))
     else:
         traffic(sys.argv[2], sys.argv[3])
