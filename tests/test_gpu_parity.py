@@ -797,6 +797,24 @@ def test_native_schedule_equals_host_driven_schedule(body, res_list, cmap_mode):
     assert torch.equal(v1, v3)
 
 
+def test_fresh_meshes_and_schedules_repeat_bit_for_bit(body):
+    """a new device mesh build + the native schedule, 40 times: the build's queues / atomics and the search's shared walks are
+    timing dependent in HOW they get there - every volume and every per-level count must equal the first (tools/stress_adaptive.py
+    runs 300 per process)"""
+    eng = make_engine(body)
+    feat = T(body.features)
+    v, f, cm, vs = T(body.smpl_verts), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis)
+    first = None
+    for it in range(40):
+        eng.set_mesh(v.clone(), f, cm, vs)
+        vol, counts, pos = eng.adaptive_eval(feat, [33, 65, 129, 257])
+        if first is None:
+            first, c0 = vol.clone(), counts
+            assert pos and counts[1] > 0 and counts[2] > 0
+        else:
+            assert counts == c0 and torch.equal(vol.view(torch.int32), first.view(torch.int32)), f"iteration {it}: {counts} vs {c0}"
+
+
 def test_native_schedule_returns_none_like_the_reference(body):
     """nothing above 0.5 on the coarsest lattice -> None (seg3d_lossless.py:173-177), native and host-driven alike"""
     import copy
