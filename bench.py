@@ -13,7 +13,7 @@ BASELINE.json configs[4] with --res 513).  Per-image constants (feature planes, 
 HBM before the timed region; their one-off preparation time is reported in config.prep_ms.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--res 257] [--prior icon|pamir]
-                    [--precision f16x3|f32|mx6] [--replicas] [--no-cpu-baseline] [--no-extras]
+                    [--precision f16x3|f32] [--replicas] [--no-cpu-baseline] [--no-extras]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -40,11 +40,9 @@ MLP_FLOP_PER_POINT = 344_602          # 2 * (13*512 + 512*256 + 269*128 + 141), 
 ALGO_BYTES_PER_POINT = 4              # one fp32 occupancy write, lattice generated in-kernel
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks for the instruction each path issues
 PEAK_TFLOPS = {"f32": 157.3,          # v_mfma_f32_32x32x2_f32
-               "f16x3": 2500.0,       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
-               "mx6": 2500.0}         # same f16 peak; 4 f16 + 2 fp6 MFMAs per K=64 (1.5 issue slots per K=16)
-KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_fused_f16x3", "mx6": "k_mlp_mx6"}   # f16x3: features + MLP in one kernel
-DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (22-bit operands, f32 accumulate)",
-         "mx6": "f32 via f16 MFMA + block-scaled fp6 cross terms (NOT f32-equivalent; calibrated opt-in)"}
+               "f16x3": 2500.0}       # v_mfma_f32_32x32x16_f16; 3 MFMA products per algorithmic MAC
+KERNEL = {"f32": "k_mlp_f32", "f16x3": "k_fused_f16x3"}   # f16x3: features + MLP in one kernel
+DTYPE = {"f32": "f32", "f16x3": "f32 via 3x f16 split MFMA (22-bit operands, f32 accumulate)"}
 
 
 def host_cores() -> int:
@@ -248,7 +246,7 @@ def main():
     ap.add_argument("--prior", default="icon", choices=["icon", "pamir"])
     ap.add_argument("--cmap-mode", default="reference", choices=["reference", "local"])
     ap.add_argument("--search", default="bvh", choices=["bvh", "brute"])
-    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3", "mx6"])
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"])
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one image per GPU, every rank evaluates a whole volume, no data-path collective (BASELINE.json "
                          "configs[4]: 513^3 x 8 images); default: ONE image, Z-slabs sharded over the ranks (configs[2])")
@@ -256,7 +254,7 @@ def main():
                     help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine reserve_cus)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the post-timing legs (mx6 fast path, reference schedule, parity sample, mesh Chamfer): "
+                    help="skip the post-timing legs (reference schedule, parity sample, mesh Chamfer): "
                          "use it under rocprofv3 so the trace holds only the dense step")
     args = ap.parse_args()
 
@@ -412,26 +410,6 @@ def main():
     if not args.no_extras and world == 1 and rank == 0 and args.prior == "icon":
         from icon_amd.recon import AdaptiveReconEngine, export_mesh_device
         from icon_amd import metrics
-        # (1) explicit fast path: MX-fp6 cross terms, honoured only if the per-checkpoint calibration passes
-        try:
-            e6 = make_engine("mx6")
-            r6 = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[res],
-                                  align_corners=True, engine=e6).to(dev)
-            import warnings
-            with warnings.catch_warnings():
-                warnings.simplefilter("ignore")
-                step(r6, e6); step(r6, e6)
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(3):
-                step(r6, e6)
-            torch.cuda.synchronize()
-            extras["fast_path"] = {"precision": "mx6", "ms_per_step": (time.perf_counter() - t1) / 3 * 1e3,
-                                   "calibrated_max_dev_vs_f16x3": e6.mx6_max_err,
-                                   "accepted": e6._effective_precision == "mx6",
-                                   "note": "~15-bit products: not f32-equivalent, never the headline; gate 2.5e-5"}
-        except Exception as ex:
-            extras["fast_path"] = {"error": repr(ex)}
         # (2) the reference's own coarse-to-fine schedule (Seg3dLossless._forward_faster, ~1 % of the lattice
         #     queried, last level interpolated) on the same engine: second baseline line + the "reference mesh"
         if res == 257:

@@ -18,7 +18,7 @@ CSRC = os.path.join(_HERE, "csrc")
 PRIOR = {"icon": 0, "pamir": 1, "pifu": 2}
 CMAP = {"reference": 0, "local": 1}
 SEARCH = {"bvh": 0, "brute": 1}
-PRECISION = {"f32": 0, "f16x3": 1, "mx6": 2}
+PRECISION = {"f32": 0, "f16x3": 1}
 
 # every symbol include/icon_amd.h declares (tests check that the library exports all of them)
 SYMBOLS = [

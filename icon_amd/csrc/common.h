@@ -250,8 +250,6 @@ struct icon_mlp {
     // 3xf16 split-precision path (mlp_f16x3.hip): chunked hi/lo operand image + f32 side arrays
     char *d_f16 = nullptr;
     float f16_inv[3] = {1.f, 1.f, 1.f};
-    // f16 + MX-fp6 path (mlp_mx6.hip): f16 hi operands, block-scaled fp6 images of W and W - W_hi
-    char *d_mx6 = nullptr;
 };
 
 namespace icon {
@@ -287,7 +285,7 @@ int morton_order(icon_work *w, const float *d_points, const float *calib12, cons
 // mlp_kernels.hip
 int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, int precision, hipStream_t st);
 int mlp_launch_ex(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
-// mlp_kernels.hip: after an f16x3 / mx6 launch over materialised rows - recompute the points the flag was raised for in plain f32
+// mlp_kernels.hip: after an f16x3 launch over materialised rows - recompute the points the flag was raised for in plain f32
 int mlp_rescue_rows(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, hipStream_t st);
 int mlp_flag_reset(const icon_mlp *mlp, hipStream_t st);
 int rescue_always();
@@ -308,13 +306,10 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
 // per-device launch facts (CU count; one-off kernel attributes): a process may drive several devices
 int device_cu_count(int *n_cu);
 int once_per_device(int kernel_id, const std::function<hipError_t()> &set);   // runs `set` once per (kernel_id, current device), under a mutex
-// mlp_mx6.hip
-int mlp_pack_mx6(icon_mlp *m, const std::vector<std::vector<float>> &W, const std::vector<std::vector<float>> &B, hipStream_t st);
-int mlp_launch_mx6(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, bool mask, hipStream_t st);
 }  // namespace icon
 
 struct icon_work {
-    float *d_x = nullptr;                 // [cap_x][16] MLP input rows (materialising paths only: f32 / mx6 / brute force)
+    float *d_x = nullptr;                 // [cap_x][16] MLP input rows (materialising paths only: f32 / brute force)
     int64_t cap_x = 0;
     uint16_t *d_near16 = nullptr;         // nearest-triangle result (NearRef): low slot bits + far flag [cap_points]
     uint8_t *d_near_hi = nullptr;         //   higher slot bits [cap_points_hi], allocated for meshes with > 32,768 slots only

@@ -189,7 +189,6 @@ int mlp_launch(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_out, i
 {
     if (precision == ICON_PRECISION_F32) return mlp_launch_ex(mlp, d_x, N, d_out, true, st);
     if (precision == ICON_PRECISION_F16X3) return mlp_launch_f16x3(mlp, d_x, N, d_out, true, st);
-    if (precision == ICON_PRECISION_MX6) return mlp_launch_mx6(mlp, d_x, N, d_out, true, st);
     return fail(ICON_ERR_ARG, "mlp: unknown precision");
 }
 
@@ -339,7 +338,6 @@ extern "C" int icon_mlp_create(int n_layers, const int *cin, const int *cout, co
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { icon_mlp_destroy(m); return fail(ICON_ERR_HIP, std::string("upload mlp: ") + hipGetErrorString(e)); }
     int rc = mlp_pack_f16x3(m, W, B, st);
-    if (!rc) rc = mlp_pack_mx6(m, W, B, st);
     if (rc) { icon_mlp_destroy(m); return rc; }
     *out = m;
     return ICON_OK;
@@ -406,7 +404,7 @@ int mlp_rescue_rows(const icon_mlp *mlp, const float *d_x, int64_t N, float *d_o
 extern "C" int icon_mlp_destroy(icon_mlp_t *m)
 {
     if (!m) return ICON_OK;
-    (void)hipFree(m->d_blob); (void)hipFree(m->d_f16); (void)hipFree(m->d_mx6);
+    (void)hipFree(m->d_blob); (void)hipFree(m->d_f16);
     delete m;
     return ICON_OK;
 }
@@ -426,6 +424,5 @@ extern "C" int icon_mlp_forward(const icon_mlp_t *mlp, const float *d_x, int64_t
     ICON_ARG(N >= 0, "icon_mlp_forward: negative N");
     if (precision == ICON_PRECISION_F32) return mlp_launch_ex(mlp, d_x, N, d_out, false, (hipStream_t)stream);
     if (precision == ICON_PRECISION_F16X3) return mlp_launch_f16x3(mlp, d_x, N, d_out, false, (hipStream_t)stream);
-    if (precision == ICON_PRECISION_MX6) return mlp_launch_mx6(mlp, d_x, N, d_out, false, (hipStream_t)stream);
     return fail(ICON_ERR_ARG, "icon_mlp_forward: unknown precision");
 }

@@ -1,6 +1,6 @@
 // The MLP in plain f32 for ONE point, one wavefront: the range safety net of the split-precision kernels.
 //
-// The f16x3 / mx6 paths carry every operand as f16 pieces: an input or a hidden activation beyond the f16 range (65504 -
+// The f16x3 path carries every operand as f16 pieces: an input or a hidden activation beyond the f16 range (65504 -
 // three orders of magnitude above anything a body mesh produces, but reachable with a degenerate one: the unclamped
 // barycentric extrapolation of mesh_util.py:319-354 on a sliver triangle) becomes inf and the point's occupancy NaN, where
 // the reference's f32 MLP returns a number.  Those kernels raise a flag when an in-cube result is not finite; k_rescue_*

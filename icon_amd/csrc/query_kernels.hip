@@ -756,7 +756,7 @@ inline void mark(icon_work *w, int k, hipStream_t st)
 }
 
 // scratch for n_points: (slot, d^2) + 1-byte codes + scan arrays + sign list; the 64-byte input rows only
-// for the paths that still materialise them (need_x: precisions f32 / mx6 and the brute-force search)
+// for the paths that still materialise them (need_x: precision f32 and the brute-force search)
 int ensure_work(icon_work *w, int64_t n_points, bool need_x)
 {
     if (n_points > w->cap_points) {

@@ -276,33 +276,9 @@ class MlpHandle(_Handle):
         return out
 
 
-    def calibrate_mx6(self, n: int = 65536, seed: int = 1993) -> float:
-        """max |mx6 - f16x3| of this checkpoint on ``n`` representative input rows (both HIP paths):
-        image / volume features ~ N(0,1); for the 13-channel icon layout the sdf channel is +-1 or
-        inside the clip band, cmap in [0,1] or the +-1 outlier signs, norm a unit vector
-        (lib/net/HGPIFuNet.py:298-311).  The engine refuses mx6 above MX6_GATE."""
-        g = torch.Generator(device="cpu").manual_seed(seed)
-        x = torch.zeros((n, 16), dtype=torch.float32)
-        x[:, : self.c0] = torch.randn((n, self.c0), generator=g)
-        if self.c0 == 13:
-            out = torch.rand(n, generator=g) < 0.9
-            sgn = torch.where(torch.rand(n, generator=g) < 0.5, -1.0, 1.0)
-            x[:, 6] = torch.where(out, sgn, (torch.rand(n, generator=g) - 0.5) * 0.1)
-            cm = torch.rand((n, 3), generator=g)
-            sg3 = torch.where(torch.rand((n, 3), generator=g) < 0.5, -1.0, 1.0)
-            x[:, 7:10] = torch.where(out[:, None], sg3, cm)
-            nr = torch.randn((n, 3), generator=g)
-            x[:, 10:13] = nr / nr.norm(dim=1, keepdim=True).clamp_min(1e-6)
-        xd = x.to(torch.device("cuda", torch.cuda.current_device()))
-        return float((self.forward(xd, "mx6") - self.forward(xd, "f16x3")).abs().max().item())
-
 
 _WARNED_VOXELIZER = False
 _WARNED_COMPOSED = set()      # reasons the composed path was announced for
-
-# precision="mx6" is accepted only while its calibrated deviation from the f32-class path leaves 4x
-# headroom under the 1e-4 occupancy tolerance of BASELINE.json's north star
-MX6_GATE = 2.5e-5
 
 
 class Workspace(_Handle):
@@ -430,7 +406,6 @@ class IconQueryEngine:
         self._mlp = self._mlp_key = self._mlp_src = None
         self._vol = self._vol_key = self._vol_src = None
         self._vol_cached = None
-        self.mx6_max_err = None          # result of the last mx6 calibration (see _mlp_handle)
         self._smpl_feat_dict = None
         self._regressor = None
 
@@ -688,23 +663,11 @@ class IconQueryEngine:
         return self._mlp
 
     def _resolve_precision(self) -> None:
-        """The precision the kernels run at for (current checkpoint, current ``self.precision``) - re-derived whenever
-        either changes, so assigning ``eng.precision`` after the first query takes effect and mx6 is never used
-        uncalibrated.  mx6 carries ~15 significant bits: whether it stays inside the 1e-4 occupancy tolerance depends
-        on the checkpoint (error ~ hidden-activation magnitude x last-layer gain); it is calibrated against the
-        f32-class path on representative rows and refused when it does not have 4x headroom."""
+        """The precision the kernels run at for (current checkpoint, current ``self.precision``) - re-derived whenever either
+        changes, so assigning ``eng.precision`` after the first query takes effect."""
         if self.precision not in _lib.PRECISION:
-            raise IconAmdError(f"unknown precision {self.precision!r}")
-        if self._calibrated == (self._mlp_key, self.precision):
-            return
+            raise IconAmdError(f"unknown precision {self.precision!r} (one of {sorted(_lib.PRECISION)})")
         self._effective_precision = self.precision
-        if self.precision == "mx6":
-            self.mx6_max_err = self._mlp.calibrate_mx6()
-            if not (self.mx6_max_err <= MX6_GATE):
-                import warnings
-                warnings.warn(f"icon_amd: precision='mx6' deviates {self.mx6_max_err:.2e} from the f32-class path on this "
-                              f"checkpoint (gate {MX6_GATE:.1e}); using 'f16x3' instead")
-                self._effective_precision = "f16x3"
         self._calibrated = (self._mlp_key, self.precision)
 
     def _precision(self) -> int:

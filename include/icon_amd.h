@@ -48,13 +48,10 @@ enum { ICON_CMAP_REFERENCE = 0, ICON_CMAP_LOCAL = 1 };
  * with f32 accumulation (22-bit operands; ~1e-6 of the f32 result, 5x the rate) - f32-class.
  * Its range is f16's: an input or hidden activation beyond 65504 (a thousand times anything a body mesh produces; a mesh
  * squashed flat reaches it) would make the result NaN - the kernels flag such points and redo them in plain f32
- * (k_rescue_*, mlp_plain_device.h), so F16X3 and MX6 return a number wherever F32 does.
- * MX6 (explicit opt-in, NOT f32-equivalent): a_hi*b_hi on the f16 MFMA and the two 2^-11 cross terms
- * on the block-scaled fp6 MFMA v_mfma_scale_f32_32x32x64_f8f6f4, i.e. ~15 significant bits per
- * product; its occupancy error scales with the hidden activations and the last layer's gain
- * (3e-4 on an unattenuated checkpoint), so the host layer calibrates it per checkpoint against
- * F16X3 and falls back unless the deviation is <= 2.5e-5. */
-enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1, ICON_PRECISION_MX6 = 2 };
+ * (k_rescue_*, mlp_plain_device.h), so F16X3 returns a number wherever F32 does.
+ * (Rounds 1-3 carried a third, explicitly NOT f32-equivalent mode - f16 main term + block-scaled fp6 cross terms, value 2 -
+ *  that only ever ran the materialising pipeline; removed in round 4: it could never be the headline.) */
+enum { ICON_PRECISION_F32 = 0, ICON_PRECISION_F16X3 = 1 };
 
 /* nearest-triangle search strategy (both give identical results; BRUTE is the validation path) */
 enum { ICON_SEARCH_BVH = 0, ICON_SEARCH_BRUTE = 1 };

@@ -167,13 +167,11 @@ def test_sdf_golden_reference(body):
 # ---------------------------------------------------------------------------------------------
 # MLP
 # ---------------------------------------------------------------------------------------------
-PRECISIONS = ["f32", "f16x3", "mx6"]
+PRECISIONS = ["f32", "f16x3"]
 # f32: exact-f32 MFMA chain (differs from the float64 oracle by f32 round-off only);
-# f16x3: 22-bit split operands on the f16 matrix cores, f32 accumulate;
-# mx6: f16 main term + block-scaled fp6 cross terms (tools/sim_mx6.py predicts <= ~2.5e-5)
-MLP_TOL = {"f32": 1e-5, "f16x3": 2e-5, "mx6": 6e-5}
-# precisions the host layer may select on its own (mx6 is an explicit, calibrated opt-in): these carry
-# the FLAT 1e-4 bar on every checkpoint scale below
+# f16x3: 22-bit split operands on the f16 matrix cores, f32 accumulate
+MLP_TOL = {"f32": 1e-5, "f16x3": 2e-5}
+# both carry the FLAT 1e-4 bar on every checkpoint scale below
 F32_CLASS = ["f32", "f16x3"]
 
 
@@ -235,30 +233,6 @@ def test_hidden_activations_below_the_f16_normal_range(g, layer):
         assert err.max() <= OCC_TOL, (precision, err.max())
 
 
-def test_mx6_is_gated_per_checkpoint(body):
-    """precision='mx6' is only honoured when its calibrated deviation from the f32-class path leaves 4x
-    headroom under 1e-4; on a checkpoint with an unattenuated last layer the engine falls back to f16x3
-    (and the result then carries the f32-class bar)."""
-    import warnings
-    from icon_amd.engine import MX6_GATE
-    x = synth.representative_rows(20000, 13, seed=9)
-    pts = synth.stratified_points(body.smpl_verts[0], body.smpl_faces[0], 4000)
-    for learned_std, expect_fallback in [(0.05, False), (1.0, True)]:
-        a = synth.make_assets("body")
-        a.state_dict = synth.make_mlp_state_dict(seed=synth.SEED, learned_std=learned_std)
-        eng = make_engine(a, precision="mx6")
-        with warnings.catch_warnings(record=True) as w:
-            warnings.simplefilter("always")
-            occ = eng.query([T(a.features)], T(pts.T[None].copy()), torch.eye(4, device=dev())[None])[0].cpu().numpy().ravel()
-        assert eng.mx6_max_err is not None
-        fell_back = eng._effective_precision == "f16x3"
-        print(f"learned_std {learned_std}: calibrated mx6 deviation {eng.mx6_max_err:.2e} (gate {MX6_GATE:.1e}) fallback {fell_back}")
-        assert fell_back == expect_fallback
-        assert fell_back == any("using 'f16x3'" in str(m.message) for m in w)
-        ref, _ = oracle_query(a, pts)
-        assert np.abs(occ - ref).max() <= OCC_TOL
-
-
 @pytest.mark.parametrize("precision", PRECISIONS)
 @pytest.mark.parametrize("n", [1, 31, 32, 33, 127, 128, 129, 255, 256, 257, 777, 40000])
 def test_mlp_forward_vs_oracle(body, n, precision):
@@ -296,13 +270,6 @@ def test_mlp_f16x3_error_statistics(body):
     print(f"max/mean |err|/max(1,|ref|): f32 {np.max(e32 / scale):.2e}/{np.mean(e32 / scale):.2e}  "
           f"f16x3 {np.max(e16 / scale):.2e}/{np.mean(e16 / scale):.2e}")
     assert np.max(e16 / scale) <= 2e-5 and np.mean(e16 / scale) <= 2e-6
-    e6 = np.abs(mlp.forward(T(rows16(x)), precision="mx6").cpu().numpy() - ref)
-    print(f"mx6 {np.max(e6 / scale):.2e}/{np.mean(e6 / scale):.2e}  p99.9 {np.quantile(e6 / scale, 0.999):.2e}")
-    big = np.argmax(e6 / scale)
-    print(f"worst mx6 sample: |x|max {np.abs(x[big]).max():.1f} ref {ref[big]:.3f} err {e6[big]:.2e}")
-    for lim in (2.0, 5.0, 20.0):
-        sel = np.abs(x).max(1) <= lim
-        print(f"  |x|<={lim}: n {sel.sum()} max {np.max((e6 / scale)[sel]):.2e} mean {np.mean((e6 / scale)[sel]):.2e}")
     # the fp6 cross terms make the error proportional to the activations' magnitude: bound it against
     # the input scale for the wide-range samples and absolutely for in-distribution inputs
     xs = np.maximum(scale, np.abs(x).max(1))
@@ -326,10 +293,7 @@ def test_mlp_transpose_detecting(precision):
     x = rng.normal(0, 1, (4096, 13)).astype(np.float32)
     y = MlpHandle({k: torch.from_numpy(v) for k, v in sd.items()}).forward(T(rows16(x)), precision=precision).cpu().numpy()
     ref = orc.Mlp(sd).forward(x, f64=True)[:, 0]
-    # single-term sums: no averaging of the fp6 rounding of the cross terms (2^-4 * 2^-11 per layer), so
-    # mx6 is bounded relative to the activations' magnitude here; a routing slip would be an O(1) error
-    tol = MLP_TOL[precision] if precision != "mx6" else 1e-4 * max(1.0, float(np.abs(x).max()))
-    assert np.abs(y - ref).max() <= tol, np.abs(y - ref).max()
+    assert np.abs(y - ref).max() <= MLP_TOL[precision], np.abs(y - ref).max()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -1180,7 +1144,7 @@ def test_extreme_inputs_vs_oracle(body, case):
             assert np.abs(occ - ref).max() <= OCC_TOL * max(1.0, np.abs(ref).max()), (case, cmap_mode, n)
 
 
-@pytest.mark.parametrize("precision", ["f16x3", "mx6"])
+@pytest.mark.parametrize("precision", ["f16x3"])
 def test_operands_beyond_the_f16_range_are_redone_in_f32(body, precision):
     """the split-precision kernels carry operands as f16 pieces: an input or activation beyond 65504 would be inf and the
     occupancy NaN where the reference's f32 MLP returns a number.  They flag it and the flagged points are recomputed in plain
@@ -1199,7 +1163,7 @@ def test_operands_beyond_the_f16_range_are_redone_in_f32(body, precision):
     got = h.forward(T(rows), precision).cpu().numpy()
     want = omlp.forward(x, f64=True)[:, 0]
     assert np.isfinite(got).all()
-    assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= (OCC_TOL if precision == "f16x3" else 3e-4)
+    assert (np.abs(got - want) / np.maximum(1.0, np.abs(want))).max() <= OCC_TOL
     assert np.abs(want[big]).max() > 1e3                          # the redone points are the large ones
     v = (body.smpl_verts * np.asarray((1.0, 1.0, 1e-4), np.float32)).astype(np.float32)
     with warnings.catch_warnings():
@@ -1212,7 +1176,7 @@ def test_operands_beyond_the_f16_range_are_redone_in_f32(body, precision):
         seen_big = 0
         # the f32 arithmetic itself rounds at 2^-24 of the LARGEST operand: the bound carries a term in max |input| (5e-6 of it:
         # just under the range limit the split's low piece no longer reaches 2^-22)
-        tol = OCC_TOL if eng._effective_precision != "mx6" else 3e-4
+        tol = OCC_TOL
         for res in (5, 9, 17):
             vol = eng.eval_slab(T(body.features), res, 0, res).cpu().numpy().ravel()
             ref, X = orc.query_icon(*args, synth.lattice_points(res), sdf_clip=body.sdf_clip)

@@ -246,7 +246,7 @@ def test_two_threads_drive_engines_on_the_same_device(body):
 
 
 def test_precision_can_be_changed_after_the_first_query(body):
-    """assigning eng.precision takes effect on the next call (and mx6 is never used uncalibrated)"""
+    """assigning eng.precision takes effect on the next call; an unknown one is refused by name"""
     res = 33
     feat = T(body.features)
     eng = make_engine(body, precision="f16x3")
@@ -255,15 +255,10 @@ def test_precision_can_be_changed_after_the_first_query(body):
     b = eng.eval_slab(feat, res, 0, res)
     assert torch.equal(b, make_engine(body, precision="f32").eval_slab(feat, res, 0, res))
     assert not torch.equal(a, b) and (a - b).abs().max() <= 1e-4
-    eng.precision = "mx6"
-    import warnings
-    with warnings.catch_warnings(record=True):
-        warnings.simplefilter("always")
-        c = eng.eval_slab(feat, res, 0, res)
-    assert eng.mx6_max_err is not None                        # calibrated on the switch
-    assert eng._effective_precision in ("mx6", "f16x3")
-    if eng._effective_precision == "f16x3":
-        assert torch.equal(c, a)
+    from icon_amd.engine import IconAmdError
+    eng.precision = "mx6"                                     # (rounds 1-3 had this mode; removed in round 4)
+    with pytest.raises(IconAmdError, match="unknown precision"):
+        eng.eval_slab(feat, res, 0, res)
     eng.precision = "f16x3"
     assert torch.equal(eng.eval_slab(feat, res, 0, res), a)
 
@@ -502,7 +497,7 @@ def test_explicit_points_at_scale_equal_the_lattice_path(body):
 # ---------------------------------------------------------------------------------------------
 # last_op = Sigmoid (cfg.test_mode False, lib/net/HGPIFuNet.py:133; lib/net/MLP.py:68-70)
 # ---------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("precision", ["f16x3", "f32", "mx6"])
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_sigmoid_last_op_vs_oracle(body, precision):
     """a regressor built with last_op = nn.Sigmoid(): sigmoid(MLP) then the in_cube mask, every precision, explicit points,
     lattice and the standalone MLP.forward; the module's own last_op is picked up by attach-style binding"""
@@ -523,7 +518,7 @@ def test_sigmoid_last_op_vs_oracle(body, precision):
         vol = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()
     ref, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp, pts,
                             sdf_clip=body.sdf_clip)
-    tol = OCC_TOL if (precision != "mx6" or eng._effective_precision != "mx6") else 3e-4
+    tol = OCC_TOL
     assert np.abs(occ - ref).max() <= tol
     assert (occ[-3:] == 0).all() and occ.min() >= 0.0 and occ.max() <= 1.0                # in_cube * sigmoid(.)
     inside = (np.abs(pts) < 1.0).all(1)
@@ -531,12 +526,11 @@ def test_sigmoid_last_op_vs_oracle(body, precision):
     ref33, _ = orc.query_icon(body.smpl_verts[0], body.smpl_faces[0], body.smpl_cmap[0], body.smpl_vis[0], body.features, omlp,
                               synth.lattice_points(33), sdf_clip=body.sdf_clip)
     assert np.abs(vol - ref33).max() <= tol
-    if precision != "mx6":
-        x = np.random.RandomState(1).normal(0, 1, (777, 13)).astype(np.float32)
-        from common import rows16
-        h = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()}, last_op="sigmoid")
-        got = h.forward(T(rows16(x)), precision).cpu().numpy()
-        assert np.abs(got - omlp.forward(x)[:, 0]).max() <= OCC_TOL
+    x = np.random.RandomState(1).normal(0, 1, (777, 13)).astype(np.float32)
+    from common import rows16
+    h = MlpHandle({k: torch.from_numpy(v) for k, v in body.state_dict.items()}, last_op="sigmoid")
+    got = h.forward(T(rows16(x)), precision).cpu().numpy()
+    assert np.abs(got - omlp.forward(x)[:, 0]).max() <= OCC_TOL
     # the same weights without last_op differ (the flag is part of the handle key)
     reg.last_op = None
     plain = eng.eval_slab(T(body.features), 33, 0, 33).cpu().numpy().ravel()

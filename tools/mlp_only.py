@@ -6,7 +6,7 @@ import numpy as np, torch
 from icon_amd import synth
 from icon_amd.engine import MlpHandle
 
-prec = sys.argv[1] if len(sys.argv) > 1 else "mx6"
+prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
 n_launch = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = torch.device("cuda:0")
 a = synth.make_assets("body")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # two rocprofv3 --pmc passes over the MLP kernel alone; run on the GPU box: tools/pmc_mlp.sh <precision>
-P=${1:-mx6}
+P=${1:-f16x3}
 R=$PWD
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU -d $R/gpurun_out/pmc_${P}_a -- python $R/tools/mlp_only.py $P 3 > $R/gpurun_out/pmc_${P}_a.log 2>&1
