@@ -250,8 +250,9 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one image per GPU, every rank evaluates a whole volume, no data-path collective (BASELINE.json "
                          "configs[4]: 513^3 x 8 images); default: ONE image, Z-slabs sharded over the ranks (configs[2])")
-    ap.add_argument("--reserve-cus", type=int, default=0,
-                    help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine reserve_cus)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine "
+                         "reserve_cus); -1 = the engine's default (16 over RCCL with the overlapped gather, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the post-timing legs (reference schedule, parity sample, mesh Chamfer): "
@@ -315,7 +316,7 @@ def main():
     feats = [T(a.features)]
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions=[33, 65, 129, res] if res == 257 else [res], align_corners=True,
-                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=args.reserve_cus).to(dev)
+                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
     opt = SimpleNamespace(num_views=1)
 
     def step(r=recon, e=eng):
@@ -545,6 +546,8 @@ def main():
             out["roofline"]["sustained_note"] = sustained["error"]
         if rank_stage is not None:
             out["config"]["rank_stage_ms"] = rank_stage
+        if world > 1 and not args.replicas:
+            out["config"]["reserve_cus"] = getattr(recon, "reserve_cus_effective", None)     # CUs the MLP grid left to the collective
         if not args.no_cpu_baseline and world == 1 and args.prior == "icon":
             out["cpu_baseline"] = cpu_baseline(a, res)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -97,7 +97,8 @@ class DenseReconEngine(nn.Module):
     overlap_gather  the volume all_gather in two halves, the first overlapping the second half of the slab's MLP kernel
     reserve_cus   sharded only: the persistent MLP kernel (one workgroup per CU, the whole CU) leaves this many CUs free so
                   that RCCL's kernels can run beside it (the overlap is otherwise a hope: they cannot co-reside on a CU);
-                  costs reserve_cus / CUs of the MLP time (bench.py: config.reserve_cus_cost)
+                  costs reserve_cus / CUs of the MLP time (bench.py: config.reserve_cus_cost: 16 of 256 CUs = 0.7 % of a step).
+                  None (default) = 16 when the volume gather overlaps the MLP kernel over a device backend (nccl = RCCL), else 0
     backend       object providing eval_slab / slab_features / slab_finish (tests inject a CPU
                   checker here; the default is the HIP engine)
     """
@@ -105,7 +106,7 @@ class DenseReconEngine(nn.Module):
     def __init__(self, query_func=None, b_min=((-1.0, 1.0, -1.0),), b_max=((1.0, -1.0, 1.0),), resolutions=(257,),
                  channels=1, balance_value=0.5, align_corners=False, visualize=False, debug=False,
                  use_cuda_impl=False, faster=False, use_shadow=False, engine=None, process_group=None,
-                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, reserve_cus=0, **kwargs):
+                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, reserve_cus=None, **kwargs):
         super().__init__()
         self.query_func = query_func
         self.register_buffer("b_min", torch.tensor(b_min).float().unsqueeze(1))   # [1,1,3]
@@ -133,7 +134,7 @@ class DenseReconEngine(nn.Module):
         self.shard = shard
         self.balance_slabs = balance_slabs
         self.overlap_gather = overlap_gather
-        self.reserve_cus = int(reserve_cus)      # CUs the persistent MLP kernel leaves to the collective's kernels when sharded (0: none)
+        self.reserve_cus = None if reserve_cus is None else int(reserve_cus)   # CUs the persistent MLP kernel leaves to the collective's kernels when sharded (None: auto)
         self.last_stats = {}
 
     # ------------------------------------------------------------------------------------------
@@ -253,9 +254,13 @@ class DenseReconEngine(nn.Module):
     def _forward_sharded(self, be, im_feat, res, dist, world, rank):
         g = self.process_group
         dev = im_feat.device
-        if hasattr(be, "_work") and getattr(self, "_reserved", None) != self.reserve_cus:
-            be._work().set_reserve_cus(self.reserve_cus)
-            self._reserved = self.reserve_cus
+        want = self.reserve_cus
+        if want is None:                 # auto: RCCL's kernels need CUs of their own to run BESIDE the persistent MLP grid
+            want = 16 if (self.overlap_gather and dist.get_backend(g) == "nccl") else 0
+        if hasattr(be, "_work") and getattr(self, "_reserved", None) != want:
+            be._work().set_reserve_cus(want)
+            self._reserved = want
+        self.reserve_cus_effective = want
         parts = self._slab_cuts(be, res, dist, world, rank, dev)
         z0, z1 = parts[rank]
         per = max(b - a for a, b in parts)
