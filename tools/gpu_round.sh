@@ -16,11 +16,27 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_stats -- pyth
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/gpurun_out/${T}_fetch -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/gpurun_out/${T}_write -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d $R/gpurun_out/${T}_pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_pmc.log 2>&1
+if [ -n "$WITH_LDS" ]; then
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD -d $R/gpurun_out/${T}_lds -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_lds.log 2>&1
+fi
+# the reference's schedule as one native call: kernel stats + the launch timeline of the last volume; the per-image mesh build
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_adaptive -- env REPEAT=2 WHICH=adaptive python $R/tools/time_adaptive.py > $R/gpurun_out/${T}_adaptive.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_meshbuild -- python $R/tools/time_mesh_build.py 20 > $R/gpurun_out/${T}_meshbuild.log 2>&1
 cd $R
 python tools/rocprof_summary.py stats $(find gpurun_out/${T}_stats -name "*.db" | head -1) > gpurun_out/${T}_kernel_stats.csv; head -9 gpurun_out/${T}_kernel_stats.csv
 python tools/rocprof_summary.py traffic $(find gpurun_out/${T}_fetch -name "*.db" | head -1) $(find gpurun_out/${T}_write -name "*.db" | head -1) > gpurun_out/${T}_traffic.json
 python tools/pmc_extract.py $(find gpurun_out/${T}_pmc -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc.txt
+if [ -n "$WITH_LDS" ]; then
 python tools/pmc_extract.py $(find gpurun_out/${T}_lds -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc_lds.txt
 python tools/mlp_power_probe.py f16x3 5 > gpurun_out/${T}_power_probe.txt; cat gpurun_out/${T}_power_probe.txt
+fi
+DBA=$(find gpurun_out/${T}_adaptive -name "*.db" | head -1)
+python tools/rocprof_summary.py stats $DBA > gpurun_out/${T}_adaptive_kernel_stats.csv
+python tools/rocprof_summary.py timeline $DBA 36 > gpurun_out/${T}_adaptive_timeline.csv
+grep "^adaptive" gpurun_out/${T}_adaptive.log | cut -c1-100
+python tools/rocprof_summary.py stats $(find gpurun_out/${T}_meshbuild -name "*.db" | head -1) | grep "k_face_prep\|k_vertex_normals\|k_bvh\|k_tri_records\|k_scan_cells\|k_bin_\|kernel,calls" > gpurun_out/${T}_mesh_build_kernel_stats.csv
+grep "^build 1[0-9]" gpurun_out/${T}_meshbuild.log | cut -c1-170 | head -3
+python tools/time_coarse.py 2>/dev/null | grep "^slab" > gpurun_out/${T}_coarse_slabs.txt; cat gpurun_out/${T}_coarse_slabs.txt
+python tools/trav_stats.py 2>/dev/null | grep "^33\|^65\|^129\|^257" | cut -c1-250 > gpurun_out/${T}_traversal_stats.txt
+for k in 1 2 3; do python tools/stress_adaptive.py 2>/dev/null | grep "stress ok\|MISMATCH"; done > gpurun_out/${T}_stress.txt; cat gpurun_out/${T}_stress.txt
 find gpurun_out -name "*.db" -delete
