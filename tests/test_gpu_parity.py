@@ -270,11 +270,6 @@ def test_mlp_f16x3_error_statistics(body):
     print(f"max/mean |err|/max(1,|ref|): f32 {np.max(e32 / scale):.2e}/{np.mean(e32 / scale):.2e}  "
           f"f16x3 {np.max(e16 / scale):.2e}/{np.mean(e16 / scale):.2e}")
     assert np.max(e16 / scale) <= 2e-5 and np.mean(e16 / scale) <= 2e-6
-    # the fp6 cross terms make the error proportional to the activations' magnitude: bound it against
-    # the input scale for the wide-range samples and absolutely for in-distribution inputs
-    xs = np.maximum(scale, np.abs(x).max(1))
-    assert np.max(e6 / xs) <= 2e-5 and np.mean(e6 / xs) <= 2e-6
-    assert np.max(e6[np.abs(x).max(1) <= 5.0]) <= 3e-5
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)

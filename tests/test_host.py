@@ -402,3 +402,14 @@ def test_host_mesh_builder_invariants(mesh):
             cz = int(np.clip(np.floor((np.float32(0.5) * (tlo[fc, 2] + thi[fc, 2]) - np.float32(z0)) * np.float32(iz)), 0, gz - 1))
             c = cz * gy + cy
             assert p in slots[start[c]:start[c + 1]]
+
+
+def test_python_sources_bind_every_name_they_load():
+    """tools/check_names.py over the package, the tests, bench.py and the tools: a GPU-only test that loads a name bound nowhere in
+    its module fails on the GPU box only - after the round (the removal of a precision mode left one behind in round 4)"""
+    import glob, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = (glob.glob(os.path.join(root, "tests", "*.py")) + glob.glob(os.path.join(root, "icon_amd", "*.py")) +
+             glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_names.py")] + sorted(files), capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout

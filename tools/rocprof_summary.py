@@ -35,6 +35,9 @@ def kernel_sources_sha() -> str:
     return h.hexdigest()[:16]
 
 
+# kernels of the per-image preparation (device mesh build, feature plane packing): not part of a step
+PREP_KERNELS = ("pack_planes", "k_face_prep", "k_vertex_normals", "k_bvh_", "k_tri_records", "k_scan_cells", "k_bin_fill", "k_bin_sort")
+
 # FETCH_SIZE calibration factors (true bytes / reported bytes) measured on known array sizes - see the module docstring
 FETCH_CALIBRATION = {"k_fused_f16x3": 1.0, "k_outlier_compact": 1.33}
 
@@ -84,7 +87,7 @@ def traffic(fetch_db, write_db):
     out = collections.OrderedDict()
     tot_raw = tot_cor = tot_w = 0.0
     per = {}
-    tot_best = 0.0
+    tot_best = prep = 0.0
     for k in sorted(set(f) | set(w)):
         fr = f.get(k, (0.0, 0))[0] * 1024.0
         wr = w.get(k, (0.0, 0))[0] * 1024.0
@@ -94,7 +97,8 @@ def traffic(fetch_db, write_db):
             per[k]["fetch_bytes_calibrated"] = cal * fr
             per[k]["fetch_calibration_factor"] = cal
         per[k]["fetch_bytes_best"] = cal * fr if cal is not None else 2.0 * fr
-        if "pack_planes" in k:          # per-image preparation, not part of a step
+        if any(n in k for n in PREP_KERNELS):      # per-image preparation, not part of a step: summed separately
+            prep += per[k]["fetch_bytes_best"] + wr
             continue
         tot_raw += fr; tot_cor += 2.0 * fr; tot_w += wr; tot_best += per[k]["fetch_bytes_best"]
     out["kernel_sources_sha"] = kernel_sources_sha()
@@ -104,6 +108,7 @@ def traffic(fetch_db, write_db):
     out["per_kernel"] = per
     out["step_total_bytes"] = {"fetch_raw": tot_raw, "fetch_x2": tot_cor, "fetch_best": tot_best, "write": tot_w,
                                "fetch_x2_plus_write": tot_cor + tot_w, "fetch_best_plus_write": tot_best + tot_w}
+    out["prep_total_bytes"] = prep      # the per-image mesh build + plane packing (once per image, outside the step)
     for k, v in per.items():
         key = k.split("::")[-1].split("<")[0]
         out[key + "_bytes_per_launch"] = v["fetch_bytes_best"] + v["write_bytes"]
