@@ -139,6 +139,41 @@ def test_queries_on_device_built_mesh_vs_oracle(name):
     assert np.array_equal(gb[: len(pts)], idx)
 
 
+def test_full_query_on_a_mesh_whose_ray_bins_overflowed():
+    """3,000 copies of one triangle: the ray-bin lists do not fit their buffer (kMeshBinOverflow), the inside test of EVERY
+    kernel falls back to the brute-force parity count - the 4-lane sign kernel of small calls, the row crossings and the
+    lattice sign kernel of slabs, the native schedule.  Occupancy vs the oracle (points and a 33^3 lattice), and the schedule
+    against the host-driven one."""
+    from types import SimpleNamespace
+    from icon_amd.engine import IconQueryEngine, query_func
+    from icon_amd.recon import AdaptiveReconEngine
+    a = assets("body")
+    v, f, cm, vs = mesh_arrays("dup")
+    eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip)
+    eng.set_mesh(T(v[None]), T(f[None]), T(cm[None]), T(vs[None, :, None]))
+    eng.set_regressor({k: torch.from_numpy(x) for k, x in a.state_dict.items()})
+    assert eng._mesh_handle().stats()["bin_entries"] == 0       # kMeshBinOverflow: no lists at all
+    omlp = orc.Mlp(a.state_dict)
+    rs = np.random.RandomState(6)
+    pts = (rs.rand(5000, 3) * 0.9 - 0.45).astype(np.float32)
+    occ = eng.query([T(a.features)], T(pts.T.copy())[None], torch.eye(4, device=dev())[None])[0][0, 0].cpu().numpy()
+    ref, _ = orc.query_icon(v, f, cm, vs, a.features, omlp, pts, sdf_clip=a.sdf_clip)
+    assert np.abs(occ - ref).max() <= 1e-4 * max(1.0, float(np.abs(ref).max()))
+    from icon_amd import synth as S
+    vol = eng.eval_slab(T(a.features), 33, 0, 33).cpu().numpy().ravel()
+    ref33, _ = orc.query_icon(v, f, cm, vs, a.features, omlp, S.lattice_points(33), sdf_clip=a.sdf_clip)
+    assert np.abs(vol - ref33).max() <= 1e-4 * max(1.0, float(np.abs(ref33).max()))
+    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True)
+    call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None)
+    nat, host = AdaptiveReconEngine(**kw).to(dev()), AdaptiveReconEngine(**kw).to(dev())
+    host.native = False
+    v1, v2 = nat(**call), host(**call)
+    if v1 is None or v2 is None:
+        assert v1 is None and v2 is None
+    else:
+        assert nat.last_stats["queries"] == host.last_stats["queries"] and (v1 - v2).abs().max().item() <= 1e-6
+
+
 def test_bad_input_is_reported_not_faulted():
     """a face naming a missing vertex / a NaN coordinate: the build makes them harmless, the status says what was wrong
     (validate=True raises as the host build of round 3 did; the engine's lazy check raises one call late)"""
