@@ -779,6 +779,17 @@ def test_mesh_with_more_slots_than_15_bits(body, precision):
     assert np.abs(q - refq).max() <= OCC_TOL
     faces_hit = h.sdf_query(T(pts))["face"].cpu().numpy()
     assert faces_hit.max() > 40000          # the sample does reach triangles stored beyond slot 32,768
+    if precision == "f16x3":                # the native schedule (shared-walk block search, 4-lane sign kernel) carries the high byte too
+        from types import SimpleNamespace
+        from icon_amd.engine import query_func
+        from icon_amd.recon import AdaptiveReconEngine
+        kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True)
+        call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None)
+        nat, host = AdaptiveReconEngine(**kw).to(dev()), AdaptiveReconEngine(**kw).to(dev())
+        host.native = False
+        v1, v2 = nat(**call), host(**call)
+        assert nat.last_stats.get("native") is True and nat.last_stats["queries"] == host.last_stats["queries"]
+        assert (v1 - v2).abs().max().item() <= 1e-6
 
 
 # ---------------------------------------------------------------------------------------------
