@@ -327,7 +327,13 @@ __device__ __forceinline__ void sign_list_extent(const FusedGeom &G, int64_t &K,
     else if (G.sg.mode == kSignSeg) { K = G.sg.seg[G.sg.world]; rank0 = G.sg.seg[G.sg.rank]; }
 }
 
-template <int PRIOR, bool LATTICE>
+// SMALL (calls of at most 262,144 points: the levels of the reference's schedule, ordinary query() batches): a 256-point tile is
+// ~50 us of ONE CU's matrix cores whatever the launch size, and a call of 20,000 points occupies 79 of the 256 CUs.  When the
+// call fits the grid as 128-point tiles, the tiles are 128 points: waves 0-3 (one per SIMD) carry 32 points each through the
+// MLP, waves 4-7 only issue their share of the weight DMA and keep the barriers - twice the CUs at work, half the chain per
+// tile.  Decided in the kernel (the point count of a schedule level lives on the device).  SMALL = false compiles the
+// 257^3 kernel as it was.
+template <int PRIOR, bool LATTICE, bool SMALL = false>
 __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float *__restrict__ out, MlpF16Dev w)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -350,7 +356,8 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     // (a tile of interior rows does not end on a line) and the triangles / feature texels of neighbouring points, and a
     // workgroup stays on one XCD - interleaved over the grid, those lines were fetched into two L2s (105 vs 91 MB of HBM
     // reads per 257^3 launch when the tiles stopped being 1 KiB-aligned runs of the linear order)
-    const int64_t ntiles = (G.N + kTilePts - 1) / kTilePts;
+    const int tp = (SMALL && G.N <= (int64_t)(kTilePts / 2) * gridDim.x) ? kTilePts / 2 : kTilePts;       // points per tile (wave-uniform)
+    const int64_t ntiles = (G.N + tp - 1) / tp;
     const int64_t per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
     int64_t tile = (int64_t)blockIdx.x * per + min((int64_t)blockIdx.x, rem);
     const int64_t tile_end = uniform64(tile + per + ((int64_t)blockIdx.x < rem ? 1 : 0));
@@ -367,12 +374,28 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const int j = lane & 31, h = lane >> 5;
         // ---- feature phase: waves 0-3, one work item per thread -> Xs[t][16] -----------------------------
         const int t = tid;
-        const bool worker = t < kTilePts;                       // wave-uniform
-        int64_t q = tile * kTilePts + (worker ? t : 0);
+        const bool worker = t < tp;                             // wave-uniform
+        int64_t q = tile * tp + (worker ? t : 0);
         if (q >= G.N) q = G.N - 1;                               // padding lanes of the last tile recompute its last item
         if (worker) build_row<PRIOR, LATTICE>(G, q, Xs + t * kXRow, K, rank0);
         __syncthreads();          // tile visible; chunk 0 (and, the first time, W0 + side arrays) landed
 
+        const bool more = tile + 1 < tile_end;                  // the first chunks of the next tile ride on the last ones
+        if (SMALL && wave >= (tp >> 5)) {
+            // a wave without points (128-point tiles): its share of the weight stream, the same barriers as the body below
+            for (int c = 0; c < 16; ++c) {
+                issue_chunk(w.image, smem + ((c + 1) & 1) * kBufBytes, c + 1, wave, lane);
+                ICON_CHUNK_BARRIER();
+            }
+            issue_chunk(w.image, smem + kBufBytes, 17, wave, lane);
+            ICON_CHUNK_BARRIER();
+            issue_chunk(w.image, smem, 18, wave, lane);
+            ICON_CHUNK_BARRIER();
+            issue_chunk(w.image, smem + kBufBytes, 19, wave, lane);
+            ICON_CHUNK_BARRIER();
+            if (more) issue_chunk(w.image, smem, 0, wave, lane);
+            continue;
+        }
         // ---- MLP: one wave = 32 points, lane (j,h) holds input slots 8h..8h+7 of point j ------------------
         const int pt = wave * 32 + j;
         float xr[8];
@@ -393,7 +416,6 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         half8 bh[2], bl[2];
         activate_split(l0_tile(smem + kW0Off, sb0, 0, xhi, xlo, h, lane), LeakyK{w.inv0, w.p0, w.q0}, bh, bl);
         f32x16 acc2[4];
-        const bool more = tile + 1 < tile_end;                  // the first chunks of the next tile ride on the last ones
         for (int c = 0; c < 16; ++c) {
             l01_chunk(smem + (c & 1) * kBufBytes, smem + ((c + 1) & 1) * kBufBytes, smem + kW0Off, sb0, w.image, c, acc1, xhi, xlo,
                       LeakyK{w.inv0, w.p0, w.q0}, h, lane, wave, bh, bl);
@@ -427,7 +449,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const float y = apply_last_op((part + other) + w.b3, w.last_op);
         // where this point's occupancy goes is re-derived from the work item (a handful of integer instructions):
         // nothing lane-dependent lives across the MFMA body
-        const int64_t oq = tile * kTilePts + pt;
+        const int64_t oq = tile * tp + pt;
         if (h == 0 && oq < G.N) {
             int ix, iy, iz;
             out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : (G.out_map ? (int64_t)G.out_map[oq] : oq)] = masked_result(y, maskf != 0.0f, w.flag);
@@ -590,20 +612,24 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     work->flag_clean = false;
     const MlpPlain plain = mlp_plain_of(mlp);
     const int64_t n_resc = std::min<int64_t>((N + 63) / 64, 2048);
-    const int64_t ntiles = (N + kTilePts - 1) / kTilePts;
+    // calls of few points: the kernel variant that may cut its tiles in half (k_fused_f16x3<..., SMALL>; icon prior only); its
+    // grid is sized for 128-point tiles.  A schedule level's N is n_max here - its real size lives on the device
+    const bool small = prior == ICON_PRIOR_ICON && (work->q_n_dev != nullptr || N <= 262144);
+    const int64_t ntiles = small ? (N + kTilePts / 2 - 1) / (kTilePts / 2) : (N + kTilePts - 1) / kTilePts;
     // one persistent workgroup per CU (LDS-bound: 132 KiB, all registers).  Multi-GPU: a collective's kernels cannot co-reside
     // with it on a CU - icon_work_set_reserve_cus leaves some CUs to them
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, std::max(n_cu - work->reserve_cus, 1));
-#define ICON_FUSED(P, L_, ID)                                                                                              \
+#define ICON_FUSED(P, L_, ID, ...)                                                                                         \
     do {                                                                                                                   \
-        if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_>),   \
+        if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_, ##__VA_ARGS__>),   \
                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds); }))) return rc; \
-        hipLaunchKernelGGL((k_fused_f16x3<P, L_>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w);               \
+        hipLaunchKernelGGL((k_fused_f16x3<P, L_, ##__VA_ARGS__>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w); \
         debug_sync("k_fused_f16x3", st);                                                                                   \
         hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
         debug_sync("k_rescue_fused", st);                                                                                  \
     } while (0)
-    if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }
+    if (small) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 9, true); else ICON_FUSED(ICON_PRIOR_ICON, false, 10, true); }
+    else if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }
     else if (prior == ICON_PRIOR_PAMIR) { if (lattice) ICON_FUSED(ICON_PRIOR_PAMIR, true, 2); else ICON_FUSED(ICON_PRIOR_PAMIR, false, 3); }
     else { if (lattice) ICON_FUSED(ICON_PRIOR_PIFU, true, 4); else ICON_FUSED(ICON_PRIOR_PIFU, false, 5); }
 #undef ICON_FUSED

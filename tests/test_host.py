@@ -313,7 +313,8 @@ def test_hot_kernels_do_not_spill():
     with ThreadPoolExecutor(3) as ex:
         fused, mlp, query = ex.map(lambda a: remarks(*a), [("fused_f16x3.hip", True), ("mlp_f16x3.hip", False), ("query_kernels.hip", True)])
     icon_fused = {k: v for k, v in fused.items() if "k_fused_f16x3ILi0E" in k}
-    assert len(icon_fused) == 2, list(fused)
+    assert len(icon_fused) == 4, list(fused)                # lattice / points x (257^3 kernel, small-call variant)
+    print({k[-40:]: v for k, v in icon_fused.items()})
     for k, v in {**icon_fused, **{k: v for k, v in mlp.items() if "k_mlp_f16x3" in k}}.items():
         assert v["ScratchSize [bytes/lane]"] == 0, (k, v)
     # no timing-only experiment switch (wrong results by construction) is left in the product sources: one stray -D in the
