@@ -280,6 +280,9 @@ int ensure_work_points(icon_work *w, int64_t n_points);
 // mc_device.hip
 struct McDevState;
 void mc_destroy(McDevState *s);
+// clean_mesh.hip
+struct CleanState;
+void clean_destroy(CleanState *s);
 // sort_points.hip: perm[k] = index of the k-th point in Morton order of the projected positions (device array owned by w)
 int morton_order(icon_work *w, const float *d_points, const float *calib12, const float *d_calib12, int64_t N, hipStream_t st, const int32_t **perm);
 // mlp_kernels.hip
@@ -362,6 +365,7 @@ struct icon_work {
     int reserve_cus = 0;                  // the persistent MLP kernel leaves this many CUs free (icon_work_set_reserve_cus)
     struct icon_adaptive *ad = nullptr;   // level buffers of icon_adaptive_eval
     icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
+    icon::CleanState *clean = nullptr;    // icon_clean_mesh scratch
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
     bool prof = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -40,6 +40,23 @@ __device__ __forceinline__ float mc_at(const float *occ, int res, int z, int y, 
     return occ[((size_t)(z + 1) * res + (y + 1)) * res + (x + 1)];
 }
 
+// cell index -> (x, y, z), x fastest.  32-bit arithmetic whenever the index allows it (every res <= 1291 does: 1290^3 < 2^31.1 -
+// checked per call): a 64-bit division by a run-time n is ~40 instructions, three of them per cell were most of the
+// classification pass (97 us for 16.8 M cells)
+__device__ __forceinline__ void mc_cell(int64_t i, int n, int &x, int &y, int &z)
+{
+    if (i < (1ll << 31)) {
+        const uint32_t ii = (uint32_t)i, un = (uint32_t)n;
+        const uint32_t r = ii / un;
+        x = (int)(ii - r * un);
+        const uint32_t zz = r / un;
+        y = (int)(r - zz * un); z = (int)zz;
+    } else {
+        const int64_t r = i / n;
+        x = (int)(i - r * n); z = (int)(r / n); y = (int)(r - (int64_t)z * n);
+    }
+}
+
 __device__ __forceinline__ float mc_lerp(float level, float v0, float v1)
 {
     const float d = v1 - v0;
@@ -48,19 +65,27 @@ __device__ __forceinline__ float mc_lerp(float level, float v0, float v1)
 }
 
 // flags: bit0/1/2 = +x/+y/+z edge crossed, bit3 = inside
+__device__ __forceinline__ unsigned long long mc_block_exscan(unsigned long long v, unsigned long long *wsum, unsigned long long *total);
+
+// also: block_tot[block] = (triangles << 32 | vertices) of the block's cells - the blocks away from the surface (99 % of them)
+// are skipped by the emit passes on that one word
 __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restrict__ occ, int res, float level, int64_t npts,
-                                                          uint8_t *__restrict__ flags, uint8_t *__restrict__ ntri)
+                                                          uint8_t *__restrict__ flags, uint8_t *__restrict__ ntri,
+                                                          unsigned long long *__restrict__ block_tot)
 {
+    __shared__ unsigned wsum[kMcBlock / 64];
     const int n = res - 1;
     const int64_t i = (int64_t)blockIdx.x * kMcBlock + threadIdx.x;
-    if (i >= npts) return;
-    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((int64_t)n * n));
+    unsigned mine = 0;                                           // vertices | triangles << 16 of this cell (<= 3, <= 5)
+    if (i < npts) {
+    int x, y, z; mc_cell(i, n, x, y, z);
+    // the eight corners from ONE base address and three clamped strides (a corner beyond the last cell repeats the last one):
+    // per-corner min() / multiply chains were most of this kernel's instructions
+    const float *p0 = occ + ((size_t)(z + 1) * res + (y + 1)) * res + (x + 1);
+    const size_t dx = x + 1 < n ? 1 : 0, dy = y + 1 < n ? (size_t)res : 0, dz = z + 1 < n ? (size_t)res * res : 0;
     bool in[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const int xx = min(x + (k & 1), n - 1), yy = min(y + ((k >> 1) & 1), n - 1), zz = min(z + ((k >> 2) & 1), n - 1);
-        in[k] = mc_at(occ, res, zz, yy, xx) > level;
-    }
+    for (int k = 0; k < 8; ++k) in[k] = p0[((k & 1) ? dx : 0) + ((k & 2) ? dy : 0) + ((k & 4) ? dz : 0)] > level;
     uint8_t f = in[0] ? 8 : 0;
     if (x + 1 < n && in[1] != in[0]) f |= 1;
     if (y + 1 < n && in[2] != in[0]) f |= 2;
@@ -74,6 +99,18 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restric
         t = (uint8_t)c_mc.tri[c][0];
     }
     ntri[i] = t;
+    mine = (unsigned)__popc(f & 7) | ((unsigned)t << 16);
+    }
+    // block total: a 32-bit wave reduction of the packed pair (a wave's sums are <= 192 and <= 320), 16 partial sums through LDS
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long nv = 0, nt = 0;
+        for (int k = 0; k < kMcBlock / 64; ++k) { nv += wsum[k] & 0xffffu; nt += wsum[k] >> 16; }
+        block_tot[blockIdx.x] = nv | (nt << 32);
+    }
 }
 
 __device__ __forceinline__ unsigned long long mc_count(const uint8_t *flags, const uint8_t *ntri, int64_t i, int64_t npts)
@@ -101,53 +138,64 @@ __device__ __forceinline__ unsigned long long mc_block_exscan(unsigned long long
     return before + inc - v;
 }
 
-__global__ __launch_bounds__(kMcBlock) void k_mc_blocksum(const uint8_t *__restrict__ flags, const uint8_t *__restrict__ ntri,
-                                                          int64_t npts, unsigned long long *block_sums)
+// exclusive scan of the block totals (66,000 for a 257^3 volume) into offsets: one workgroup, eight consecutive entries per
+// thread and round - coalesced (a contiguous range per thread was a 41 us pass of strided loads)
+// ... and the list of the blocks that hold anything (any order): the emit passes are launched over those only (600 of 66,000
+// for the body at 257^3: 66,000 workgroups that read one word and leave were 30 us per pass)
+__global__ __launch_bounds__(1024) void k_mc_scanblocks(const unsigned long long *__restrict__ block_tot, unsigned long long *__restrict__ block_off,
+                                                        int64_t nblocks, unsigned long long *totals, int32_t *__restrict__ active)
 {
-    __shared__ unsigned long long wsum[kMcBlock / 64];
-    const int64_t i = (int64_t)blockIdx.x * kMcBlock + threadIdx.x;
-    unsigned long long total;
-    (void)mc_block_exscan(mc_count(flags, ntri, i, npts), wsum, &total);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
-}
-
-__global__ __launch_bounds__(1024) void k_mc_scanblocks(unsigned long long *block_sums, int64_t nblocks, unsigned long long *totals)
-{
-    __shared__ unsigned long long part[1024];
-    const int t = threadIdx.x;
-    const int64_t per = (nblocks + 1023) / 1024;
-    const int64_t beg = min((int64_t)t * per, nblocks), end = min(beg + per, nblocks);
-    unsigned long long s = 0;
-    for (int64_t k = beg; k < end; ++k) s += block_sums[k];
-    part[t] = s;
-    __syncthreads();
-    if (t == 0) {
-        unsigned long long run = 0;
-        for (int k = 0; k < 1024; ++k) { const unsigned long long v = part[k]; part[k] = run; run += v; }
-        totals[0] = run & 0xffffffffull; totals[1] = run >> 32;
+    __shared__ unsigned long long wtot[16];
+    __shared__ int n_active;
+    if (threadIdx.x == 0) n_active = 0;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long carry = 0;
+    for (int64_t base = 0; base < nblocks; base += 8192) {
+        const int64_t i = base + (int64_t)threadIdx.x * 8;
+        unsigned long long v[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { v[k] = i + k < nblocks ? block_tot[i + k] : 0ull; sum += v[k]; }
+        unsigned long long incl = sum;
+        for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+        __syncthreads();
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        unsigned long long before = 0, all = 0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { const unsigned long long t = wtot[q]; before += q < w ? t : 0ull; all += t; }
+        unsigned long long run = carry + before + incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            if (i + k < nblocks) block_off[i + k] = run;
+            if (v[k]) active[atomicAdd(&n_active, 1)] = (int32_t)(i + k);     // (LDS counter; the first __syncthreads of the round ordered its reset)
+            run += v[k];
+        }
+        carry += all;
     }
     __syncthreads();
-    unsigned long long run = part[t];
-    for (int64_t k = beg; k < end; ++k) { const unsigned long long v = block_sums[k]; block_sums[k] = run; run += v; }
+    if (threadIdx.x == 0) { totals[0] = carry & 0xffffffffull; totals[1] = carry >> 32; totals[2] = (unsigned long long)n_active; }
 }
 
 __global__ __launch_bounds__(kMcBlock) void k_mc_vertices(const float *__restrict__ occ, int res, float level, int64_t npts,
                                                           const uint8_t *__restrict__ flags, const uint8_t *__restrict__ ntri,
+                                                          const int32_t *__restrict__ active,
                                                           const unsigned long long *__restrict__ block_offsets,
                                                           int32_t *__restrict__ first_vertex, int32_t *__restrict__ first_tri,
                                                           float *__restrict__ verts)
 {
     __shared__ unsigned long long wsum[kMcBlock / 64];
+    const int64_t blk = active[blockIdx.x];                      // a block with a vertex or a triangle (nobody reads the first_* entries of the others)
     const int n = res - 1;
-    const int64_t i = (int64_t)blockIdx.x * kMcBlock + threadIdx.x;
-    const unsigned long long ex = mc_block_exscan(mc_count(flags, ntri, i, npts), wsum, nullptr) + block_offsets[blockIdx.x];
-    if (i >= npts) return;
+    const int64_t i = blk * kMcBlock + threadIdx.x;
+    const unsigned long long own = mc_count(flags, ntri, i, npts);
+    const unsigned long long ex = mc_block_exscan(own, wsum, nullptr) + block_offsets[blk];
+    if (i >= npts || own == 0ull) return;                        // first_vertex is read for vertex owners, first_tri for cells with triangles
     const int32_t v0 = (int32_t)(ex & 0xffffffffull);
     first_vertex[i] = v0;
     first_tri[i] = (int32_t)(ex >> 32);
     const uint8_t f = flags[i];
     if (!(f & 7)) return;
-    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((int64_t)n * n));
+    int x, y, z; mc_cell(i, n, x, y, z);
     const float v = mc_at(occ, res, z, y, x);
     int k = v0;
     if (f & 1) { const float t = mc_lerp(level, v, mc_at(occ, res, z, y, x + 1)); verts[3 * k] = x + t; verts[3 * k + 1] = (float)y; verts[3 * k + 2] = (float)z; ++k; }
@@ -156,15 +204,16 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_vertices(const float *__restric
 }
 
 __global__ __launch_bounds__(kMcBlock) void k_mc_faces(int res, int64_t npts, const uint8_t *__restrict__ flags,
-                                                       const uint8_t *__restrict__ ntri, const int32_t *__restrict__ first_vertex,
+                                                       const uint8_t *__restrict__ ntri, const int32_t *__restrict__ active,
+                                                       const int32_t *__restrict__ first_vertex,
                                                        const int32_t *__restrict__ first_tri, int64_t *__restrict__ faces)
 {
     const int n = res - 1;
-    const int64_t i = (int64_t)blockIdx.x * kMcBlock + threadIdx.x;
+    const int64_t i = (int64_t)active[blockIdx.x] * kMcBlock + threadIdx.x;
     if (i >= npts) return;
     const int nt = ntri[i];
     if (nt == 0) return;
-    const int x = (int)(i % n), y = (int)((i / n) % n), z = (int)(i / ((int64_t)n * n));
+    int x, y, z; mc_cell(i, n, x, y, z);
     int c = 0;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
@@ -187,7 +236,8 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_faces(int res, int64_t npts, co
 
 struct McDevState {
     uint8_t *flags = nullptr, *ntri = nullptr;
-    unsigned long long *block_sums = nullptr, *totals = nullptr;
+    unsigned long long *block_sums = nullptr, *block_tot = nullptr, *totals = nullptr;
+    int32_t *active = nullptr; int64_t n_active = 0;      // blocks holding a vertex or a triangle
     int32_t *first_vertex = nullptr, *first_tri = nullptr;
     int64_t cap = 0;
     const float *occ = nullptr; int res = 0; float level = 0.f; bool counted = false;
@@ -195,7 +245,7 @@ struct McDevState {
 
 static void mc_free(McDevState *s)
 {
-    (void)hipFree(s->flags); (void)hipFree(s->ntri); (void)hipFree(s->block_sums); (void)hipFree(s->totals);
+    (void)hipFree(s->flags); (void)hipFree(s->ntri); (void)hipFree(s->block_sums); (void)hipFree(s->block_tot); (void)hipFree(s->totals); (void)hipFree(s->active);
     (void)hipFree(s->first_vertex); (void)hipFree(s->first_tri);
     *s = McDevState();
 }
@@ -226,19 +276,20 @@ extern "C" int icon_mc_count(const float *d_occ, int res, float level, icon_work
         ICON_HIP(hipMalloc((void **)&s->flags, (size_t)npts));
         ICON_HIP(hipMalloc((void **)&s->ntri, (size_t)npts));
         ICON_HIP(hipMalloc((void **)&s->block_sums, (size_t)nblk * sizeof(unsigned long long)));
-        ICON_HIP(hipMalloc((void **)&s->totals, 2 * sizeof(unsigned long long)));
+        ICON_HIP(hipMalloc((void **)&s->block_tot, (size_t)nblk * sizeof(unsigned long long)));
+        ICON_HIP(hipMalloc((void **)&s->totals, 4 * sizeof(unsigned long long)));
+        ICON_HIP(hipMalloc((void **)&s->active, (size_t)nblk * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&s->first_vertex, (size_t)npts * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&s->first_tri, (size_t)npts * sizeof(int32_t)));
         s->cap = npts;
     }
-    hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri);
-    hipLaunchKernelGGL(k_mc_blocksum, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, s->flags, s->ntri, npts, s->block_sums);
-    hipLaunchKernelGGL(k_mc_scanblocks, dim3(1), dim3(1024), 0, st, s->block_sums, nblk, s->totals);
+    hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot);
+    hipLaunchKernelGGL(k_mc_scanblocks, dim3(1), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->totals, s->active);
     ICON_HIP(hipGetLastError());
-    unsigned long long h[2];
+    unsigned long long h[3];
     ICON_HIP(hipMemcpyAsync(h, s->totals, sizeof(h), hipMemcpyDeviceToHost, st));
     ICON_HIP(hipStreamSynchronize(st));
-    *n_verts = (int64_t)h[0]; *n_faces = (int64_t)h[1];
+    *n_verts = (int64_t)h[0]; *n_faces = (int64_t)h[1]; s->n_active = (int64_t)h[2];
     s->occ = d_occ; s->res = res; s->level = level; s->counted = true;
     return ICON_OK;
 }
@@ -251,11 +302,12 @@ extern "C" int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work,
     hipStream_t st = (hipStream_t)stream;
     const int n = s->res - 1;
     const int64_t npts = (int64_t)n * n * n;
-    const int64_t nblk = (npts + kMcBlock - 1) / kMcBlock;
-    hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, s->occ, s->res, s->level, npts, s->flags, s->ntri,
-                       s->block_sums, s->first_vertex, s->first_tri, d_verts);
-    hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, s->res, npts, s->flags, s->ntri, s->first_vertex,
-                       s->first_tri, d_faces);
+    if (s->n_active > 0) {
+        hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)s->n_active), dim3(kMcBlock), 0, st, s->occ, s->res, s->level, npts, s->flags, s->ntri,
+                           s->active, s->block_sums, s->first_vertex, s->first_tri, d_verts);
+        hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)s->n_active), dim3(kMcBlock), 0, st, s->res, npts, s->flags, s->ntri, s->active, s->first_vertex,
+                           s->first_tri, d_faces);
+    }
     ICON_HIP(hipGetLastError());
     s->counted = false;
     return ICON_OK;

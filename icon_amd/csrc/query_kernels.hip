@@ -692,6 +692,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
+    icon::clean_destroy(w->clean);
     icon::adaptive_destroy(w->ad);
     delete w;
     return ICON_OK;

@@ -471,31 +471,25 @@ def clean_mesh(verts: torch.Tensor, faces: torch.Tensor):
     the most vertices kept (ties: the one containing the lowest-index face); vertices and faces keep their relative
     order, as trimesh's submesh does.  Returns (verts float32, faces int32) on the device of ``verts`` - the reference
     returns ``.float()`` / ``.int()`` tensors on ``verts.device``.  Inputs on the host (export_mesh returns CPU
-    tensors, seg3d_lossless.py:601-602) are moved to the current HIP device for the labelling."""
+    tensors, seg3d_lossless.py:601-602) are moved to the current HIP device for the labelling.
+    ONE native call since round 4 (icon_clean_mesh, csrc/clean_mesh.hip: edge hash table, union-find over the faces, vertex
+    counts, order-preserving compaction; 2.0 ms of torch sort / unique / bincount operators before)."""
+    from .engine import _stream
     if not torch.cuda.is_available():
         raise IconAmdError("clean_mesh needs the HIP device (there is no CPU fallback)")
     out_dev = verts.device
     dev = verts.device if verts.is_cuda else torch.device("cuda", torch.cuda.current_device())
-    v = verts.detach().to(dev)
-    f = faces.detach().to(dev, torch.int64).reshape(-1, 3)
+    v = verts.detach().to(dev, torch.float32).reshape(-1, 3).contiguous()
+    f = faces.detach().to(dev, torch.int64).reshape(-1, 3).contiguous()
     if f.shape[0] == 0 or v.shape[0] == 0:
         return v.float().to(out_dev), f.int().to(out_dev)
-    V = v.shape[0]
-    if int(f.min()) < 0 or int(f.max()) >= V:
-        raise IconAmdError("clean_mesh: face index out of range")
-    face_label = face_components(f, V)                           # [F], smallest face index of the component
-    # vertices per component = distinct (component, vertex) incidences (a pinch vertex counts for both sides, as in
-    # trimesh's submeshes)
-    inc = torch.unique(face_label.repeat_interleave(3) * V + f.reshape(-1))
-    counts = torch.bincount(inc // V, minlength=f.shape[0])
-    best_count = counts.max()
-    tied = counts[face_label] == best_count                      # faces of the largest component(s)
-    best = face_label[tied.nonzero()[0, 0]]                      # ... the one met first in face order
-    keep_f = face_label == best
-    keep_v = torch.zeros(V, dtype=torch.bool, device=dev)
-    keep_v[f[keep_f].reshape(-1)] = True
-    remap = torch.cumsum(keep_v.to(torch.int64), 0) - 1
-    return v[keep_v].float().to(out_dev), remap[f[keep_f]].int().to(out_dev)
+    with torch.cuda.device(dev):
+        ov = torch.empty_like(v)
+        of = torch.empty((f.shape[0], 3), dtype=torch.int32, device=dev)
+        hc = (C.c_int64 * 2)()
+        check(_lib.lib().icon_clean_mesh(_lib.ptr(v), C.c_int64(v.shape[0]), _lib.ptr(f), C.c_int64(f.shape[0]), _lib.ptr(ov), _lib.ptr(of),
+                                         hc, _mc_workspace(dev).h, _stream()), "clean_mesh")
+    return ov[: hc[0]].to(out_dev), of[: hc[1]].to(out_dev)
 
 
 _mc_tls = threading.local()

@@ -372,6 +372,17 @@ int icon_semantic_voxelize(const float *d_verts, int64_t V, int64_t V_surf, cons
  * Synchronises the stream (reports out-of-range face indices). */
 int icon_mesh_components(const int64_t *d_faces, int64_t F, int64_t V, int32_t *d_labels, void *stream);
 
+/* clean_mesh (lib/dataset/mesh_util.py:778-791, called at apps/ICON.py:755-756 on the marching-cubes output) as ONE call:
+ * trimesh's split(only_watertight=False) - components over FACE adjacency (two faces are adjacent when they share an edge that
+ * exactly two faces use; faces meeting in a vertex only are not) - and the component with the most vertices kept (a pinch
+ * vertex counts for every component it touches; ties: the component holding the lowest-index face); vertices and faces keep
+ * their relative order, vertex indices are renumbered.  d_verts [V,3] f32, d_faces [F,3] i64 -> d_out_verts [V,3] f32,
+ * d_out_faces [F,3] i32 (caller-allocated at the INPUT sizes; the first h_counts[0] vertices / h_counts[1] faces are
+ * valid).  All device pointers; synchronises the stream once, for the two counts.  ICON_ERR_ARG for a face naming a vertex
+ * that does not exist.  Scratch lives in `work`. */
+int icon_clean_mesh(const float *d_verts, int64_t V, const int64_t *d_faces, int64_t F, float *d_out_verts, int32_t *d_out_faces,
+                    int64_t *h_counts, icon_work_t *work, void *stream);
+
 /* ---- SMPL vertex visibility ----------------------------------------------------------------------
  * replaces get_visibility (lib/dataset/mesh_util.py:280-316: pytorch3d rasterisation at 2^12 squared,
  * cull_backfaces, 1 face per pixel; vis[faces[unique(pix_to_face)]] = 1, faces[-1] included).

@@ -290,6 +290,47 @@ def test_clean_mesh_splits_components_that_touch_in_one_vertex():
     assert np.array_equal(cv2.cpu().numpy()[cf2.cpu().numpy().astype(np.int64)], v[fa])
 
 
+@pytest.mark.parametrize("case", ["soup", "fans", "mc_noise", "mc_body", "ties"])
+def test_clean_mesh_native_vs_plain_python_checker(case):
+    """icon_clean_mesh (edge hash table, union-find over the faces, vertex counts through the same table, order-preserving
+    compaction) against tests/common.py: clean_mesh_check - trimesh's rules in plain Python: triangle soups (edges used by 1, 2,
+    3+ faces, degenerate faces), fans around pinch vertices, marching-cubes surfaces of noise (hundreds of components) and of the
+    body, equal-sized components (the one holding the lowest-index face wins)"""
+    from common import clean_mesh_check
+    from icon_amd.recon import clean_mesh, export_mesh_device
+    rs = np.random.RandomState(11)
+    if case == "soup":
+        v = rs.rand(60, 3).astype(np.float32)
+        f = rs.randint(0, 60, (400, 3)).astype(np.int64)
+        f[::37, 1] = f[::37, 0]                                      # some degenerate faces (a repeated vertex)
+    elif case == "fans":                                            # 30 fans of 6 triangles around ONE shared vertex: 30 components of 7 vertices
+        n = 30
+        v = np.concatenate([np.zeros((1, 3)), rs.rand(n * 6, 3)]).astype(np.float32)
+        f = np.array([[0, 1 + 6 * k + j, 1 + 6 * k + (j + 1) % 6] for k in range(n) for j in range(6)], np.int64)
+        f = f[rs.permutation(len(f))]
+    elif case == "ties":                                            # two tetrahedra of 4 vertices each, a third one listed first
+        t = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], np.int64)
+        v = rs.rand(12, 3).astype(np.float32)
+        f = np.concatenate([t + 8, t, t + 4])
+    else:
+        if case == "mc_noise":
+            occ = torch.from_numpy(rs.rand(41, 41, 41).astype(np.float32)).to(dev())
+        else:
+            a = assets("body")
+            occ = make_engine(a).eval_slab(T(a.features), 65, 0, 65)
+        vt, ft = export_mesh_device(occ, 0.5)
+        v, f = vt.cpu().numpy(), ft.cpu().numpy()
+    ev, ef = clean_mesh_check(v, f)
+    for rep in range(3):                                            # (the table inserts and unions race in a different order every time)
+        cv, cf = clean_mesh(T(v), T(f))
+        assert cv.dtype == torch.float32 and cf.dtype == torch.int32
+        assert np.array_equal(cv.cpu().numpy(), ev) and np.array_equal(cf.cpu().numpy(), ef), (case, rep, cv.shape, ev.shape, cf.shape, ef.shape)
+    from icon_amd.engine import IconAmdError
+    fb = f.copy(); fb[len(fb) // 2, 2] = len(v)
+    with pytest.raises(IconAmdError, match="face index out of range"):
+        clean_mesh(T(v), T(fb))
+
+
 # ---------------------------------------------------------------------------------------------
 # attach(): the HIP path behind a network object carrying exactly what the reference's HGPIFuNet carries
 # ---------------------------------------------------------------------------------------------
