@@ -44,7 +44,7 @@ def main():
     def sync():
         torch.cuda.synchronize(); return time.perf_counter()
     w = recon(opt=opt, netG=eng, features=features, proj_matrix=None)          # warm-up: BVH build, operand packing, workspaces,
-    clean_mesh(*recon.export_mesh(w))                                           # ... and torch's sort / unique kernels (0.6 s the first time)
+    clean_mesh(*recon.export_mesh(w))                                           # ... and the marching-cubes / clean_mesh scratch
     t0 = sync()
     sdf = recon(opt=opt, netG=eng, features=features, proj_matrix=None)
     t1 = sync()
