@@ -465,9 +465,26 @@ def main():
             dense_ms, create_host_ms = cold(step)
             cold_cfg = {"dense": dense_ms, "mesh_create_host_ms": create_host_ms,
                         "note": "median of 5 after one warm-up; new SMPL tensors every step, mesh built on the device inside the timed region; "
-                                "mesh_create_host_ms = host time of icon_mesh_create_arena (enqueue only, it never waits)"}
+                                "mesh_create_host_ms = host time of icon_mesh_create_arena (enqueue only, it never waits); reference_mode_image = "
+                                "mesh build + the reference's schedule + marching cubes + clean_mesh (apps/ICON.py:729-761), device tensors throughout"}
             if res == 257:
                 cold_cfg["reference_schedule"] = cold(lambda: ad(opt=opt, netG=eng, features=feats, proj_matrix=None))[0]
+                # the whole image in the reference's own mode (apps/ICON.py:729-761): schedule -> export_mesh -> clean_mesh
+                from icon_amd.recon import clean_mesh
+
+                def image():
+                    vol = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
+                    clean_mesh(*export_mesh_device(vol.contiguous(), 0.5))
+                cold_cfg["reference_mode_image"] = cold(image)[0]
+                stage = []
+                for _ in range(5):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    vol = ad(opt=opt, netG=eng, features=feats, proj_matrix=None); torch.cuda.synchronize(); t2 = time.perf_counter()
+                    vm, fm = export_mesh_device(vol.contiguous(), 0.5); torch.cuda.synchronize(); t3 = time.perf_counter()
+                    clean_mesh(vm, fm); torch.cuda.synchronize(); t4 = time.perf_counter()
+                    stage.append(((t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
+                med = np.median(np.array(stage[1:]), 0)
+                cold_cfg["reference_mode_stages_warm"] = {"schedule": float(med[0]), "marching_cubes": float(med[1]), "clean_mesh": float(med[2])}
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fresh = [t.clone() for t in base]
             eng.set_mesh(*fresh)
