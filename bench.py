@@ -476,14 +476,14 @@ def main():
                     vol = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
                     clean_mesh(*export_mesh_device(vol.contiguous(), 0.5))
                 cold_cfg["reference_mode_image"] = cold(image)[0]
-                stage = []
+                img_stage = []
                 for _ in range(5):
                     torch.cuda.synchronize(); t1 = time.perf_counter()
                     vol = ad(opt=opt, netG=eng, features=feats, proj_matrix=None); torch.cuda.synchronize(); t2 = time.perf_counter()
                     vm, fm = export_mesh_device(vol.contiguous(), 0.5); torch.cuda.synchronize(); t3 = time.perf_counter()
                     clean_mesh(vm, fm); torch.cuda.synchronize(); t4 = time.perf_counter()
-                    stage.append(((t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
-                med = np.median(np.array(stage[1:]), 0)
+                    img_stage.append(((t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
+                med = np.median(np.array(img_stage[1:]), 0)
                 cold_cfg["reference_mode_stages_warm"] = {"schedule": float(med[0]), "marching_cubes": float(med[1]), "clean_mesh": float(med[2])}
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fresh = [t.clone() for t in base]
