@@ -275,7 +275,7 @@ extern "C" int icon_clean_mesh(const float *d_verts, int64_t V, const int64_t *d
                                int64_t *h_counts, icon_work_t *work, void *stream)
 {
     ICON_ARG(work && h_counts && d_verts && d_faces && d_out_verts && d_out_faces, "icon_clean_mesh: null argument");
-    ICON_ARG(V > 0 && F > 0 && V < (1ll << 31) && F < (1ll << 29), "icon_clean_mesh: 0 < V < 2^31, 0 < F < 2^29");
+    ICON_ARG(V > 0 && F > 0 && V < (1ll << 31) && F < (1ll << 28), "icon_clean_mesh: 0 < V < 2^31, 0 < F < 2^28");      // (the table: <= 2^31 slots)
     hipStream_t st = (hipStream_t)stream;
     if (!work->clean) work->clean = new CleanState();
     CleanState *s = work->clean;
