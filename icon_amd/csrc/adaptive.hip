@@ -5,9 +5,10 @@
 //   level l >= 1   : occ_l   = trilinear upsample of occ_{l-1} (F.interpolate, align_corners=True: :201, :213-216)
 //                    valid_l = upsample of (occ_{l-1} > balance); a voxel is a BOUNDARY voxel when 0 < valid < 1 (:217-218) -
 //                              with res_l = 2 res_{l-1} - 1 every weight is 0, 1/2 or 1, so that is exactly "the (up to 8)
-//                              parent corners around the voxel are not all on one side of the level" (integer logic, k_ad_boundary)
+//                              parent corners around the voxel are not all on one side of the level" (integer logic)
 //                    dilate the boundary by a 9^3 / 7^3 / 3^3 box (SmoothConv3D(k) > 0, lib/common/seg3d_utils.py:169-181:
-//                    a box is separable - three 1-D passes), drop the voxels evaluated at an earlier level (coords_accum),
+//                    a box is separable - three 1-D passes), drop the voxels evaluated at an earlier level (coords_accum)
+//                    - boundary, dilation and removal in ONE kernel on 64-bit rows in LDS (k_ad_mask) -,
 //                    compact in the reference's order (is_boundary.permute(2,1,0).nonzero(): x slowest, z fastest, :236-240),
 //                    query those points as ONE call (own outlier sign list, same order), scatter (:256-262)
 //   last level     : upsample only ("last step no examine", :186-203)
