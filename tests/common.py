@@ -184,39 +184,3 @@ def volume_encoder_replica(num_in=3, num_out=7, num_stacks=2):
             return outs if intermediate_output else [outs[-1]]
 
     return VolumeEncoder()
-
-
-def clean_mesh_check(verts, faces):
-    """lib/dataset/mesh_util.py:778-791 with trimesh's connectivity spelled out in plain Python (the checker of icon_clean_mesh):
-    faces are adjacent when they share an edge that EXACTLY two faces use (graph.face_adjacency: grouping.group_rows(edges,
-    require_count=2)); components of that graph; the one with the most distinct vertices wins (ties: the one holding the
-    lowest-index face); vertices and faces keep their order, indices renumbered.  -> (verts float32, faces int32)"""
-    v = np.asarray(verts, np.float32)
-    f = np.asarray(faces, np.int64).reshape(-1, 3)
-    uses = {}
-    for i, (a, b, c) in enumerate(f.tolist()):
-        for p, q in ((a, b), (b, c), (c, a)):
-            uses.setdefault((min(p, q), max(p, q)), []).append(i)
-    parent = list(range(len(f)))
-
-    def find(x):
-        while parent[x] != x:
-            parent[x] = parent[parent[x]]
-            x = parent[x]
-        return x
-    for fl in uses.values():
-        if len(fl) == 2:
-            ra, rb = find(fl[0]), find(fl[1])
-            if ra != rb:
-                parent[max(ra, rb)] = min(ra, rb)
-    lab = np.array([find(i) for i in range(len(f))])
-    best, best_n = -1, -1
-    for L in np.unique(lab):                     # ascending: the first of several largest is the one with the lowest face
-        n = len(np.unique(f[lab == L]))
-        if n > best_n:
-            best, best_n = L, n
-    keep_f = lab == best
-    keep_v = np.zeros(len(v), bool)
-    keep_v[f[keep_f].reshape(-1)] = True
-    remap = np.cumsum(keep_v) - 1
-    return v[keep_v], remap[f[keep_f]].astype(np.int32)

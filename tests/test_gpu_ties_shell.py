@@ -293,10 +293,10 @@ def test_clean_mesh_splits_components_that_touch_in_one_vertex():
 @pytest.mark.parametrize("case", ["soup", "fans", "mc_noise", "mc_body", "ties"])
 def test_clean_mesh_native_vs_plain_python_checker(case):
     """icon_clean_mesh (edge hash table, union-find over the faces, vertex counts through the same table, order-preserving
-    compaction) against tests/common.py: clean_mesh_check - trimesh's rules in plain Python: triangle soups (edges used by 1, 2,
+    compaction) against oracle/mc_check.py: largest_component_by_faces - trimesh's rules in plain Python: triangle soups (edges used by 1, 2,
     3+ faces, degenerate faces), fans around pinch vertices, marching-cubes surfaces of noise (hundreds of components) and of the
     body, equal-sized components (the one holding the lowest-index face wins)"""
-    from common import clean_mesh_check
+    from oracle.mc_check import largest_component_by_faces as clean_mesh_check
     from icon_amd.recon import clean_mesh, export_mesh_device
     rs = np.random.RandomState(11)
     if case == "soup":

@@ -69,6 +69,26 @@ def test_device_marching_cubes_257_vs_independent_checker():
     print("257^3 mesh:", t)
 
 
+def test_checker_face_connectivity_vs_vertex_connectivity():
+    """oracle/mc_check.py: largest_component_by_faces (trimesh's edge-based face adjacency, the checker of icon_clean_mesh)
+    against largest_component (vertex connectivity): equal on closed surfaces without pinch vertices; at a pinch (two
+    tetrahedra sharing ONE vertex) the edge-based rule keeps them apart"""
+    from icon_amd import synth
+    v1, f1 = synth.icosphere(2, radius=0.5)
+    v2, f2 = synth.icosphere(1, radius=0.2, center=(2.0, 0.0, 0.0))
+    v = np.concatenate([v1, v2]).astype(np.float32)
+    f = np.concatenate([f2 + len(v1), f1])                         # the small component listed first
+    a, b = mc_check.largest_component_by_faces(v, f), mc_check.largest_component(v, f)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and len(a[0]) == len(v1)
+    t = np.array([[0, 1, 2], [0, 1, 3], [0, 2, 3], [1, 2, 3]], np.int64)
+    vp = np.random.RandomState(0).rand(7, 3).astype(np.float32)
+    fp = np.concatenate([t, np.array([0, 4, 5, 6])[t]])            # vertex 0 is in both tetrahedra
+    pv, pf = mc_check.largest_component_by_faces(vp, fp)
+    assert len(pv) == 4 and len(pf) == 4 and np.array_equal(pv, vp[:4])    # equal sizes: the one holding face 0
+    wv, wf = mc_check.largest_component(vp, fp)
+    assert len(wv) == 7 and len(wf) == 8                           # a vertex union-find merges them
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("case", ["noise", "body"])
 def test_clean_mesh_keeps_the_largest_component(case):
