@@ -69,9 +69,14 @@ __device__ __forceinline__ unsigned long long mc_block_exscan(unsigned long long
 
 // also: block_tot[block] = (triangles << 32 | vertices) of the block's cells - the blocks away from the surface (99 % of them)
 // are skipped by the emit passes on that one word
+// [zc0, zc1): the cell layers this call triangulates (the whole cube: 0, res - 1).  A Z-slab rank of the sharded driver owns a
+// range of layers and holds the planes they read only (`occ` is then a VIRTUAL base pointer: plane z of the full volume at
+// occ + z res^2, dereferenced for its own planes alone); with `halo` the layer zc1 - whose corner plane is the neighbour's first
+// plane - is classified for what the layer below needs from it: the inside bit and the crossings of its x / y edges (their
+// vertices are emitted a second time here, keyed, and merged after the exchange), no z edges, no triangles.  Everything else: 0.
 __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restrict__ occ, int res, float level, int64_t npts,
                                                           uint8_t *__restrict__ flags, uint8_t *__restrict__ ntri,
-                                                          unsigned long long *__restrict__ block_tot)
+                                                          unsigned long long *__restrict__ block_tot, int zc0, int zc1, int halo)
 {
     __shared__ unsigned wsum[kMcBlock / 64];
     const int n = res - 1;
@@ -79,20 +84,23 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restric
     unsigned mine = 0;                                           // vertices | triangles << 16 of this cell (<= 3, <= 5)
     if (i < npts) {
     int x, y, z; mc_cell(i, n, x, y, z);
+    const bool own = z >= zc0 && z < zc1, hal = halo && z == zc1;
+    if (!own && !hal) { flags[i] = 0; ntri[i] = 0; }
+    else {
     // the eight corners from ONE base address and three clamped strides (a corner beyond the last cell repeats the last one):
     // per-corner min() / multiply chains were most of this kernel's instructions
     const float *p0 = occ + ((size_t)(z + 1) * res + (y + 1)) * res + (x + 1);
-    const size_t dx = x + 1 < n ? 1 : 0, dy = y + 1 < n ? (size_t)res : 0, dz = z + 1 < n ? (size_t)res * res : 0;
+    const size_t dx = x + 1 < n ? 1 : 0, dy = y + 1 < n ? (size_t)res : 0, dz = (z + 1 < n && own) ? (size_t)res * res : 0;
     bool in[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) in[k] = p0[((k & 1) ? dx : 0) + ((k & 2) ? dy : 0) + ((k & 4) ? dz : 0)] > level;
     uint8_t f = in[0] ? 8 : 0;
     if (x + 1 < n && in[1] != in[0]) f |= 1;
     if (y + 1 < n && in[2] != in[0]) f |= 2;
-    if (z + 1 < n && in[4] != in[0]) f |= 4;
+    if (own && z + 1 < n && in[4] != in[0]) f |= 4;
     flags[i] = f;
     uint8_t t = 0;
-    if (x + 1 < n && y + 1 < n && z + 1 < n) {
+    if (own && x + 1 < n && y + 1 < n && z + 1 < n) {
         int c = 0;
 #pragma unroll
         for (int k = 0; k < 8; ++k) c |= in[k] ? (1 << k) : 0;
@@ -100,6 +108,7 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restric
     }
     ntri[i] = t;
     mine = (unsigned)__popc(f & 7) | ((unsigned)t << 16);
+    }
     }
     // block total: a 32-bit wave reduction of the packed pair (a wave's sums are <= 192 and <= 320), 16 partial sums through LDS
 #pragma unroll
@@ -181,7 +190,7 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_vertices(const float *__restric
                                                           const int32_t *__restrict__ active,
                                                           const unsigned long long *__restrict__ block_offsets,
                                                           int32_t *__restrict__ first_vertex, int32_t *__restrict__ first_tri,
-                                                          float *__restrict__ verts)
+                                                          float *__restrict__ verts, int64_t *__restrict__ keys)
 {
     __shared__ unsigned long long wsum[kMcBlock / 64];
     const int64_t blk = active[blockIdx.x];                      // a block with a vertex or a triangle (nobody reads the first_* entries of the others)
@@ -198,9 +207,10 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_vertices(const float *__restric
     int x, y, z; mc_cell(i, n, x, y, z);
     const float v = mc_at(occ, res, z, y, x);
     int k = v0;
-    if (f & 1) { const float t = mc_lerp(level, v, mc_at(occ, res, z, y, x + 1)); verts[3 * k] = x + t; verts[3 * k + 1] = (float)y; verts[3 * k + 2] = (float)z; ++k; }
-    if (f & 2) { const float t = mc_lerp(level, v, mc_at(occ, res, z, y + 1, x)); verts[3 * k] = (float)x; verts[3 * k + 1] = y + t; verts[3 * k + 2] = (float)z; ++k; }
-    if (f & 4) { const float t = mc_lerp(level, v, mc_at(occ, res, z + 1, y, x)); verts[3 * k] = (float)x; verts[3 * k + 1] = (float)y; verts[3 * k + 2] = z + t; }
+    // keys (optional): 3 * cell + edge direction - the vertex's place in the order of the whole-volume call
+    if (f & 1) { const float t = mc_lerp(level, v, mc_at(occ, res, z, y, x + 1)); verts[3 * k] = x + t; verts[3 * k + 1] = (float)y; verts[3 * k + 2] = (float)z; if (keys) keys[k] = 3 * i; ++k; }
+    if (f & 2) { const float t = mc_lerp(level, v, mc_at(occ, res, z, y + 1, x)); verts[3 * k] = (float)x; verts[3 * k + 1] = y + t; verts[3 * k + 2] = (float)z; if (keys) keys[k] = 3 * i + 1; ++k; }
+    if (f & 4) { const float t = mc_lerp(level, v, mc_at(occ, res, z + 1, y, x)); verts[3 * k] = (float)x; verts[3 * k + 1] = (float)y; verts[3 * k + 2] = z + t; if (keys) keys[k] = 3 * i + 2; }
 }
 
 __global__ __launch_bounds__(kMcBlock) void k_mc_faces(int res, int64_t npts, const uint8_t *__restrict__ flags,
@@ -257,8 +267,15 @@ using namespace icon;
 extern "C" int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, void *stream,
                              int64_t *n_verts, int64_t *n_faces)
 {
+    return icon_mc_count_range(d_occ, res, level, 0, res - 1, 0, work, stream, n_verts, n_faces);
+}
+
+extern "C" int icon_mc_count_range(const float *d_occ, int res, float level, int zc0, int zc1, int halo, icon_work_t *work, void *stream,
+                                   int64_t *n_verts, int64_t *n_faces)
+{
     ICON_ARG(d_occ && work && n_verts && n_faces, "icon_mc_count: null argument");
     ICON_ARG(res >= 3 && res <= 1291, "icon_mc_count: res out of range");
+    ICON_ARG(zc0 >= 0 && zc0 <= zc1 && zc1 <= res - 1 && (!halo || zc1 < res - 1), "icon_mc_count_range: bad layer range");
     std::call_once(g_mc_once, [] {
         McTab h;
         mc_tables(h.tri, h.edge);
@@ -283,7 +300,7 @@ extern "C" int icon_mc_count(const float *d_occ, int res, float level, icon_work
         ICON_HIP(hipMalloc((void **)&s->first_tri, (size_t)npts * sizeof(int32_t)));
         s->cap = npts;
     }
-    hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot);
+    hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot, zc0, zc1, halo);
     hipLaunchKernelGGL(k_mc_scanblocks, dim3(1), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->totals, s->active);
     ICON_HIP(hipGetLastError());
     unsigned long long h[3];
@@ -296,6 +313,11 @@ extern "C" int icon_mc_count(const float *d_occ, int res, float level, icon_work
 
 extern "C" int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream)
 {
+    return icon_mc_emit_keyed(d_verts, d_faces, nullptr, work, stream);
+}
+
+extern "C" int icon_mc_emit_keyed(float *d_verts, int64_t *d_faces, int64_t *d_keys, icon_work_t *work, void *stream)
+{
     ICON_ARG(work && work->mc && work->mc->counted, "icon_mc_emit: call icon_mc_count first");
     ICON_ARG(d_verts && d_faces, "icon_mc_emit: null output");
     McDevState *s = work->mc;
@@ -304,7 +326,7 @@ extern "C" int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work,
     const int64_t npts = (int64_t)n * n * n;
     if (s->n_active > 0) {
         hipLaunchKernelGGL(k_mc_vertices, dim3((unsigned)s->n_active), dim3(kMcBlock), 0, st, s->occ, s->res, s->level, npts, s->flags, s->ntri,
-                           s->active, s->block_sums, s->first_vertex, s->first_tri, d_verts);
+                           s->active, s->block_sums, s->first_vertex, s->first_tri, d_verts, d_keys);
         hipLaunchKernelGGL(k_mc_faces, dim3((unsigned)s->n_active), dim3(kMcBlock), 0, st, s->res, npts, s->flags, s->ntri, s->active, s->first_vertex,
                            s->first_tri, d_faces);
     }

@@ -198,6 +198,92 @@ class DenseReconEngine(nn.Module):
             occ = self._forward_sharded(be, im_feat, res, dist, world, rank)
         return self._none_if_empty(occ)
 
+    def forward_mesh(self, **kwargs):
+        """``export_mesh(forward(**kwargs))`` in one step - on one rank exactly that; SHARDED (one image over N GPUs) the ranks
+        exchange MESHES instead of the volume: every rank triangulates the cell layers of its own Z-slab (icon_mc_count_range;
+        the neighbour's first plane - one plane, 264 KB at 257^3 - is the only part of the volume that travels), the keyed
+        vertices and faces are gathered (~6 MB at 257^3 instead of the 68 MB volume) and merged by key: the same vertices and
+        faces, in the same order, as marching cubes on the gathered volume.  -> (verts, faces) CPU tensors as export_mesh, or
+        None where forward() returns None.  The volume itself exists on no rank: use forward() when it is needed."""
+        netG = kwargs.get("netG")
+        features = kwargs.get("features")
+        dist, world, rank = self._dist()
+        if world == 1 or not self._lattice_fast_path(kwargs.get("proj_matrix", None)):
+            occ = self.forward(**kwargs)
+            return None if occ is None else self.export_mesh(occ)
+        be = self._backend_for(netG)
+        if not hasattr(be, "slab_finish_gathered"):
+            raise IconAmdError("forward_mesh: the sharded mesh exchange needs the HIP engine as backend")
+        res = self._res()[-1][0]
+        im_feat = features[-1] if isinstance(features, (list, tuple)) else features
+        slab, parts = self._forward_sharded(be, im_feat, res, dist, world, rank, local_only=True)
+        return self._gather_mesh(slab, parts, res, dist, world, rank, im_feat.device)
+
+    def _gather_mesh(self, slab, parts, res, dist, world, rank, dev):
+        from .engine import _stream
+        g = self.process_group
+        z0, z1 = parts[rank]
+        nz = z1 - z0
+        # every rank's first plane: the halo of the rank below it
+        first = slab[:1].contiguous() if nz > 0 else torch.zeros((1, res, res), dtype=torch.float32, device=dev)
+        firsts = self._all_gather_cat(dist, first, world, g)                      # [world, res, res]
+        # forward()'s None rule (_none_if_empty): nothing above 0.5 on the reference's COARSEST lattice - this rank's part of it
+        rs = self._res()
+        st = [max((rs[-1][k] - 1) // max(rs[0][k] - 1, 1), 1) for k in range(3)]   # x, y, z
+        any_pos = bool(nz > 0 and (slab[(-z0) % st[2]:nz:st[2], ::st[1], ::st[0]] > 0.5).any())
+        nxt = next((r for r in range(rank + 1, world) if parts[r][1] > parts[r][0]), None)
+        nv = nf = 0
+        verts = torch.empty((0, 3), dtype=torch.float32, device=dev)
+        faces = torch.empty((0, 3), dtype=torch.int64, device=dev)
+        keys = torch.empty((0,), dtype=torch.int64, device=dev)
+        if nz > 0:
+            halo = nxt is not None
+            buf = torch.empty((nz + 1, res, res), dtype=torch.float32, device=dev)
+            buf[:nz] = slab[:nz]
+            if halo:
+                buf[nz] = firsts[nxt]
+            # a cell layer z reads the planes z + 1 and z + 2: this rank triangulates the layers whose lower plane is its own
+            zc0, zc1 = max(z0 - 1, 0), (z1 - 1 if halo else res - 1)
+            if zc1 > zc0:
+                L = _lib.lib()
+                work = _mc_workspace(dev)
+                virt = C.c_void_p(buf.data_ptr() - z0 * res * res * 4)            # where plane 0 of the whole volume would be
+                cv, cf = C.c_int64(0), C.c_int64(0)
+                with torch.cuda.device(dev):
+                    check(L.icon_mc_count_range(virt, C.c_int(res), C.c_float(float(self.balance_value)), C.c_int(zc0), C.c_int(zc1),
+                                                C.c_int(1 if halo else 0), work.h, _stream(), C.byref(cv), C.byref(cf)), "icon_mc_count_range")
+                    nv, nf = cv.value, cf.value
+                    verts = torch.empty((max(nv, 1), 3), dtype=torch.float32, device=dev)
+                    faces = torch.empty((max(nf, 1), 3), dtype=torch.int64, device=dev)
+                    keys = torch.empty((max(nv, 1),), dtype=torch.int64, device=dev)
+                    if nv:
+                        check(L.icon_mc_emit_keyed(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(keys), work.h, _stream()), "icon_mc_emit_keyed")
+        sizes = self._all_gather_cat(dist, torch.tensor([[nv, nf, int(any_pos)]], dtype=torch.int64, device=dev), world, g).tolist()
+        if not any(s[2] for s in sizes):
+            return None                                                          # forward() returns None: nothing above 0.5 anywhere
+        mv, mf = max(max(s[0] for s in sizes), 1), max(max(s[1] for s in sizes), 1)
+
+        def padded(t, n, m):
+            out = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+            out[:n] = t[:n]
+            return out
+        all_v = self._all_gather_cat(dist, padded(verts, nv, mv), world, g).view(world, mv, 3)
+        all_k = self._all_gather_cat(dist, padded(keys, nv, mv), world, g).view(world, mv)
+        all_f = self._all_gather_cat(dist, padded(faces, nf, mf), world, g).view(world, mf, 3)
+        kk = torch.cat([all_k[r, : sizes[r][0]] for r in range(world)])
+        vv = torch.cat([all_v[r, : sizes[r][0]] for r in range(world)])
+        uniq, inv = torch.unique(kk, sorted=True, return_inverse=True)           # a key = the vertex's place in the whole-volume order
+        out_v = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=dev)
+        out_v[inv] = vv                                                          # (a plane's crossings come from both of its ranks: same bits)
+        off, ff = 0, []
+        for r in range(world):
+            ff.append(inv[all_f[r, : sizes[r][1]] + off])
+            off += sizes[r][0]
+        out_f = torch.cat(ff) if ff else torch.empty((0, 3), dtype=torch.int64, device=dev)
+        self.last_stats = dict(gather="mesh", exchanged_bytes=int(world * (res * res * 4 + mv * 20 + mf * 24)), slabs=parts,
+                               verts=int(out_v.shape[0]), faces=int(out_f.shape[0]))
+        return out_v.cpu(), out_f.cpu()
+
     @staticmethod
     def _all_gather_cat(dist, t, world, group):
         """all_gather of one equal-shaped tensor per rank, concatenated along dim 0 (ONE collective into
@@ -251,7 +337,7 @@ class DenseReconEngine(nn.Module):
         self._cuts_key, self._cuts = key, parts
         return parts
 
-    def _forward_sharded(self, be, im_feat, res, dist, world, rank):
+    def _forward_sharded(self, be, im_feat, res, dist, world, rank, local_only=False):
         g = self.process_group
         dev = im_feat.device
         want = self.reserve_cus
@@ -272,7 +358,7 @@ class DenseReconEngine(nn.Module):
         pieces = hasattr(be, "slab_finish_gathered")
         # the volume is gathered in two halves of every rank's (padded) slab: the first half travels over xGMI while
         # the second half is still in the MLP kernel
-        per_a = (per + 1) // 2 if (self.overlap_gather and pieces and per > 1) else per
+        per_a = (per + 1) // 2 if (self.overlap_gather and pieces and per > 1 and not local_only) else per
         handles = []
 
         def gather_async(t):
@@ -296,6 +382,8 @@ class DenseReconEngine(nn.Module):
             zm = min(z1, z0 + per_a)
             if zm > z0:
                 be.slab_finish_gathered(res, z0, z1, gathered, stride, world, rank, out=slab[: z1 - z0], za=z0, zb=zm, device=dev)
+            if local_only:                       # forward_mesh: the slab stays here, meshes travel
+                return slab, parts
             vol_a, h = gather_async(slab[:per_a])
             handles.append(h)
             vol_b = None

@@ -352,6 +352,17 @@ int icon_export_mesh(const float *h_occ, int res, float level,
 int icon_mc_count(const float *d_occ, int res, float level, icon_work_t *work, void *stream,
                   int64_t *n_verts, int64_t *n_faces);
 int icon_mc_emit(float *d_verts, int64_t *d_faces, icon_work_t *work, void *stream);
+/* One Z-slab's share of the same triangulation (the sharded driver's gather="mesh": meshes instead of the volume cross xGMI).
+ * Cell layers [zc0, zc1) only (a layer z reads the planes z + 1 and z + 2 of the volume, export_mesh's occ[1:,1:,1:] view);
+ * d_occ is the address plane 0 of the full [res,res,res] volume WOULD have - only the planes the layers read (and, with halo,
+ * plane zc1 + 1, the neighbour's first) are dereferenced, so a rank passes slab_ptr - first_plane * res^2.  halo = 1: the x / y
+ * edge crossings of plane zc1 + 1 are emitted too (the layer below refers to them; the neighbour emits them as well).
+ * icon_mc_emit_keyed also writes d_keys [n_verts] i64 = 3 * cell + edge direction: the vertex's place in the vertex order of the
+ * whole-volume call - concatenating the ranks' outputs in rank order and merging equal keys (sorted unique) reproduces
+ * icon_mc_count / icon_mc_emit on the whole volume, vertex for vertex and face for face. */
+int icon_mc_count_range(const float *d_occ, int res, float level, int zc0, int zc1, int halo, icon_work_t *work, void *stream,
+                        int64_t *n_verts, int64_t *n_faces);
+int icon_mc_emit_keyed(float *d_verts, int64_t *d_faces, int64_t *d_keys, icon_work_t *work, void *stream);
 
 /* ---- PaMIR semantic voxelisation ---------------------------------------------------------------------
  * replaces voxelize_cuda.forward_semantic_voxelization (external CUDA wheel, requirements.txt:34; call site

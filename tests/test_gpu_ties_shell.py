@@ -437,6 +437,29 @@ def test_real_ranks_on_one_gpu_run_the_hip_slab_kernels(world):
     assert p.returncode == 0 and f"DIST_GPU_OK world={world} checked=8" in p.stdout, p.stdout[-4000:]
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_real_ranks_exchange_meshes_instead_of_the_volume(world):
+    """DenseReconEngine.forward_mesh under REAL ranks (gloo, one GPU): every rank triangulates the cell layers of its own Z-slab
+    (icon_mc_count_range / icon_mc_emit_keyed; only the neighbour's first plane of the volume travels), keyed vertices and faces
+    are gathered and merged by key - the same vertices and faces IN THE SAME ORDER as marching cubes on the single-process
+    volume, 33^3 .. 129^3, both cmap modes, equal and cost-balanced cuts; None where forward() returns None
+    (tests/dist_gpu_mesh_worker.py)"""
+    import os
+    import socket
+    import subprocess
+    import sys
+    from common import ROOT
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_mesh_worker.py")]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0 and f"DIST_MESH_OK world={world} checked=12" in p.stdout, p.stdout[-4000:]
+
+
 # ---------------------------------------------------------------------------------------------
 # randomised sweep over lattice sizes, slabs, pieces, clip bands and bodies (tile mapping, shell, ranks)
 # ---------------------------------------------------------------------------------------------
