@@ -250,6 +250,10 @@ def main():
     ap.add_argument("--replicas", action="store_true",
                     help="N > 1: one image per GPU, every rank evaluates a whole volume, no data-path collective (BASELINE.json "
                          "configs[4]: 513^3 x 8 images); default: ONE image, Z-slabs sharded over the ranks (configs[2])")
+    ap.add_argument("--mesh-exchange", action="store_true",
+                    help="N > 1, sharded: the step ends in the MESH (DenseReconEngine.forward_mesh: every rank triangulates its own "
+                         "Z-slab, keyed meshes are exchanged instead of the 68 MB volume) - same points evaluated, other collective; "
+                         "the default (volume all-gather, what BASELINE.json's north_star names) is what the driver measures")
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine "
                          "reserve_cus); -1 = the engine's default (16 over RCCL with the overlapped gather, else 0)")
@@ -319,7 +323,11 @@ def main():
                              balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
     opt = SimpleNamespace(num_views=1)
 
+    mesh_exchange = bool(args.mesh_exchange and world > 1 and not args.replicas)
+
     def step(r=recon, e=eng):
+        if mesh_exchange:
+            return r.forward_mesh(opt=opt, netG=e, features=feats, proj_matrix=None)
         return r(opt=opt, netG=e, features=feats, proj_matrix=None)
 
     # one-off per-image preparation (BVH build, plane repack, BatchNorm fold + operand packing)
@@ -355,7 +363,10 @@ def main():
         elapsed = float(t.item())
     stage /= max(args.steps, 1)
     eng._work().profile(False)
-    assert occ is not None and occ.shape == (res, res, res)
+    if mesh_exchange:                                   # the step returned (verts, faces): what marching cubes on the volume gives
+        assert occ is not None and occ[0].shape[1] == 3 and occ[1].shape[1] == 3 and occ[1].shape[0] > 0
+    else:
+        assert occ is not None and occ.shape == (res, res, res)
 
     n_points = res ** 3
     z0, z1 = recon.last_stats["slabs"][rank] if (world > 1 and not args.replicas) else (0, res)      # the cut the engine actually used
@@ -565,6 +576,9 @@ def main():
             out["config"]["rank_stage_ms"] = rank_stage
         if world > 1 and not args.replicas:
             out["config"]["reserve_cus"] = getattr(recon, "reserve_cus_effective", None)     # CUs the MLP grid left to the collective
+            out["config"]["gather"] = "mesh" if mesh_exchange else "volume"
+            if mesh_exchange:
+                out["config"]["exchanged_bytes_per_step"] = recon.last_stats.get("exchanged_bytes")
         if not args.no_cpu_baseline and world == 1 and args.prior == "icon":
             out["cpu_baseline"] = cpu_baseline(a, res)
             out["cpu_baseline"]["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]

@@ -263,13 +263,18 @@ class DenseReconEngine(nn.Module):
             return None                                                          # forward() returns None: nothing above 0.5 anywhere
         mv, mf = max(max(s[0] for s in sizes), 1), max(max(s[1] for s in sizes), 1)
 
-        def padded(t, n, m):
-            out = torch.zeros((m,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
-            out[:n] = t[:n]
-            return out
-        all_v = self._all_gather_cat(dist, padded(verts, nv, mv), world, g).view(world, mv, 3)
-        all_k = self._all_gather_cat(dist, padded(keys, nv, mv), world, g).view(world, mv)
-        all_f = self._all_gather_cat(dist, padded(faces, nf, mf), world, g).view(world, mf, 3)
+        # ONE message per rank: [keys i64 x mv | vertices f32 x 3 mv | faces i32 x 3 mf], padded to the largest rank
+        nb_k, nb_v, nb_f = mv * 8, mv * 12, mf * 12
+        msg = torch.zeros(nb_k + nb_v + nb_f, dtype=torch.uint8, device=dev)
+        if nv:
+            msg[:nb_k].view(torch.int64)[:nv] = keys[:nv]
+            msg[nb_k:nb_k + nb_v].view(torch.float32).view(mv, 3)[:nv] = verts[:nv]
+        if nf:
+            msg[nb_k + nb_v:].view(torch.int32).view(mf, 3)[:nf] = faces[:nf].to(torch.int32)
+        allm = self._all_gather_cat(dist, msg, world, g).view(world, -1)
+        all_k = allm[:, :nb_k].contiguous().view(torch.int64).view(world, mv)
+        all_v = allm[:, nb_k:nb_k + nb_v].contiguous().view(torch.float32).view(world, mv, 3)
+        all_f = allm[:, nb_k + nb_v:].contiguous().view(torch.int32).view(world, mf, 3).to(torch.int64)
         kk = torch.cat([all_k[r, : sizes[r][0]] for r in range(world)])
         vv = torch.cat([all_v[r, : sizes[r][0]] for r in range(world)])
         uniq, inv = torch.unique(kk, sorted=True, return_inverse=True)           # a key = the vertex's place in the whole-volume order
@@ -280,7 +285,7 @@ class DenseReconEngine(nn.Module):
             ff.append(inv[all_f[r, : sizes[r][1]] + off])
             off += sizes[r][0]
         out_f = torch.cat(ff) if ff else torch.empty((0, 3), dtype=torch.int64, device=dev)
-        self.last_stats = dict(gather="mesh", exchanged_bytes=int(world * (res * res * 4 + mv * 20 + mf * 24)), slabs=parts,
+        self.last_stats = dict(gather="mesh", exchanged_bytes=int(world * (res * res * 4 + 24 + mv * 20 + mf * 12)), collectives=3, slabs=parts,
                                verts=int(out_v.shape[0]), faces=int(out_f.shape[0]))
         return out_v.cpu(), out_f.cpu()
 
