@@ -275,16 +275,8 @@ class DenseReconEngine(nn.Module):
         all_k = allm[:, :nb_k].contiguous().view(torch.int64).view(world, mv)
         all_v = allm[:, nb_k:nb_k + nb_v].contiguous().view(torch.float32).view(world, mv, 3)
         all_f = allm[:, nb_k + nb_v:].contiguous().view(torch.int32).view(world, mf, 3).to(torch.int64)
-        kk = torch.cat([all_k[r, : sizes[r][0]] for r in range(world)])
-        vv = torch.cat([all_v[r, : sizes[r][0]] for r in range(world)])
-        uniq, inv = torch.unique(kk, sorted=True, return_inverse=True)           # a key = the vertex's place in the whole-volume order
-        out_v = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=dev)
-        out_v[inv] = vv                                                          # (a plane's crossings come from both of its ranks: same bits)
-        off, ff = 0, []
-        for r in range(world):
-            ff.append(inv[all_f[r, : sizes[r][1]] + off])
-            off += sizes[r][0]
-        out_f = torch.cat(ff) if ff else torch.empty((0, 3), dtype=torch.int64, device=dev)
+        out_v, out_f = merge_keyed_meshes([all_k[r, : sizes[r][0]] for r in range(world)], [all_v[r, : sizes[r][0]] for r in range(world)],
+                                          [all_f[r, : sizes[r][1]] for r in range(world)])
         self.last_stats = dict(gather="mesh", exchanged_bytes=int(world * (res * res * 4 + 24 + mv * 20 + mf * 12)), collectives=3, slabs=parts,
                                verts=int(out_v.shape[0]), faces=int(out_f.shape[0]))
         return out_v.cpu(), out_f.cpu()
@@ -598,6 +590,24 @@ def _mc_workspace(device: torch.device):
     if idx not in pool:
         pool[idx] = Workspace()
     return pool[idx]
+
+
+def merge_keyed_meshes(keys, verts, faces):
+    """The pieces of a sharded triangulation (DenseReconEngine.forward_mesh) -> one mesh.  Per rank, in rank order: keys [nv] int64
+    (3 * cell + edge direction = the vertex's place in the vertex order of marching cubes on the whole volume; the crossings
+    of a plane two ranks share appear in both, with the same coordinates), verts [nv,3], faces [nf,3] indexing the rank's own
+    vertices.  Vertices: sorted unique keys; faces: renumbered through the inverse map, concatenated in rank order (= cell
+    order).  -> (verts [V,3] float32, faces [F,3] int64)"""
+    kk, vv = torch.cat(list(keys)), torch.cat(list(verts))
+    uniq, inv = torch.unique(kk, sorted=True, return_inverse=True)
+    out_v = torch.empty((uniq.shape[0], 3), dtype=torch.float32, device=vv.device)
+    out_v[inv] = vv.to(torch.float32)
+    off, ff = 0, []
+    for k, f in zip(keys, faces):
+        ff.append(inv[f.to(torch.int64) + off])
+        off += int(k.shape[0])
+    out_f = torch.cat(ff) if ff else torch.empty((0, 3), dtype=torch.int64, device=vv.device)
+    return out_v, out_f.reshape(-1, 3)
 
 
 def export_mesh_device(occ: torch.Tensor, level: float = 0.5):

@@ -69,6 +69,28 @@ def test_device_marching_cubes_257_vs_independent_checker():
     print("257^3 mesh:", t)
 
 
+def test_merge_of_keyed_mesh_pieces_restores_the_whole_mesh():
+    """recon.merge_keyed_meshes (the last step of the sharded mesh exchange, DenseReconEngine.forward_mesh) on the CPU: a host
+    marching-cubes mesh with its vertices keyed by their order, cut into 3 'ranks' by face ranges - every piece re-indexes its
+    own vertices, so vertices used on both sides of a cut appear in two pieces - merges back into exactly the original"""
+    from icon_amd.recon import export_mesh_numpy, merge_keyed_meshes
+    z, y, x = np.meshgrid(*([np.linspace(-1, 1, 33)] * 3), indexing="ij")
+    occ = (0.7 - np.sqrt(x * x + 0.8 * y * y + 1.3 * z * z)).astype(np.float32) + 0.5
+    v, f = export_mesh_numpy(occ, 0.5)
+    assert f.shape[0] > 1000
+    keys = torch.arange(v.shape[0], dtype=torch.int64) * 7 + 3              # any strictly increasing keys
+    cuts = [0, f.shape[0] // 3, f.shape[0] // 2, f.shape[0]]
+    pk, pv, pf = [], [], []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        used = torch.unique(f[a:b].reshape(-1))                              # ascending: a piece's vertices keep their relative order
+        local = torch.full((v.shape[0],), -1, dtype=torch.int64)
+        local[used] = torch.arange(used.shape[0])
+        pk.append(keys[used]); pv.append(v[used]); pf.append(local[f[a:b]])
+    assert sum(k.shape[0] for k in pk) > v.shape[0]                          # the cuts do duplicate vertices
+    mv, mf = merge_keyed_meshes(pk, pv, pf)
+    assert torch.equal(mv, v.float()) and torch.equal(mf, f.long())
+
+
 def test_checker_face_connectivity_vs_vertex_connectivity():
     """oracle/mc_check.py: largest_component_by_faces (trimesh's edge-based face adjacency, the checker of icon_clean_mesh)
     against largest_component (vertex connectivity): equal on closed surfaces without pinch vertices; at a pinch (two
