@@ -219,8 +219,30 @@ class DenseReconEngine(nn.Module):
         slab, parts = self._forward_sharded(be, im_feat, res, dist, world, rank, local_only=True)
         return self._gather_mesh(slab, parts, res, dist, world, rank, im_feat.device)
 
-    def _gather_mesh(self, slab, parts, res, dist, world, rank, dev):
+    @staticmethod
+    def _hip_slab_mesh(buf, z0, res, zc0, zc1, halo, level):
+        """marching cubes over the cell layers [zc0, zc1) of the volume whose planes z0, z0 + 1, ... are `buf` (device), the
+        x / y edge crossings of layer zc1 included when `halo`; -> (keys [nv] i64, verts [nv,3] f32, faces [nf,3] i64 local)"""
         from .engine import _stream
+        if not buf.is_cuda:
+            raise IconAmdError("forward_mesh: the slab triangulation runs on the HIP device (there is no CPU path)")
+        dev = buf.device
+        L = _lib.lib()
+        work = _mc_workspace(dev)
+        virt = C.c_void_p(buf.data_ptr() - z0 * res * res * 4)                    # where plane 0 of the whole volume would be
+        cv, cf = C.c_int64(0), C.c_int64(0)
+        with torch.cuda.device(dev):
+            check(L.icon_mc_count_range(virt, C.c_int(res), C.c_float(level), C.c_int(zc0), C.c_int(zc1), C.c_int(1 if halo else 0),
+                                        work.h, _stream(), C.byref(cv), C.byref(cf)), "icon_mc_count_range")
+            nv, nf = cv.value, cf.value
+            verts = torch.empty((max(nv, 1), 3), dtype=torch.float32, device=dev)
+            faces = torch.empty((max(nf, 1), 3), dtype=torch.int64, device=dev)
+            keys = torch.empty((max(nv, 1),), dtype=torch.int64, device=dev)
+            if nv:
+                check(L.icon_mc_emit_keyed(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(keys), work.h, _stream()), "icon_mc_emit_keyed")
+        return keys[:nv], verts[:nv], faces[:nf]
+
+    def _gather_mesh(self, slab, parts, res, dist, world, rank, dev):
         g = self.process_group
         z0, z1 = parts[rank]
         nz = z1 - z0
@@ -245,19 +267,9 @@ class DenseReconEngine(nn.Module):
             # a cell layer z reads the planes z + 1 and z + 2: this rank triangulates the layers whose lower plane is its own
             zc0, zc1 = max(z0 - 1, 0), (z1 - 1 if halo else res - 1)
             if zc1 > zc0:
-                L = _lib.lib()
-                work = _mc_workspace(dev)
-                virt = C.c_void_p(buf.data_ptr() - z0 * res * res * 4)            # where plane 0 of the whole volume would be
-                cv, cf = C.c_int64(0), C.c_int64(0)
-                with torch.cuda.device(dev):
-                    check(L.icon_mc_count_range(virt, C.c_int(res), C.c_float(float(self.balance_value)), C.c_int(zc0), C.c_int(zc1),
-                                                C.c_int(1 if halo else 0), work.h, _stream(), C.byref(cv), C.byref(cf)), "icon_mc_count_range")
-                    nv, nf = cv.value, cf.value
-                    verts = torch.empty((max(nv, 1), 3), dtype=torch.float32, device=dev)
-                    faces = torch.empty((max(nf, 1), 3), dtype=torch.int64, device=dev)
-                    keys = torch.empty((max(nv, 1),), dtype=torch.int64, device=dev)
-                    if nv:
-                        check(L.icon_mc_emit_keyed(_lib.ptr(verts), _lib.ptr(faces), _lib.ptr(keys), work.h, _stream()), "icon_mc_emit_keyed")
+                mesher = getattr(self, "slab_mesher", None) or self._hip_slab_mesh     # (tests inject a CPU stand-in, like `backend`)
+                keys, verts, faces = mesher(buf, z0, res, zc0, zc1, halo, float(self.balance_value))
+                nv, nf = int(keys.shape[0]), int(faces.shape[0])
         sizes = self._all_gather_cat(dist, torch.tensor([[nv, nf, int(any_pos)]], dtype=torch.int64, device=dev), world, g).tolist()
         if not any(s[2] for s in sizes):
             return None                                                          # forward() returns None: nothing above 0.5 anywhere

@@ -188,6 +188,83 @@ def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, world):
     assert all(r[1] for r in res), res
 
 
+def standin_slab_mesh(buf, z0, res, zc0, zc1, halo, level):
+    """A stand-in for the slab triangulation with marching cubes' OWNERSHIP structure (what the exchange protocol depends on): a cell
+    owns the crossings of its +x / +y / +z edges (keys 3 * cell + direction, the halo layer only its x / y edges), and its faces -
+    every run of three in [its own crossings, the x / y crossings of the cell ABOVE] - refer to vertices of the next layer.  Plain numpy loops; -> (keys, verts, faces) torch tensors, faces index the call's own vertices."""
+    vol = buf.numpy() if hasattr(buf, "numpy") else np.asarray(buf)
+    n = res - 1
+    inside = lambda z: vol[z + 1 - z0][1:, 1:] > level                           # corner 0 of the cells of layer z: plane z + 1
+    keys, verts, idx = [], [], {}
+    for z in list(range(zc0, zc1)) + ([zc1] if halo else []):
+        own = z < zc1
+        P = inside(z)
+        Pz = inside(z + 1) if (own and z + 1 < n) else None
+        for y in range(n):
+            for x in range(n):
+                cell = (z * n + y) * n + x
+                cand = [(0, x + 1 < n and P[y, x] != P[y, min(x + 1, n - 1)], (x + 0.5, y, z)),
+                        (1, y + 1 < n and P[y, x] != P[min(y + 1, n - 1), x], (x, y + 0.5, z)),
+                        (2, Pz is not None and P[y, x] != Pz[y, x], (x, y, z + 0.5))]
+                for d, hit, pos in cand:
+                    if hit:
+                        idx[(cell, d)] = len(keys); keys.append(3 * cell + d); verts.append(pos)
+    faces = []
+    for z in range(zc0, zc1):
+        if z + 1 >= n:
+            continue
+        for y in range(n):
+            for x in range(n):
+                here, above = (z * n + y) * n + x, ((z + 1) * n + y) * n + x
+                lst = [idx[(here, d)] for d in (0, 1, 2) if (here, d) in idx] + [idx[(above, d)] for d in (0, 1) if (above, d) in idx]
+                faces += [tuple(lst[k:k + 3]) for k in range(len(lst) - 2)]          # every run of three: many refer to the layer above
+    return (torch.tensor(keys, dtype=torch.int64), torch.tensor(verts, dtype=torch.float32).reshape(-1, 3),
+            torch.tensor(faces, dtype=torch.int64).reshape(-1, 3))
+
+
+def _mesh_worker(rank, world, port, cmap_mode, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a = assets("ico")
+        be = OracleBackend(a, cmap_mode)
+        be.cmap_mode = cmap_mode
+        recon = DenseReconEngine(query_func=None, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                 resolutions=[9, RES], align_corners=True, backend=be)
+        recon.slab_mesher = standin_slab_mesh
+        out = recon.forward_mesh(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)
+        wk, wv, wf = standin_slab_mesh(torch.from_numpy(be.full), 0, RES, 0, RES - 1, False, 0.5)      # the whole volume at once
+        ok = out is not None and recon.last_stats.get("gather") == "mesh" and recon.last_stats["collectives"] == 3
+        ok = ok and len(wf) > 30 and torch.equal(out[0], wv) and torch.equal(out[1], wf)
+        q.put((rank, bool(ok), [tuple(out[0].shape), tuple(out[1].shape), tuple(wv.shape), tuple(wf.shape)] if out is not None else None))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+@pytest.mark.parametrize("world", [2, 3])
+def test_mesh_exchange_protocol_gloo(cmap_mode, world):
+    """DenseReconEngine.forward_mesh under gloo ranks on the CPU: slabs from the checker backend, the slab triangulation replaced
+    by a stand-in with marching cubes' ownership structure (standin_slab_mesh) - what is under test is the PROTOCOL: the halo
+    plane from the next rank, the cell-layer ranges, the sizes, the one packed message per rank, the merge by key.  The merged mesh
+    equals the stand-in applied to the whole volume, vertex for vertex and face for face.  (The real triangulation behind the
+    same protocol: tests/test_gpu_ties_shell.py::test_real_ranks_exchange_meshes_instead_of_the_volume.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mesh_worker, args=(r, world, port, cmap_mode, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+
+
 def test_single_process_path_uses_one_slab():
     a = assets("ico")
     be = OracleBackend(a, "reference")
