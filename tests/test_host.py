@@ -31,6 +31,21 @@ def test_header_is_plain_c():
     assert r.returncode == 0, r.stderr
 
 
+def test_every_object_is_compiled_once_with_its_own_flags():
+    """round 4 left an orphan recipe line behind a deleted target: mlp_f16x3.o was compiled twice, the shipped
+    object with flags meant for another file.  Every object: one compile command, naming its own source."""
+    csrc = os.path.join(ROOT, "icon_amd", "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    objs = re.search(r"^OBJS\s*:=\s*(.*)$", mk, re.M).group(1).split()
+    assert len(objs) == len(set(objs)) >= 14
+    for o in objs:
+        r = subprocess.run(["make", "-n", "-B", "-C", csrc, o], capture_output=True, text=True)
+        cmds = [l for l in r.stdout.splitlines() if "hipcc" in l]
+        assert len(cmds) == 1, (o, cmds)
+        assert re.search(r"-c %s\.(hip|cpp) -o %s$" % (o[:-2], o), cmds[0]), cmds[0]
+        assert "-fno-honor-nans" not in cmds[0] and "-ffast-math" not in cmds[0]
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-device behaviour")
 def test_fails_loudly_without_device():
     from icon_amd.engine import IconAmdError, IconQueryEngine, MlpHandle
