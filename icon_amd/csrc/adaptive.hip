@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ 
 // longest walk (4^3 blocks: 390 us per level; 2^3 blocks, 8 of 64 lanes at work: 270 us; shared 4^3 blocks: ~100 us).
 template <int P, int NW>
 __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev m, int r, int nbk, const int32_t *__restrict__ list,
-                                                                       const int *__restrict__ n_list, const uint8_t *__restrict__ C, NearRef near, float sdf_clip)
+                                                                       const int *__restrict__ n_list, const uint8_t *__restrict__ C, NearRef near, float sdf_clip, ShareDbg dbg)
 {
     constexpr int kWaves = NW == 1 ? 4 : NW;
     __shared__ int lds[kWaves * kStackDepth];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev 
         const f3 p = lattice_world(r, cx, cy, cz);
         Nearest nr;
         if (NW == 1) nr = nearest_packet(m, p, live, lds + wave * kStackDepth, nullptr, nullptr, INFINITY, nullptr, P == 4 ? 21 : 0);
-        else nr = nearest_shared<NW>(m, p, live, lds + wave * kStackDepth, smem, P == 4 ? 21 : 0);
+        else nr = nearest_shared<NW>(m, p, live, lds + wave * kStackDepth, smem, P == 4 ? 21 : 0, dbg);
         if (live && (NW == 1 || wave == 0)) store_near(near, ((int64_t)cz * r + cy) * r + cx, nr, sdf_clip);
     }
 }
@@ -378,28 +378,40 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
     bool same = a && a->n_levels == n_levels;
     for (int l = 0; same && l < n_levels; ++l) same = a->res[l] == resolutions[l];
     if (!same) {
+        // built in a local and published only when every allocation succeeded: a failure half-way must not leave a record behind
+        // whose resolutions match the next call's (it would skip this block and launch on null buffers)
         adaptive_destroy(a);
-        work->ad = a = new icon_adaptive();
+        work->ad = nullptr;
+        a = new icon_adaptive();
         a->n_levels = n_levels;
         for (int l = 0; l < n_levels; ++l) a->res[l] = resolutions[l];
         const int rq = n_levels >= 2 ? resolutions[n_levels - 2] : resolutions[0];      // the largest level that is queried / masked
         a->cap = (int64_t)rq * rq * rq;
-        for (int l = 0; l + 1 < n_levels; ++l) {
+        rc = ICON_OK;
+        for (int l = 0; !rc && l + 1 < n_levels; ++l) {
             const size_t n = (size_t)resolutions[l] * resolutions[l] * resolutions[l];
-            if ((rc = grow(&a->occ[l], n))) return rc;
-            if (l >= 1 && (rc = grow(&a->D[l], n))) return rc;
+            rc = grow(&a->occ[l], n);
+            if (!rc && l >= 1) rc = grow(&a->D[l], n);
         }
         const int nbk = (rq + 1) / 2;                            // blocks of the finest granularity used (2^3)
-        if ((rc = grow(&a->P, (size_t)a->cap)) || (rc = grow(&a->M1, (size_t)a->cap)) ||
-            (rc = grow(&a->map, (size_t)a->cap)) || (rc = grow(&a->pts, (size_t)a->cap * 3)) ||
-            (rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256)) || (rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256)) ||
-            (rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk)) ||
-            (rc = grow(&a->counters, (size_t)16)))
-            return rc;
-        ICON_HIP(hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocDefault));
+        if (!rc) rc = grow(&a->P, (size_t)a->cap);
+        if (!rc) rc = grow(&a->M1, (size_t)a->cap);
+        if (!rc) rc = grow(&a->map, (size_t)a->cap);
+        if (!rc) rc = grow(&a->pts, (size_t)a->cap * 3);
+        if (!rc) rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256);
+        if (!rc) rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256);
+        if (!rc) rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk);
+        if (!rc) rc = grow(&a->counters, (size_t)16);
+        if (!rc && hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+            rc = fail(ICON_ERR_HIP, "icon_adaptive_eval: hipHostMalloc of the counter mirror failed");
+        if (rc) { adaptive_destroy(a); return rc; }
+        work->ad = a;
     }
     a->occ[n_levels - 1] = d_out;
     ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
+    // whatever way this function is left, the workspace must not keep pointing at a level's compaction buffers: a later point
+    // query on it would read them as ITS map
+    struct QMapGuard { icon_work *w; ~QMapGuard() { w->q_map = nullptr; w->q_n_dev = nullptr; } } q_guard{work};
 
     // ---- level 0: the coarsest lattice, dense, ONE call ---------------------------------------------------------------
     const int r0 = resolutions[0];
@@ -451,10 +463,12 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             int n_cu = 0;
             if ((rc = device_cu_count(&n_cu))) return rc;
             // the number of blocks is known on the device only: a grid that fills the wave slots, every workgroup loops
-            static const int share_env = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;   // diagnostics: 1 = one wave per block
+            const int share_env = share_waves_override();        // diagnostics: 1 = one wave per block
             const int nw = (share_env == 1 || share_env == 4 || share_env == 8 || share_env == 16) ? share_env : kShareWavesMany;
+            ShareDbg dbg{};
+            if ((rc = work_share_dbg(work, &dbg))) return rc;
 #define ICON_AD_NEAREST(PP, NW) hipLaunchKernelGGL((k_ad_nearest<PP, NW>), dim3((unsigned)(n_cu * 32 / (NW == 1 ? 4 : NW))), dim3(NW == 1 ? 256 : NW * 64), 0, st, \
-                                                   mesh->dev, r, nbk, a->blk_list, a->counters + 8, C, raw, sdf_clip)
+                                                   mesh->dev, r, nbk, a->blk_list, a->counters + 8, C, raw, sdf_clip, dbg)
             if (P == 4 && nw == 16) ICON_AD_NEAREST(4, 16);
             else if (P == 4 && nw == 8) ICON_AD_NEAREST(4, 8);
             else if (P == 4 && nw == 4) ICON_AD_NEAREST(4, 4);
@@ -492,6 +506,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
         h_counts[0] = (int64_t)r0 * r0 * r0;                    // level 0 evaluates every voxel
         h_counts[n_levels] = host[9];
+        if ((rc = work_check_err(work))) return rc;             // the stream is idle: the verdict on THIS schedule's shared walks
     }
     return ICON_OK;
 }
@@ -507,5 +522,5 @@ extern "C" int icon_adaptive_counts(icon_work_t *work, int n_levels, int64_t *h_
     for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
     h_counts[0] = (int64_t)work->ad->res[0] * work->ad->res[0] * work->ad->res[0];
     h_counts[n_levels] = host[9];
-    return ICON_OK;
+    return work_check_err(work);
 }

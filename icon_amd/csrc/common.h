@@ -309,6 +309,18 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
 // per-device launch facts (CU count; one-off kernel attributes): a process may drive several devices
 int device_cu_count(int *n_cu);
 int once_per_device(int kernel_id, const std::function<hipError_t()> &set);   // runs `set` once per (kernel_id, current device), under a mutex
+struct LatticeFast;                   // geom_device.h
+// shared walks (nearest_shared, geom_device.h): where a wave reports a hand-over it gave up on + the test-only switches
+struct ShareDbg {
+    int *err;                                 // [8] host-mapped error record (zero = no error), or null
+    int ring, lose, spin_log2;
+};
+// fills `out` for a launch on this workspace: the workspace's host-mapped error record (allocated on first use) and the process-
+// wide test switches of icon_debug_set_option
+int work_share_dbg(icon_work *w, ShareDbg *out);
+// ICON_ERR_STATE (and the record cleared) if a shared walk of an earlier launch on this workspace reported; no synchronisation
+int work_check_err(icon_work *w);
+int share_waves_override();           // ICON_AMD_SHARE / icon_debug_set_option("share_waves"): -1 = by launch size
 }  // namespace icon
 
 struct icon_work {
@@ -337,6 +349,8 @@ struct icon_work {
     int32_t *d_row_count = nullptr;       // lattice mode: per (y,z) row, triangles covering the row
     int32_t *d_row_slots = nullptr;       // [rows][kRowCap]
     int64_t cap_rows = 0;
+    int *h_err = nullptr;                 // [8] host-mapped error record of the shared walks (zero = none): work_share_dbg / work_check_err
+    icon::LatticeFast *d_lfast = nullptr; // lattice mode: the search's per-packet set-up, written once per call (geom_device.h)
     // point mode: Morton order of the query points (sort_points.hip), so that a wavefront's 64 points are neighbours
     uint32_t *d_sort_keys = nullptr;      // [2][cap_sort]
     int32_t *d_sort_idx = nullptr;        // [2][cap_sort]

@@ -340,16 +340,46 @@ __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool l
 // over a superset of the faces within the final bound: the same key as nearest_packet, bit for bit.
 // All NW waves must call this together (workgroup barriers).  The result is valid in wave 0 only.
 constexpr int kRing = 64, kRingEmpty = 0x7fffffff;
+// EVERY wait of the hand-over is bounded (round 5).  The two waits below - a popper for the push that owns its ticket, a pusher
+// for the popper a full turn of the ring behind to clear its slot - are waits for a wave that is itself never blocked, so they
+// last nanoseconds; but an unbounded spin turns any bug or lost store into a GPU hang that ends in SIGKILL with no message (the
+// one unexplained fatal signal of round 4).  On expiry the wave records WHAT it was waiting for in the workspace's error word
+// (host-mapped memory, written on errors only: code, workgroup, ticket, head / tail at that moment), gives the wait up and the
+// walk still terminates - its result is then suspect, and the host reports ICON_ERR_STATE at its next status read
+// (icon_work_status; icon_adaptive_eval / icon_grid_eval_slab / icon_query_points check the word without synchronising).
+constexpr int kShareSpinLog2 = 18;            // 2^18 polls of ~0.2 us: ~50 ms, five orders of magnitude above a real hand-over
+constexpr int kShareErrPop = 1;               // a popper's ticket was never filled (lost / abandoned push)
+constexpr int kShareErrPush = 2;              // a pusher's slot was never cleared (ring a full turn behind)
+constexpr int kShareErrIdle = 3;              // the idle loop of a wave expired while other waves were still active
+// test-only behaviour, all zero in production (icon_debug_set_option "share_ring" / "share_lose_push" / "share_spin_log2"):
+//   ring     - forced ring size (power of two >= 2): a ring smaller than 2 NW makes pushers really wait for poppers
+//   lose     - the push with ticket `lose` (>= 1) of every packet claims its ticket and announces it, but never stores the node
+//   spin_log2 - wait bound 2^spin_log2 polls
 struct ShareLds {
     unsigned thr[64];
     int head, tail, avail, active;
-    int pad[12];
+    int mask, lose, spins, pad1;
+    int pad[8];
     int ring[kRing];
     unsigned long long keys[1];           // [NW][64]
 };
 __host__ __device__ constexpr size_t share_lds_bytes(int nw) { return sizeof(ShareLds) + (size_t)nw * 64 * 8; }
 
-__device__ __forceinline__ int share_pop(ShareLds &S, int lane)
+// first error wins (system scope: the record lives in host memory); lane 0 of the reporting wave only
+__device__ __forceinline__ void share_report(const ShareDbg &dbg, int code, int ticket, const ShareLds &S)
+{
+    if (!dbg.err) return;
+    int expected = 0;
+    if (__hip_atomic_compare_exchange_strong(dbg.err, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+        dbg.err[1] = (int)blockIdx.x; dbg.err[2] = ticket;
+        dbg.err[3] = *(volatile const int *)&S.head; dbg.err[4] = *(volatile const int *)&S.tail;
+        dbg.err[5] = *(volatile const int *)&S.avail; dbg.err[6] = *(volatile const int *)&S.active;
+        dbg.err[7] = (int)(threadIdx.x >> 6);
+        __threadfence_system();
+    }
+}
+
+__device__ __forceinline__ int share_pop(ShareLds &S, int lane, const ShareDbg &dbg)
 {
     int t = 0;
     if (lane == 0) t = atomicSub(&S.avail, 1);
@@ -358,29 +388,54 @@ __device__ __forceinline__ int share_pop(ShareLds &S, int lane)
     int i = 0;
     if (lane == 0) i = atomicAdd(&S.head, 1);
     i = __builtin_amdgcn_readfirstlane(i);
-    volatile int *slot = &S.ring[i & (kRing - 1)];
-    int v;
-    do { v = __builtin_amdgcn_readfirstlane(*slot); } while (v == kRingEmpty);      // the push that owns this ticket is completing
+    volatile int *slot = &S.ring[i & S.mask];
+    int v = __builtin_amdgcn_readfirstlane(*slot);
+    for (int spins = 0; v == kRingEmpty; ++spins) {               // the push that owns this ticket is completing
+        if (spins >= S.spins) {                                  // ... or was lost: give the ticket up (the walk misses a subtree: reported)
+            if (lane == 0) share_report(dbg, kShareErrPop, i, S);
+            return kRingEmpty;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        v = __builtin_amdgcn_readfirstlane(*slot);
+    }
     if (lane == 0) *slot = kRingEmpty;
     return v;
 }
-__device__ __forceinline__ void share_push(ShareLds &S, int lane, int node)
+// true: the node is in the queue; false: it is not (the caller keeps it on its own stack - nothing is lost)
+__device__ __forceinline__ bool share_push(ShareLds &S, int lane, int node, const ShareDbg &dbg)
 {
+    int ok = 1;
     if (lane == 0) {
         const int i = atomicAdd(&S.tail, 1);
-        while (atomicCAS(&S.ring[i & (kRing - 1)], kRingEmpty, node) != kRingEmpty) {}     // (a full turn of the ring behind: never in practice)
-        atomicAdd(&S.avail, 1);
+        if (i == S.lose) {                                       // test only: the hand-over a popper will wait for in vain
+            atomicAdd(&S.avail, 1);
+        } else {
+            int spins = 0;
+            while (atomicCAS(&S.ring[i & S.mask], kRingEmpty, node) != kRingEmpty) {      // the popper a full turn behind has not cleared its slot yet
+                if (++spins >= S.spins) { ok = 0; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (ok) atomicAdd(&S.avail, 1);
+            else share_report(dbg, kShareErrPush, i, S);         // the ticket stays unfilled: its popper reports and gives up as well
+        }
     }
+    return __builtin_amdgcn_readfirstlane(ok) != 0;
 }
 
 template <int NW>
-__device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool live, int *wstack, char *smem /* share_lds_bytes(NW) */, int center_lane)
+__device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool live, int *wstack, char *smem /* share_lds_bytes(NW) */, int center_lane,
+                                                  const ShareDbg &dbg)
 {
     ShareLds &S = *reinterpret_cast<ShareLds *>(smem);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();                                             // (the previous packet's keys have been read)
     if (threadIdx.x < 64) { S.thr[lane] = 0x7f800000u; S.ring[lane] = lane == 0 ? mesh_root(m) : kRingEmpty; }
-    if (threadIdx.x == 0) { S.head = 0; S.tail = 1; S.avail = 1; S.active = NW; }
+    if (threadIdx.x == 0) {
+        S.head = 0; S.tail = 1; S.avail = 1; S.active = NW;
+        S.mask = (dbg.ring >= 2 && dbg.ring <= kRing ? dbg.ring : kRing) - 1;
+        S.lose = dbg.lose > 0 ? dbg.lose : -1;
+        S.spins = 1 << (dbg.spin_log2 > 0 && dbg.spin_log2 < 30 ? dbg.spin_log2 : kShareSpinLog2);
+    }
     __syncthreads();
     unsigned long long key = 0x7f8000007fffffffull;
     float thr = live ? INFINITY : -INFINITY;
@@ -389,7 +444,7 @@ __device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool l
         int cur;
         if (sp > 0) cur = __builtin_amdgcn_readfirstlane(wstack[--sp]);
         else {
-            cur = share_pop(S, lane);
+            cur = share_pop(S, lane, dbg);
             if (cur == kRingEmpty) {                             // nothing to take: idle until an entry appears or every wave is idle
                 if (lane == 0) atomicSub(&S.active, 1);
                 int spins = 0;
@@ -398,11 +453,14 @@ __device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool l
                     const int ac = __builtin_amdgcn_readfirstlane(*(volatile int *)&S.active);
                     if (av > 0) {
                         if (lane == 0) atomicAdd(&S.active, 1);
-                        cur = share_pop(S, lane);
+                        cur = share_pop(S, lane, dbg);
                         if (cur != kRingEmpty) break;
                         if (lane == 0) atomicSub(&S.active, 1);
                     } else if (ac <= 0) break;
-                    if (++spins > (1 << 16)) break;              // (never: ~10 ms; leaving early costs parallelism, not correctness)
+                    // leaving early costs parallelism, not correctness: an idle wave holds no work.  A single walk is ~1 ms at most,
+                    // so an idle wave that outlasts the bound has seen a workgroup that stopped making progress: reported
+                    // (not scaled by the test switch: with a wait bound of a few hundred polls an idle wave legitimately outlasts it)
+                    if (++spins > (4 << kShareSpinLog2)) { if (lane == 0) share_report(dbg, kShareErrIdle, spins, S); break; }
                     __builtin_amdgcn_s_sleep(2);
                 }
                 if (cur == kRingEmpty) break;
@@ -440,7 +498,7 @@ __device__ __forceinline__ Nearest nearest_shared(const MeshDev &m, f3 p, bool l
                 const bool first0 = e0 <= e1;
                 const int far = first0 ? c1 : c0;
                 const int av = __builtin_amdgcn_readfirstlane(*(volatile int *)&S.avail);
-                if (av < NW) share_push(S, lane, far); else wstack[sp++] = far;
+                if (av >= NW || !share_push(S, lane, far, dbg)) wstack[sp++] = far;
                 cur = first0 ? c0 : c1;
             } else if (v0) cur = c0;
             else if (v1) cur = c1;
@@ -948,6 +1006,70 @@ __device__ __forceinline__ bool lattice_point(const LatticeMap &L, int &ix, int 
 {
     return lattice_point_at(L, (int)blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, ix, iy, iz);
 }
+// The per-packet set-up of the throughput launch (k_nearest<LATTICE>, 4^3 packets, default block order), precomputed ONCE per call.
+// Round 4 moved the trim into the kernel (the body's box is known on the device only): every one of the 262,144 packets of a
+// 257^3 call then re-derived the trimmed tiling from MeshDyn and decoded its tile with six integer divisions by run-time values
+// - the ISA has no integer division, each is a ~25-instruction float-reciprocal sequence on the VECTOR unit even for wave-uniform
+// operands - plus three per-lane ones by the run-time packet size: ~350 instructions per packet, 6 % of a kernel that is VALU-
+// issue-bound, and 82 more than round 3 (profiles/r04_pmc_lds.txt: +1.5 % SQ_INSTS_VALU, +4.1 % cycles).  Now the first thread
+// of the row-crossings kernel - which runs before the search on the same stream anyway - writes this record (the trimmed region,
+// the tile counts and multiply-high reciprocals of the two divisors), and a packet's set-up is one s_load_dwordx16, three
+// s_mul_hi_u32 and shifts.
+struct LatticeFast {
+    int32_t sx0, sy0, sz0, sx1, sy1, sz1;     // the trimmed search region (lattice_trim), z relative to the slab
+    int32_t tx, tz, txtz, nb;                 // tiles per x-row, tile planes, tx * tz, tiles of the region
+    uint32_t m_tx, m_txtz;                    // udiv_magic of tx and tx * tz
+    int32_t pad[4];
+};
+static_assert(sizeof(LatticeFast) == 64, "LatticeFast layout");
+// floor(n / d) for 32-bit n as one multiply-high: m = floor(2^32 / d) undershoots n / d by less than n / 2^32 < 1, i.e. the
+// quotient is right or one too small - one compare-and-increment repairs it for EVERY n (no range assumption, no branch);
+// d == 1: m = 2^32 - 1 gives n - 1, repaired the same way.
+__host__ __device__ inline uint32_t udiv_magic(uint32_t d) { return d > 1 ? (uint32_t)(0x100000000ull / d) : 0xffffffffu; }
+__device__ __forceinline__ uint32_t udiv_fast(uint32_t n, uint32_t d, uint32_t m)
+{
+    const uint32_t q = __umulhi(n, m);
+    return q + ((n - q * d >= d) ? 1u : 0u);
+}
+__device__ __forceinline__ void lattice_fast_write(LatticeFast *out, LatticeMap L, const MeshDev &m)
+{
+    L = lattice_trim(L, m);
+    LatticeFast F;
+    F.sx0 = L.sx0; F.sy0 = L.sy0; F.sz0 = L.sz0; F.sx1 = L.sx1; F.sy1 = L.sy1; F.sz1 = L.sz1;
+    F.tx = L.tx; F.tz = L.tz; F.txtz = L.tx * L.tz; F.nb = L.tx * L.ty * L.tz;
+    F.m_tx = udiv_magic((uint32_t)max(L.tx, 1)); F.m_txtz = udiv_magic((uint32_t)max(L.tx * L.tz, 1));
+    F.pad[0] = F.pad[1] = F.pad[2] = F.pad[3] = 0;
+    *out = F;
+}
+// the packet of workgroup t / wave / lane under the record: the same point lattice_point_at(lattice_trim(L), ...) names for
+// pk = 4, remap = 0 (test_lattice_fast_setup_names_the_same_points runs both over whole tilings)
+__device__ __forceinline__ LatticeFast lattice_fast_load(const LatticeFast *lf)
+{
+    typedef __attribute__((address_space(4))) const int32_t *cint;
+    const cint q = (cint)(uintptr_t)lf;                          // wave-uniform constant-address loads: merged into wide s_loads
+    LatticeFast F;
+    F.sx0 = q[0]; F.sy0 = q[1]; F.sz0 = q[2]; F.sx1 = q[3]; F.sy1 = q[4]; F.sz1 = q[5];
+    F.tx = q[6]; F.tz = q[7]; F.txtz = q[8]; F.nb = q[9];
+    F.m_tx = (uint32_t)q[10]; F.m_txtz = (uint32_t)q[11];
+    return F;
+}
+__device__ __forceinline__ bool lattice_point_fast(const LatticeFast &F, uint32_t t, int wave, int lane, int &cx, int &cy, int &cz)
+{
+    const uint32_t tx = (uint32_t)F.tx, tz = (uint32_t)F.tz, txtz = (uint32_t)F.txtz;      // scalar registers, scalar arithmetic
+    const uint32_t bty = udiv_fast(t, txtz, F.m_txtz);
+    const uint32_t rem = t - bty * txtz;
+    const uint32_t btz = udiv_fast(rem, tx, F.m_tx);
+    uint32_t btx = rem - btz * tx;
+    const uint32_t rot = btz + bty * tz;                          // x-position rotated by the row number (lattice_point_at)
+    btx += rot - udiv_fast(rot, tx, F.m_tx) * tx;
+    btx = min(btx, btx - tx);                                     // (unsigned: btx - tx wraps unless btx >= tx)
+    const int ix = F.sx0 + (int)(btx * 16u) + wave * 4 + (lane & 3);
+    const int iy = F.sy0 + (int)(bty * 4u) + ((lane >> 2) & 3);
+    const int iz = F.sz0 + (int)(btz * 4u) + (lane >> 4);
+    cx = min(ix, F.sx1 - 1); cy = min(iy, F.sy1 - 1); cz = min(iz, F.sz1 - 1);      // (lattice_clamp)
+    return ix < F.sx1 && iy < F.sy1 && iz < F.sz1;
+}
+
 // the lane whose box distances order the two children of a node: the block's centre (4^3), its first point otherwise
 __device__ __forceinline__ int packet_center_lane(const LatticeMap &L) { return (L.pk == 0 || L.pk == 4) ? 21 : 0; }
 
@@ -1037,10 +1159,22 @@ __device__ __forceinline__ uint32_t sign_code(f3 p, float d2, bool ins, float sd
 // sign_code makes) and flags it in the slot word; d^2 itself is only stored for the ~6 % of points inside the band,
 // the only ones whose consumers read it: ~90 MB less HBM traffic per 257^3 step.
 constexpr uint32_t kNearFar = 0x8000u;
+__device__ __forceinline__ bool near_far_exact(float d2, float sdf_clip)
+{
+    const float dist = sqrtf(d2) / sqrtf(3.0f);
+    return dist >= sdf_clip && dist > 0.0f;                 // dist == 0 (sign 0) stays on the general path
+}
 __device__ __forceinline__ void store_near(const NearRef &r, int64_t i, const Nearest &nr, float sdf_clip)
 {
-    const float dist = sqrtf(nr.d2) / sqrtf(3.0f);
-    const bool far = dist >= sdf_clip && dist > 0.0f;       // dist == 0 (sign 0) stays on the general path
+    // `far` must be the very comparison sign_code makes on sqrt(d^2) / sqrt(3) (IEEE sqrt + division: ~45 instructions per
+    // lane).  d^2 beyond 3 clip^2 (1 +- 1e-4) decides it without them - the two roundings move the quotient by 2e-7 relative -
+    // and only a wave that holds a point INSIDE that sliver (or a clip that is not an ordinary positive number) evaluates the
+    // exact form: a wave-uniform branch that is almost never taken.
+    const float c2 = sdf_clip * sdf_clip * 3.0f;
+    const bool ordinary = sdf_clip > 1e-12f && sdf_clip < 1e12f;
+    const bool surely_far = nr.d2 > c2 * 1.0001f, surely_near = nr.d2 < c2 * 0.9999f;
+    bool far = surely_far;
+    if (__any(!ordinary || !(surely_far || surely_near))) far = near_far_exact(nr.d2, sdf_clip);
     r.lo[i] = (uint16_t)(((uint32_t)nr.slot & 0x7fffu) | (far ? kNearFar : 0u));
     if (r.hi) r.hi[i] = (uint8_t)((uint32_t)nr.slot >> 15);   // wave-uniform: meshes with more than 32,768 slots only
     if (!far) r.d2[i] = nr.d2;

@@ -90,16 +90,23 @@ __global__ __launch_bounds__(kCoopWaves * 64) void k_sdf_query_coop(MeshDev m, c
 template <bool LATTICE, bool ALT = false>
 __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, LatticeMap L, const float *__restrict__ pts, int64_t N,
                                                     NearRef near, const int32_t *__restrict__ perm,
-                                                    float sdf_clip, int tie_ulps)
+                                                    float sdf_clip, int tie_ulps, const LatticeFast *lf)
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
     if (LATTICE) {
-        L = lattice_trim(L, m);
-        if ((int)blockIdx.x >= L.tx * L.ty * L.tz) return;       // beyond the trimmed tiling (the host tiled the whole slab)
-        int ix, iy, iz, cx, cy, cz;
-        live = lattice_point(L, ix, iy, iz);
-        lattice_clamp(L, ix, iy, iz, cx, cy, cz);
+        int cx, cy, cz;
+        if (lf) {                                                // 4^3 packets, default block order: the set-up precomputed per call
+            const LatticeFast F = lattice_fast_load(lf);
+            if ((int)blockIdx.x >= F.nb) return;                 // beyond the trimmed tiling (the host tiled the whole slab)
+            live = lattice_point_fast(F, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, cx, cy, cz);
+        } else {
+            L = lattice_trim(L, m);
+            if ((int)blockIdx.x >= L.tx * L.ty * L.tz) return;
+            int ix, iy, iz;
+            live = lattice_point(L, ix, iy, iz);
+            lattice_clamp(L, ix, iy, iz, cx, cy, cz);
+        }
         p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
     } else {
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
 // shared by the NW wavefronts (nearest_shared) - such a launch lasts as long as its longest walk, and this divides the walk.
 // Workgroup b serves packet b & 3 of tile b >> 2 of k_nearest's tiling.
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_nearest_shared(MeshDev m, LatticeMap L, NearRef near, float sdf_clip)
+__global__ __launch_bounds__(NW * 64) void k_nearest_shared(MeshDev m, LatticeMap L, NearRef near, float sdf_clip, ShareDbg dbg)
 {
     __shared__ int lds[NW * kStackDepth];
     __shared__ __attribute__((aligned(16))) char smem[share_lds_bytes(NW)];
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(NW * 64) void k_nearest_shared(MeshDev m, LatticeMa
     const bool live = lattice_point_at(L, (int)(blockIdx.x >> 2), (int)(blockIdx.x & 3), threadIdx.x & 63, ix, iy, iz);
     lattice_clamp(L, ix, iy, iz, cx, cy, cz);
     const f3 p = lattice_world(L.res, cx, cy, cz + L.z0);
-    const Nearest nr = nearest_shared<NW>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, smem, packet_center_lane(L));
+    const Nearest nr = nearest_shared<NW>(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, smem, packet_center_lane(L), dbg);
     if (live && threadIdx.x < 64) store_near(near, ((int64_t)cz * L.res + cy) * L.res + cx, nr, sdf_clip);
 }
 
@@ -291,8 +298,9 @@ __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMa
 }
 
 // one thread per (y, z) row of the slab: triangles whose (y,z) projection covers the row
-__global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots)
+__global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots, LatticeFast *lf)
 {
+    if (lf && blockIdx.x == 0 && threadIdx.x == 0) lattice_fast_write(lf, L, m);      // the search's per-packet set-up, once per call
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (int64_t)L.nz * L.res) return;
     const int iy = (int)(row % L.res), iz = (int)(row / L.res);
@@ -346,8 +354,9 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_count(const uint8_t *__r
 // The same with 16 lanes per row (slabs of few rows - the coarse lattices: 33^2 = 1,089 threads walking ~100-entry bin lists one
 // after the other were a 28 us launch of pure latency): the lanes of a group take every 16th entry of the bin list, the hits are
 // appended in list order through a ballot (the same row_slots as the one-thread version, entry for entry).
-__global__ __launch_bounds__(kBlock) void k_row_crossings_wide(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots)
+__global__ __launch_bounds__(kBlock) void k_row_crossings_wide(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots, LatticeFast *lf)
 {
+    if (lf && blockIdx.x == 0 && threadIdx.x == 0) lattice_fast_write(lf, L, m);
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
     const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
     const bool have = row < (int64_t)L.nz * L.res;
@@ -688,7 +697,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
 {
     if (!w) return ICON_OK;
     (void)hipFree(w->d_x); (void)hipFree(w->d_grp_mask); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
-    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_flag); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
+    (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_flag); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_lfast); if (w->h_err) (void)hipHostFree(w->h_err); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
     icon::mc_destroy(w->mc);
@@ -749,6 +758,48 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_patch_self(float *__rest
 }
 }  // namespace icon
 
+namespace icon {
+// ---- shared walks: error record and test switches ------------------------------------------------------------------------
+int g_share_ring = 0, g_share_lose = 0, g_share_spin_log2 = 0;     // icon_debug_set_option; all zero in production
+int g_lattice_fast = -1;                                          // -1: read ICON_AMD_LATTICE_FAST once (default on)
+int g_share_waves = -2;                                           // -2: read ICON_AMD_SHARE once; -1: by launch size; 1 / 4 / 8 / 16: forced
+int share_waves_override()
+{
+    if (g_share_waves == -2) g_share_waves = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;
+    return g_share_waves;
+}
+
+int work_share_dbg(icon_work *w, ShareDbg *out)
+{
+    if (!w->h_err) {
+        ICON_HIP(hipHostMalloc((void **)&w->h_err, 8 * sizeof(int), hipHostMallocMapped));
+        memset(w->h_err, 0, 8 * sizeof(int));
+    }
+    void *dev = nullptr;
+    ICON_HIP(hipHostGetDevicePointer(&dev, w->h_err, 0));
+    out->err = (int *)dev;
+    out->ring = g_share_ring; out->lose = g_share_lose; out->spin_log2 = g_share_spin_log2;
+    return ICON_OK;
+}
+
+int work_check_err(icon_work *w)
+{
+    if (!w || !w->h_err) return ICON_OK;
+    volatile int *e = w->h_err;
+    const int code = e[0];
+    if (code == 0) return ICON_OK;
+    char buf[320];
+    static const char *what[] = {"", "a wave waited in vain for the node of its queue ticket (lost or abandoned push)",
+                                 "a wave waited in vain for its ring slot to be cleared (ring a full turn behind)",
+                                 "an idle wave outlasted its bound while the workgroup was still active"};
+    snprintf(buf, sizeof(buf), "shared-walk search: %s [code %d, workgroup %d, wave %d, ticket %d, head %d, tail %d, avail %d, active %d]; the results of "
+             "that launch are not to be trusted", what[code >= 1 && code <= 3 ? code : 0], code, e[1], e[7], e[2], e[3], e[4], e[5], e[6]);
+    for (int k = 0; k < 8; ++k) e[k] = 0;
+    return fail(ICON_ERR_STATE, buf);
+}
+
+}  // namespace icon
+
 namespace {
 
 inline void mark(icon_work *w, int k, hipStream_t st)
@@ -760,6 +811,7 @@ inline void mark(icon_work *w, int k, hipStream_t st)
 // for the paths that still materialise them (need_x: precision f32 and the brute-force search)
 int ensure_work(icon_work *w, int64_t n_points, bool need_x)
 {
+    { const int rc = work_check_err(w); if (rc) return rc; }      // an earlier launch on this workspace reported: no new work on its results
     if (n_points > w->cap_points) {
         (void)hipFree(w->d_near16); (void)hipFree(w->d_near_d2); w->d_near16 = nullptr; w->d_near_d2 = nullptr; w->cap_points = 0;
         ICON_HIP(hipMalloc((void **)&w->d_near16, (size_t)n_points * sizeof(uint16_t)));
@@ -822,6 +874,7 @@ template <bool LATTICE>
 int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &L, const float *d_points, int64_t N, float sdf_clip,
                    icon_work *work, hipStream_t st)
 {
+    LatticeFast *lf = nullptr;
     if (LATTICE) {
         const int64_t rows = (int64_t)L.nz * L.res;
         if (rows > work->cap_rows) {
@@ -831,12 +884,18 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
             ICON_HIP(hipMalloc((void **)&work->d_row_slots, (size_t)rows * kRowCap * sizeof(int32_t)));
             work->cap_rows = rows;
         }
+        // the record of the search's per-packet set-up (LatticeFast): 4^3 packets in the default block order only
+        if (g_lattice_fast < 0) g_lattice_fast = getenv("ICON_AMD_LATTICE_FAST") ? (atoi(getenv("ICON_AMD_LATTICE_FAST")) != 0) : 1;   // 0: every packet derives its own (A/B runs)
+        if (g_lattice_fast && (L.pk == 0 || L.pk == 4) && L.remap == 0) {
+            if (!work->d_lfast) ICON_HIP(hipMalloc((void **)&work->d_lfast, sizeof(LatticeFast)));
+            lf = work->d_lfast;
+        }
         if (rows <= 20000)                       // up to 129^2 rows: 16 lanes per row
             hipLaunchKernelGGL(k_row_crossings_wide, dim3((unsigned)((rows * 16 + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
-                               work->d_row_count, work->d_row_slots);
+                               work->d_row_count, work->d_row_slots, lf);
         else
             hipLaunchKernelGGL(k_row_crossings, dim3((unsigned)((rows + kBlock - 1) / kBlock)), dim3(kBlock), 0, st, mesh->dev, L,
-                               work->d_row_count, work->d_row_slots);
+                               work->d_row_count, work->d_row_slots, lf);
     }
     int64_t nb;
     if (LATTICE) nb = (int64_t)L.tx * L.ty * L.tz; else nb = (N + kBlock - 1) / kBlock;
@@ -861,12 +920,14 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
             const int rc = morton_order(work, d_points, cal.m, cal.d, N, st, &perm);
             if (rc) return rc;
         }
-        static const int share_env = getenv("ICON_AMD_SHARE") ? atoi(getenv("ICON_AMD_SHARE")) : -1;      // diagnostics: 1 = never, 8 / 16
+        const int share_env = share_waves_override();            // diagnostics: 1 = never, 8 / 16
         const int nw = (!LATTICE || alt) ? 1 : ((share_env == 1 || share_env == 8 || share_env == 16) ? share_env : share_waves(nb * 4));
-        if (nw == 16) hipLaunchKernelGGL(k_nearest_shared<16>, dim3((unsigned)nb * 4), dim3(16 * 64), 0, st, mesh->dev, L, near, sdf_clip);
-        else if (nw == 8) hipLaunchKernelGGL(k_nearest_shared<8>, dim3((unsigned)nb * 4), dim3(8 * 64), 0, st, mesh->dev, L, near, sdf_clip);
-        else if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps);
-        else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0);
+        ShareDbg dbg{};
+        if (nw > 1) { const int rc = work_share_dbg(work, &dbg); if (rc) return rc; }
+        if (nw == 16) hipLaunchKernelGGL(k_nearest_shared<16>, dim3((unsigned)nb * 4), dim3(16 * 64), 0, st, mesh->dev, L, near, sdf_clip, dbg);
+        else if (nw == 8) hipLaunchKernelGGL(k_nearest_shared<8>, dim3((unsigned)nb * 4), dim3(8 * 64), 0, st, mesh->dev, L, near, sdf_clip, dbg);
+        else if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps, lf);
+        else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0, lf);
     }
     ICON_HIP(hipGetLastError());
     debug_sync(LATTICE ? "k_row_crossings + k_nearest<lattice>" : "nearest (points)", st);
@@ -1336,6 +1397,31 @@ extern "C" int icon_grid_eval_slab(const icon_mesh_t *mesh, const icon_feat_t *f
     // the slab's own sign list is the whole list (single call == whole lattice or caller's choice)
     work->slab_ready = false;
     return phase2(mlp, self_signs(work), d_occ, precision, work, (hipStream_t)stream, z0, z1);
+}
+
+// the shared walks' error record (see work_check_err): ICON_ERR_STATE once per reported error, then clear again.  Does not
+// synchronise - a caller that wants the verdict on a particular launch synchronises its stream first.
+extern "C" int icon_work_status(icon_work_t *work)
+{
+    ICON_ARG(work != nullptr, "icon_work_status: work is null");
+    return work_check_err(work);
+}
+
+// test / A-B switches by name (process-wide): "lattice_fast" 0 / 1; "share_waves" wavefronts per shared walk (-1 = by launch size;
+// 4: the adaptive schedule's searches only); "share_ring" forced ring size of the shared walks (0 = 64),
+// "share_lose_push" the ticket of the push that is announced but never stored (0 = none), "share_spin_log2" wait bound 2^n polls
+// (0 = 2^18).  Production leaves all of them alone.
+extern "C" int icon_debug_set_option(const char *key, int value)
+{
+    ICON_ARG(key != nullptr, "icon_debug_set_option: key is null");
+    const std::string k(key);
+    if (k == "lattice_fast") g_lattice_fast = value ? 1 : 0;
+    else if (k == "share_waves") { ICON_ARG(value == -1 || value == 1 || value == 4 || value == 8 || value == 16, "share_waves: -1 (by launch size), 1, 4, 8 or 16"); g_share_waves = value; }
+    else if (k == "share_ring") { ICON_ARG(value == 0 || (value >= 2 && value <= 64 && (value & (value - 1)) == 0), "share_ring: 0 or a power of two in 2..64"); g_share_ring = value; }
+    else if (k == "share_lose_push") { ICON_ARG(value >= 0, "share_lose_push: a ticket >= 1, or 0"); g_share_lose = value; }
+    else if (k == "share_spin_log2") { ICON_ARG(value >= 0 && value < 30, "share_spin_log2: 0..29"); g_share_spin_log2 = value; }
+    else return fail(ICON_ERR_ARG, "icon_debug_set_option: unknown key " + k);
+    return ICON_OK;
 }
 
 extern "C" int icon_debug_set_shell_skip(int on)

@@ -291,6 +291,11 @@ class Workspace(_Handle):
     def set_tie_rule(self, rule: int, ulps: int = 0) -> None:
         check(_lib.lib().icon_work_set_tie_rule(self.h, C.c_int(rule), C.c_int(ulps)), "icon_work_set_tie_rule")
 
+    def status(self) -> None:
+        """Raise IconAmdError if a shared-walk search launched on this workspace gave up on a hand-over (icon_work_status: a
+        host read of the workspace's error record, no synchronisation - synchronise first for the verdict on a given launch)."""
+        check(_lib.lib().icon_work_status(self.h), "icon_work_status")
+
     def set_reserve_cus(self, n: int) -> None:
         """leave ``n`` CUs free of the persistent MLP kernel (for the RCCL kernels of an overlapped all_gather)"""
         check(_lib.lib().icon_work_set_reserve_cus(self.h, C.c_int(int(n))), "icon_work_set_reserve_cus")
@@ -458,11 +463,29 @@ class IconQueryEngine:
         ts = (d["smpl_verts"], d["smpl_faces"], d["smpl_cmap"], d["smpl_vis"])
         k = _key(*ts)
         if k != self._mesh_key:
+            old = getattr(self, "_mesh", None)
+            if old is not None and not old.checked and old.h:
+                # apps bind new SMPL tensors per image and may issue ONE asynchronous call per mesh: a mesh nobody polled must not
+                # be dropped unseen (the device build makes bad input harmless - vertex 0, coordinate 0 - and a plausible but wrong
+                # volume would be all the caller ever gets).  Its work was enqueued a whole image ago: this wait is over.
+                try:
+                    old.status(wait=True)
+                except IconAmdError as e:
+                    self._mesh, self._mesh_key, self._mesh_src = None, None, None
+                    raise IconAmdError(f"the PREVIOUS SMPL mesh bound to this engine was invalid (its results are wrong): {e}") from e
             self._mesh = MeshHandle(*ts, validate=False)
             self._mesh_key, self._mesh_src = k, ts      # strong refs: see _key
         elif not self._mesh.checked:
             self._mesh.status()                         # a host read of a pinned word: raises once the build has reported bad input
         return self._mesh
+
+    def poll_mesh_status(self, wait: bool = False) -> None:
+        """Raise if the device build of the bound mesh has reported bad input (face naming a missing vertex, non-finite
+        coordinate).  A host read of a pinned word - callers invoke it wherever they have just synchronised (the counts of
+        adaptive_eval, the None test of reconEngine.forward, marching cubes), so every mesh is checked by the end of ITS image."""
+        m = getattr(self, "_mesh", None)
+        if m is not None and not m.checked and m.h:
+            m.status(wait)
 
     def mesh_z_range(self):
         """(z_min, z_max) of the bound SMPL vertices in world coordinates (one D2H read per mesh, cached):
@@ -790,6 +813,7 @@ class IconQueryEngine:
             "icon_adaptive_eval")
         if not counts:
             return out, None, None
+        self.poll_mesh_status()                         # (the call has synchronised for the counts: the mesh build has reported)
         return out, [int(hc[k]) for k in range(n)], bool(hc[n])
 
     @_guarded

@@ -196,7 +196,10 @@ class DenseReconEngine(nn.Module):
             occ = be.eval_slab(im_feat, res, 0, res)
         else:
             occ = self._forward_sharded(be, im_feat, res, dist, world, rank)
-        return self._none_if_empty(occ)
+        occ = self._none_if_empty(occ)               # (reads a count back: the stream is idle after it)
+        if hasattr(be, "poll_mesh_status"):
+            be.poll_mesh_status()                    # ... so the device mesh build has reported: bad SMPL input raises HERE, not one image late
+        return occ
 
     def forward_mesh(self, **kwargs):
         """``export_mesh(forward(**kwargs))`` in one step - on one rank exactly that; SHARDED (one image over N GPUs) the ranks
@@ -673,6 +676,13 @@ class AdaptiveReconEngine(DenseReconEngine):
     the queries go through ``query_func`` -> ``IconQueryEngine.query`` (HIP).
     """
 
+    def forward_mesh(self, **kwargs):
+        """``export_mesh(self.forward(**kwargs))`` - the mesh of THIS class's coarse-to-fine volume on every rank.  (The inherited
+        form would take the sharded dense route when world > 1: another field - evaluated everywhere instead of interpolated at
+        the last level - at ~100x the points.  The schedule is a per-image job of well under a millisecond: nothing to shard.)"""
+        occ = self.forward(**kwargs)
+        return None if occ is None else self.export_mesh(occ)
+
     def forward(self, **kwargs):
         import torch.nn.functional as F
         if self.query_func is None:
@@ -727,9 +737,13 @@ class AdaptiveReconEngine(DenseReconEngine):
                 vol, counts, any_pos = lattice_engine.adaptive_eval(im_feat, res_list, float(self.balance_value))
                 self.last_stats = dict(queries=[counts[0]] + [c for c in counts[1:-1] if c > 0], native=True)
                 return vol if any_pos else None
-            self.last_stats = dict(native_refused=why)
+            refused = why
+        else:
+            refused = None
         occupancys = done = None                     # done[z,y,x]: voxel already evaluated (the reference keeps a
-        self.last_stats = dict(queries=[])           # sorted coordinate list, coords_accum, for the same purpose)
+        self.last_stats = dict(queries=[], native=False)   # sorted coordinate list, coords_accum, for the same purpose)
+        if refused is not None:
+            self.last_stats["native_refused"] = refused     # why the one-call schedule did not run (bench.py / tests read it)
         for level, res in enumerate(res_list):
             stride = (last - 1) // (res - 1)
             if level == 0:

@@ -313,6 +313,20 @@ int icon_debug_host_mesh_build(const float *h_verts, int64_t V, const int64_t *h
  * order of operations) instead of skipping it; both give identical results.  Process-wide; default on
  * (or ICON_AMD_SHELL_SKIP=0 in the environment). */
 int icon_debug_set_shell_skip(int on);
+/* Test / A-B switches by name, process-wide; production leaves them alone.  "lattice_fast" (default 1): 0 makes every packet
+ * of the 257^3-class search derive its own tile set-up instead of reading the per-call record.  "share_waves" (-1 = by launch
+ * size): wavefronts that share one packet's walk, 1 / 8 / 16 (4: adaptive schedule only).  "share_ring" (0 = 64): forced
+ * ring size of the shared walks' hand-over queue; "share_lose_push" (0 = none): ticket of the push that is announced but never
+ * stored; "share_spin_log2" (0 = 18): the wait bound, 2^n polls - the torture / fault-injection tests of the error path below. */
+int icon_debug_set_option(const char *key, int value);
+/* The searches of coarse lattices and of the adaptive schedule share one packet's BVH walk between the wavefronts of a
+ * workgroup through an LDS queue (csrc/geom_device.h nearest_shared).  Every wait in that hand-over is bounded; a wave that
+ * gives a wait up records what it waited for in the workspace's host-mapped error record, the walk terminates, and the host
+ * reports it: ICON_ERR_STATE (message: code, workgroup, wave, ticket, queue counters) from icon_work_status - or from the
+ * next icon_query_points / icon_grid_* / icon_adaptive_* call on the workspace, and from icon_adaptive_eval (with h_counts) /
+ * icon_adaptive_counts for the schedule they have just synchronised on.  The record is cleared by the report.  Never
+ * synchronises: synchronise the stream first for the verdict on a particular launch. */
+int icon_work_status(icon_work_t *work);
 
 /* ---- tie sensitivity of the nearest-triangle choice ---------------------------------------------------
  * lib/dataset/mesh_util.py:374-390: the winner of kaolin's point_to_mesh_distance decides the triangle whose

@@ -1,0 +1,20 @@
+#!/bin/bash
+# Same-box A/B of the geometry pre-pass: the round-4 tree (build_ab/r04, made by `git archive 534525d | tar -x` + make) against
+# this tree with and without the per-call tile record (ICON_AMD_LATTICE_FAST); kernel times from rocprofv3, interleaved twice.
+#   usage: gpurun -- 'bash tools/ab_r05.sh <tag>'
+T=${1:-ab5}
+R=$PWD
+mkdir -p gpurun_out
+cd /tmp && export TMPDIR=/tmp
+run() {   # name, bench path, env...
+  n=$1; b=$2; shift 2
+  env "$@" timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_$n -- python $b --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_$n.log 2>&1
+  python $R/tools/rocprof_summary.py stats $(find $R/gpurun_out/${T}_$n -name "*.db" | head -1) > $R/gpurun_out/${T}_${n}_stats.csv
+  echo "== $n"; grep "k_nearest\|k_fused\|k_sign\|k_row" $R/gpurun_out/${T}_${n}_stats.csv | cut -c1-150
+  find $R/gpurun_out/${T}_$n -name "*.db" -delete
+}
+for rep in 1 2; do
+  run r04_$rep $R/build_ab/r04/bench.py A=1
+  run slow_$rep $R/bench.py ICON_AMD_LATTICE_FAST=0
+  run fast_$rep $R/bench.py ICON_AMD_LATTICE_FAST=1
+done

@@ -154,6 +154,39 @@ def section_h_adaptive_257():
     print("adaptive 257: queries per level", counts, "inside voxels", int((vol > 0.5).sum()))
 
 
+def section_k_adaptive_513():
+    """(k) the schedule of the SHIPPED default mcube_res=512 (configs/icon-filter.yaml:23; apps/ICON.py:62-72 builds
+    [33,65,129,257,513]) - Seg3dLossless, faster=True, run verbatim on the synthetic subject.  The 513^3 volume (540 MB) is
+    stored as subsets: the stride-8 sub-lattice, three orthogonal mid planes, 60,000 seeded random voxels and 60,000 seeded
+    voxels of the level-set band (0.1 < v < 0.9); plus the number of points the reference queried at every level."""
+    ref = ref_loader.load()
+    a = synth.make_assets("body")
+    netG, cfg = ref_loader.build_netG(a)
+    counts = []
+    orig = ref.query_func
+
+    def counting_query_func(opt, netG, features, points, proj_matrix=None):
+        counts.append(int(points.shape[1]))
+        return orig(opt, netG, features, points, proj_matrix)
+    res = [33, 65, 129, 257, 513]
+    with torch.no_grad():
+        eng = ref.Seg3dLossless(query_func=counting_query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+                                resolutions=res, align_corners=True, balance_value=0.5, faster=True)
+        vol = eng(opt=cfg, netG=netG, features=[T(a.features)], proj_matrix=None).numpy().astype(np.float32)
+    assert vol.shape == (513, 513, 513)
+    rng = np.random.RandomState(513)
+    idx = rng.randint(0, 513 ** 3, 60000).astype(np.int64)
+    flat = vol.reshape(-1)
+    band = np.flatnonzero((flat > 0.1) & (flat < 0.9))
+    band_idx = np.sort(rng.choice(band, 60000, replace=False)).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "seg3d_body_adaptive_513.npz"), resolutions=np.array(res), queries=np.array(counts),
+                        sub8=vol[::8, ::8, ::8], plane_z=vol[256], plane_y=vol[:, 256], plane_x=vol[:, :, 256],
+                        idx=idx, samples=flat[idx], band_idx=band_idx, band_samples=flat[band_idx],
+                        inside=np.int64((vol > 0.5).sum()), band=np.int64(band.size),
+                        vol_sum=np.float64(flat.astype(np.float64).sum()))
+    print("adaptive 513: queries per level", counts, "inside voxels", int((vol > 0.5).sum()), "band", band.size)
+
+
 def section_i_variants():
     """(i) the configurations outside configs/*.yaml that the reference's classes also build (tests/common.py VARIANTS): smpl_feats
     subsets with and without 'vis', norm_mlp 'weight' / 'group' / 'instance', last_op Sigmoid - the reference's own
@@ -265,13 +298,15 @@ def section_j_pamir_real_ve():
 
 
 if __name__ == "__main__":
-    only = [s for s in ("--display", "--adaptive257", "--variants", "--pamir-real") if s in sys.argv]
+    only = [s for s in ("--display", "--adaptive257", "--adaptive513", "--variants", "--pamir-real") if s in sys.argv]
     if not only:
         main()
     if not only or "--display" in only:
         section_g_display()
     if not only or "--adaptive257" in only:
         section_h_adaptive_257()
+    if not only or "--adaptive513" in only:
+        section_k_adaptive_513()
     if not only or "--variants" in only:
         section_i_variants()
     if not only or "--pamir-real" in only:
