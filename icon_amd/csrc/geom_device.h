@@ -257,14 +257,15 @@ __device__ __forceinline__ float prune_threshold(float best)
 template <bool STATS = false, bool TIES = false>
 __device__ __forceinline__ Nearest nearest_packet(const MeshDev &m, f3 p, bool live, int *wstack /* LDS, kStackDepth ints of this wave */,
                                                   int *n_nodes = nullptr, int *n_tris = nullptr, float thr0 = INFINITY,
-                                                  unsigned long long *runner_up = nullptr, int center_lane = 21)
+                                                  unsigned long long *runner_up = nullptr, int center_lane = 21,
+                                                  bool have_root = false, int root = 0)
 {
     Nearest nr; nr.d2 = INFINITY; nr.slot = 0; nr.face = 0x7fffffff;
     unsigned long long key = 0x7f8000007fffffffull;   // (+inf, INT_MAX)
     unsigned long long key2 = 0x7f8000007fffffffull;
     float thr = live ? thr0 : -INFINITY;
     int sp = 0;
-    int cur = mesh_root(m);
+    int cur = have_root ? root : mesh_root(m);        // (wave-uniform choice; the caller that holds the root in a register passes it)
     while (true) {
         if (cur < 0) {
             const int code = ~cur;
@@ -1019,9 +1020,14 @@ struct LatticeFast {
     int32_t sx0, sy0, sz0, sx1, sy1, sz1;     // the trimmed search region (lattice_trim), z relative to the slab
     int32_t tx, tz, txtz, nb;                 // tiles per x-row, tile planes, tx * tz, tiles of the region
     uint32_t m_tx, m_txtz;                    // udiv_magic of tx and tx * tz
-    int32_t pad[4];
+    int32_t root;                             // MeshDyn::root (saves the packet a dependent scalar load through m.dyn)
+    int32_t pad[3];
+    // followed by float coord[res]: lattice_world's x / z coordinate of index i (y = -coord[i], bit for bit: 2f - 1 and
+    // -2f + 1 round alike) - three IEEE divisions by res - 1 per lane (~45 instructions) become three cached loads
 };
 static_assert(sizeof(LatticeFast) == 64, "LatticeFast layout");
+constexpr int kLatticeFastMaxRes = 2048;      // (res^3 < 2^31 keeps res <= 1290)
+constexpr size_t kLatticeFastBytes = sizeof(LatticeFast) + kLatticeFastMaxRes * sizeof(float);
 // floor(n / d) for 32-bit n as one multiply-high: m = floor(2^32 / d) undershoots n / d by less than n / 2^32 < 1, i.e. the
 // quotient is right or one too small - one compare-and-increment repairs it for EVERY n (no range assumption, no branch);
 // d == 1: m = 2^32 - 1 gives n - 1, repaired the same way.
@@ -1038,8 +1044,22 @@ __device__ __forceinline__ void lattice_fast_write(LatticeFast *out, LatticeMap 
     F.sx0 = L.sx0; F.sy0 = L.sy0; F.sz0 = L.sz0; F.sx1 = L.sx1; F.sy1 = L.sy1; F.sz1 = L.sz1;
     F.tx = L.tx; F.tz = L.tz; F.txtz = L.tx * L.tz; F.nb = L.tx * L.ty * L.tz;
     F.m_tx = udiv_magic((uint32_t)max(L.tx, 1)); F.m_txtz = udiv_magic((uint32_t)max(L.tx * L.tz, 1));
-    F.pad[0] = F.pad[1] = F.pad[2] = F.pad[3] = 0;
+    F.root = m.dyn->root;
+    F.pad[0] = F.pad[1] = F.pad[2] = 0;
     *out = F;
+}
+// the coordinate table behind the record: thread i of the launch writes entry i (the launch has at least res threads)
+__device__ __forceinline__ void lattice_fast_coords(LatticeFast *out, int res, int64_t i)
+{
+    if (i < res) {
+        const float f = (float)(int)i / (float)(res - 1);
+        reinterpret_cast<float *>(out + 1)[i] = f * 2.0f + (-1.0f);       // lattice_world's expression for x and z
+    }
+}
+__device__ __forceinline__ f3 lattice_world_fast(const LatticeFast *lf, int ix, int iy, int iz)
+{
+    const float *c = reinterpret_cast<const float *>(lf + 1);
+    return mk3(c[ix], -c[iy], c[iz]);
 }
 // the packet of workgroup t / wave / lane under the record: the same point lattice_point_at(lattice_trim(L), ...) names for
 // pk = 4, remap = 0 (test_lattice_fast_setup_names_the_same_points runs both over whole tilings)
@@ -1050,7 +1070,7 @@ __device__ __forceinline__ LatticeFast lattice_fast_load(const LatticeFast *lf)
     LatticeFast F;
     F.sx0 = q[0]; F.sy0 = q[1]; F.sz0 = q[2]; F.sx1 = q[3]; F.sy1 = q[4]; F.sz1 = q[5];
     F.tx = q[6]; F.tz = q[7]; F.txtz = q[8]; F.nb = q[9];
-    F.m_tx = (uint32_t)q[10]; F.m_txtz = (uint32_t)q[11];
+    F.m_tx = (uint32_t)q[10]; F.m_txtz = (uint32_t)q[11]; F.root = q[12];
     return F;
 }
 __device__ __forceinline__ bool lattice_point_fast(const LatticeFast &F, uint32_t t, int wave, int lane, int &cx, int &cy, int &cz)

@@ -94,20 +94,24 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
 {
     __shared__ int lds[(kBlock / 64) * kStackDepth];
     int64_t i; bool live; f3 p;
+    int root = 0;
     if (LATTICE) {
         int cx, cy, cz;
         if (lf) {                                                // 4^3 packets, default block order: the set-up precomputed per call
             const LatticeFast F = lattice_fast_load(lf);
             if ((int)blockIdx.x >= F.nb) return;                 // beyond the trimmed tiling (the host tiled the whole slab)
             live = lattice_point_fast(F, blockIdx.x, threadIdx.x >> 6, threadIdx.x & 63, cx, cy, cz);
+            p = lattice_world_fast(lf, cx, cy, cz + L.z0);
+            root = F.root;
         } else {
             L = lattice_trim(L, m);
             if ((int)blockIdx.x >= L.tx * L.ty * L.tz) return;
             int ix, iy, iz;
             live = lattice_point(L, ix, iy, iz);
             lattice_clamp(L, ix, iy, iz, cx, cy, cz);
+            p = lattice_world(L.res, cx, cy, cz + L.z0);
+            root = mesh_root(m);
         }
-        p = lattice_world(L.res, cx, cy, cz + L.z0);
         i = ((int64_t)cz * L.res + cy) * L.res + cx;
     } else {
         i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -115,9 +119,10 @@ __global__ __launch_bounds__(kBlock) void k_nearest(MeshDev m, Calib cal, Lattic
         if (!live) i = N - 1;
         if (perm) i = perm[i];          // Morton order: the wave's 64 points are neighbours (sort_points.hip)
         p = project(resolve_calib(cal), mk3(pts[3 * i], pts[3 * i + 1], pts[3 * i + 2]));
+        root = mesh_root(m);
     }
     Nearest nr = nearest_packet(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, nullptr, nullptr, INFINITY, nullptr,
-                                LATTICE ? packet_center_lane(L) : 21);
+                                LATTICE ? packet_center_lane(L) : 21, true, root);
     if (ALT) nr = nearest_packet_alt(m, p, live, lds + (threadIdx.x >> 6) * kStackDepth, (uint32_t)__float_as_int(nr.d2), (uint32_t)tie_ulps);
     // (staging the 16 x 4 x 4 block through LDS so that 16 threads store one 64-byte run removes the partial-line
     //  writes but the block-wide barrier costs 0.14 ms; not kept)
@@ -301,6 +306,7 @@ __global__ __launch_bounds__(kBlock) void k_traversal_stats(MeshDev m, LatticeMa
 __global__ __launch_bounds__(kBlock) void k_row_crossings(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots, LatticeFast *lf)
 {
     if (lf && blockIdx.x == 0 && threadIdx.x == 0) lattice_fast_write(lf, L, m);      // the search's per-packet set-up, once per call
+    if (lf) lattice_fast_coords(lf, L.res, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     const int64_t row = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (row >= (int64_t)L.nz * L.res) return;
     const int iy = (int)(row % L.res), iz = (int)(row / L.res);
@@ -357,6 +363,7 @@ __global__ __launch_bounds__(kScanBlock) void k_outlier_count(const uint8_t *__r
 __global__ __launch_bounds__(kBlock) void k_row_crossings_wide(MeshDev m, LatticeMap L, int32_t *row_count, int32_t *row_slots, LatticeFast *lf)
 {
     if (lf && blockIdx.x == 0 && threadIdx.x == 0) lattice_fast_write(lf, L, m);
+    if (lf) lattice_fast_coords(lf, L.res, (int64_t)blockIdx.x * kBlock + threadIdx.x);
     const int lane = threadIdx.x & 63, g = lane >> 4, s = lane & 15;
     const int64_t row = ((int64_t)blockIdx.x * kBlock + threadIdx.x) >> 4;
     const bool have = row < (int64_t)L.nz * L.res;
@@ -886,8 +893,8 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
         }
         // the record of the search's per-packet set-up (LatticeFast): 4^3 packets in the default block order only
         if (g_lattice_fast < 0) g_lattice_fast = getenv("ICON_AMD_LATTICE_FAST") ? (atoi(getenv("ICON_AMD_LATTICE_FAST")) != 0) : 1;   // 0: every packet derives its own (A/B runs)
-        if (g_lattice_fast && (L.pk == 0 || L.pk == 4) && L.remap == 0) {
-            if (!work->d_lfast) ICON_HIP(hipMalloc((void **)&work->d_lfast, sizeof(LatticeFast)));
+        if (g_lattice_fast && (L.pk == 0 || L.pk == 4) && L.remap == 0 && L.res <= kLatticeFastMaxRes) {
+            if (!work->d_lfast) ICON_HIP(hipMalloc((void **)&work->d_lfast, kLatticeFastBytes));
             lf = work->d_lfast;
         }
         if (rows <= 20000)                       // up to 129^2 rows: 16 lanes per row

@@ -52,15 +52,23 @@ def edge_crossings(occ: np.ndarray, level: float = 0.5) -> np.ndarray:
 
 
 def same_point_set(a: np.ndarray, b: np.ndarray, tol: float = 1e-4) -> bool:
-    """both [N,3]; equal as sets up to ``tol`` (one-to-one nearest-neighbour matching both ways)"""
+    """both [N,3]; equal as (multi)sets up to ``tol``: the same number of points, every point of one has a partner in the other,
+    and the matching is one-to-one except among points that COINCIDE within ``tol`` in their own set (a lattice value exactly at
+    the level puts the crossings of up to six edges on the lattice point itself - a handful among the 1.4e8 values of a 513^3
+    volume - and the nearest-neighbour query may hand all of them the same partner)"""
     from scipy.spatial import cKDTree
     if len(a) != len(b):
         return False
     if len(a) == 0:
         return True
-    da, ia = cKDTree(b).query(a)
+    tb = cKDTree(b)
+    da, ia = tb.query(a)
     db, _ = cKDTree(a).query(b)
-    return bool(da.max() <= tol and db.max() <= tol and len(np.unique(ia)) == len(a))
+    if not (da.max() <= tol and db.max() <= tol):
+        return False
+    twins = tb.query_pairs(tol, output_type="ndarray")
+    n_twinned = len(np.unique(twins)) if len(twins) else 0
+    return bool(len(np.unique(ia)) >= len(a) - n_twinned)
 
 
 def topology(verts: np.ndarray, faces: np.ndarray, grid: int) -> dict:
