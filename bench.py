@@ -165,6 +165,73 @@ def parity_sample(assets, res, occ, cmap_mode, eng=None, n_each=12288, seed=1993
     return out
 
 
+def mesh_vs_oracle(assets, res, occ, cmap_mode, band=0.05):
+    """SURVEY.md section 8(d) metric (i): the mesh of the GPU volume against the mesh of the ORACLE's volume (float64 MLP),
+    Chamfer / P2S as lib/dataset/Evaluator.py:200-230 defines them (x100, [-1,1]-cube units).  Marching cubes reads a lattice
+    value only where it (a) ends a lattice edge whose end points lie on different sides of the level or (b) could change side:
+    the oracle is evaluated on exactly those voxels - every end point of a crossing edge of the GPU volume plus every voxel
+    within `band` of the level (500 x the parity tolerance) - and spliced into a copy of the GPU volume; every other value of
+    the two volumes is the same number and cannot move a vertex.  Both volumes then go through the same marching cubes."""
+    import numpy as np
+    import torch
+    from icon_amd import metrics, synth
+    from icon_amd.recon import export_mesh_device
+    from oracle import oracle as orc
+    t0 = time.perf_counter()
+    ins = occ > 0.5
+    need = (occ - 0.5).abs() < band
+    for ax in range(3):
+        a, b = [slice(None)] * 3, [slice(None)] * 3
+        a[ax], b[ax] = slice(0, -1), slice(1, None)
+        cross = ins[tuple(a)] != ins[tuple(b)]
+        need[tuple(a)] |= cross
+        need[tuple(b)] |= cross
+    idx = torch.nonzero(need.reshape(-1)).reshape(-1)
+    idx_h = idx.cpu().numpy().astype(np.int64)
+    ref, _ = orc.query_icon_subset(assets.smpl_verts[0], assets.smpl_faces[0], assets.smpl_cmap[0], assets.smpl_vis[0],
+                                   assets.features, orc.Mlp(assets.state_dict), synth.lattice_points(res), idx_h,
+                                   sdf_clip=assets.sdf_clip, f64=True, cmap_local=(cmap_mode == "local"))
+    t_oracle = time.perf_counter() - t0
+    occ_o = occ.clone()
+    occ_o.view(-1)[idx] = torch.from_numpy(ref).to(occ.device)
+    err = (occ_o.view(-1)[idx] - occ.reshape(-1)[idx]).abs()
+    vg, fg = export_mesh_device(occ, 0.5)
+    vo, fo = export_mesh_device(occ_o, 0.5)
+    ch, p2s = metrics.chamfer_p2s(metrics.to_unit_cube(vg, res), fg, metrics.to_unit_cube(vo, res), fo, n=100_000)
+    same_topology = bool(fg.shape == fo.shape and torch.equal(fg, fo))
+    vmax = float((vg - vo).abs().max().item()) if vg.shape == vo.shape else None
+    return {"chamfer_x100_dense_vs_oracle": ch, "p2s_x100_dense_vs_oracle": p2s, "tolerance_x100": 0.01, "within": bool(ch <= 0.01),
+            "oracle_voxels": int(len(idx_h)), "max_abs_on_them": float(err.max().item()),
+            "voxels_changing_side": int(((occ_o > 0.5) != ins).sum().item()), "faces_gpu": int(fg.shape[0]), "faces_oracle": int(fo.shape[0]),
+            "same_faces": same_topology, "max_vertex_move_voxels": vmax, "samples_per_mesh": 100_000,
+            "dense_vs_oracle_seconds": time.perf_counter() - t0, "oracle_seconds": t_oracle,
+            "dense_vs_oracle_note": "(i) oracle (oracle/icon_oracle.c, geometry on the whole lattice, float64 MLP) on every voxel marching cubes can see a "
+                    f"difference through: end points of crossing edges + |occ - 0.5| < {band}; spliced into the GPU volume; same marching cubes on both"}
+
+
+def mlp_zero_data(dev, n_points, launches=3):
+    """The instruction-stream invariant of the MLP chain: the standalone k_mlp_f16x3 kernel (the fused kernel's chunk bodies)
+    on all-zero rows with an all-zero checkpoint - no operand bit toggles in the matrix pipe, so the chip holds its clock
+    (9.7 ms where real data takes 13.8).  Moves only when the CODE or the box's maximum clock does."""
+    import numpy as np
+    import torch
+    from icon_amd import synth
+    from icon_amd.engine import MlpHandle
+    sd = synth.make_mlp_state_dict()
+    zero = {k: (np.ones_like(v) if k.endswith("running_var") else np.zeros_like(v)) for k, v in sd.items()}
+    mlp = MlpHandle({k: torch.from_numpy(v) for k, v in zero.items()})
+    x = torch.zeros((n_points, 16), device=dev)
+    mlp.forward(x, precision="f16x3")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(launches):
+        mlp.forward(x, precision="f16x3")
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / launches
+
+
 def tie_sensitivity(assets, res, occ, make_engine, step_with, ulps=1):
     """The same volume under the ALTERNATIVE tie rule (among the faces within `ulps` ulps of the minimum d^2 the
     highest index instead of the exact minimum / lowest index): how many lattice values, level-set voxels and how much
@@ -258,6 +325,8 @@ def main():
                     help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine "
                          "reserve_cus); -1 = the engine's default (16 over RCCL with the overlapped gather, else 0)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--full-extras", action="store_true",
+                    help="also run the whole-lattice CPU checker legs (parity sample, mesh vs oracle) above 257^3 (513^3: about a minute)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the post-timing legs (reference schedule, parity sample, mesh Chamfer): "
                          "use it under rocprofv3 so the trace holds only the dense step")
@@ -319,7 +388,7 @@ def main():
     eng = make_engine(args.precision)
     feats = [T(a.features)]
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
-                             resolutions=[33, 65, 129, res] if res == 257 else [res], align_corners=True,
+                             resolutions={257: [33, 65, 129, 257], 513: [33, 65, 129, 257, 513]}.get(res, [res]), align_corners=True,
                              balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
     opt = SimpleNamespace(num_views=1)
 
@@ -362,6 +431,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     stage /= max(args.steps, 1)
+    try:
+        detail = eng._work().profile_detail()          # of the LAST timed step: search kernel alone, cycles / effective clock of the MLP kernel
+    except Exception as ex:
+        detail = {"error": repr(ex)}
     eng._work().profile(False)
     if mesh_exchange:                                   # the step returned (verts, faces): what marching cubes on the volume gives
         assert occ is not None and occ[0].shape[1] == 3 and occ[1].shape[1] == 3 and occ[1].shape[0] > 0
@@ -412,21 +485,42 @@ def main():
         rank_stage = [{"rank": r, "planes": [int(v[0]), int(v[1])], "features_ms": float(v[2]), "cmap_patch_ms": float(v[3]),
                        "mlp_ms": float(v[4]), "step_ms": float(v[5])} for r, v in enumerate(allr)]
 
+    # what the process group actually is (the driver's "did RCCL see N ranks" check reads this): backend, the world size the
+    # group reports, every rank's device as IT sees it
+    dist_info = None
+    if world > 1:
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": local_dev, "device": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+        seen = [None] * world
+        dist.all_gather_object(seen, mine)
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:
+            rccl = None
+        dist_info = {"backend": dist.get_backend(), "world_size_seen": dist.get_world_size(), "rccl_version": rccl,
+                     "distinct_devices": len({(d["device_index"], d["uuid"]) for d in seen}), "ranks": seen}
     extras = {}
     sustained = None
+    zero_ms = None
     if not args.no_extras and world == 1 and rank == 0 and args.precision == "f16x3":
         try:
             sustained = library_gemm_ceiling(dev)
         except Exception as ex:
             sustained = {"error": repr(ex)}
+        try:
+            zero_ms = mlp_zero_data(dev, 257 ** 3)
+        except Exception as ex:
+            zero_ms = repr(ex)
     if not args.no_extras and world == 1 and rank == 0 and args.prior == "icon":
         from icon_amd.recon import AdaptiveReconEngine, export_mesh_device
         from icon_amd import metrics
         # (2) the reference's own coarse-to-fine schedule (Seg3dLossless._forward_faster, ~1 % of the lattice
         #     queried, last level interpolated) on the same engine: second baseline line + the "reference mesh"
-        if res == 257:
+        sched = {257: [33, 65, 129, 257], 513: [33, 65, 129, 257, 513]}.get(res)      # apps/ICON.py:62-72 for mcube_res 256 / 512
+        if sched:
             ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
-                                     resolutions=[33, 65, 129, res], align_corners=True).to(dev)
+                                     resolutions=sched, align_corners=True).to(dev)
             for _ in range(2):
                 vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
             ts = []
@@ -450,10 +544,17 @@ def main():
                                   "voxel_x100": 2.0 / (res - 1) * 100.0, "faces_dense": int(fd.shape[0]),
                                   "faces_reference_schedule": int(fa.shape[0]), "samples_per_mesh": 100_000,
                                   "seconds": time.perf_counter() - t1,
-                                  "note": "dense 257^3 field vs the reference's adaptive schedule (interpolated last level): "
+                                  "note": f"(ii) dense {res}^3 field vs the reference's adaptive schedule (interpolated last level): "
                                           "a sub-voxel non-zero value is expected (SURVEY.md finding 1)"}
+                del vd, fd, va, fa
             except Exception as ex:
                 extras["mesh"] = {"error": repr(ex)}
+            # (3b) metric (i): the same dense mesh against the ORACLE's (CPU leg: 257^3 only unless --full-extras)
+            if res <= 257 or args.full_extras:
+                try:
+                    extras.setdefault("mesh", {}).update(mesh_vs_oracle(a, res, occ, args.cmap_mode))
+                except Exception as ex:
+                    extras.setdefault("mesh", {})["dense_vs_oracle_error"] = repr(ex)
         # (2b) COLD per-image figures: fresh SMPL tensors every step (what apps/infer.py does: filter() hands over new tensors
         #      per image, lib/net/HGPIFuNet.py:236-240) - the mesh preparation (normals, BVH, records, ray bins: kernels on the
         #      stream, icon_mesh_create_arena) is inside the timed region, unlike `value`
@@ -478,7 +579,7 @@ def main():
                         "note": "median of 5 after one warm-up; new SMPL tensors every step, mesh built on the device inside the timed region; "
                                 "mesh_create_host_ms = host time of icon_mesh_create_arena (enqueue only, it never waits); reference_mode_image = "
                                 "mesh build + the reference's schedule + marching cubes + clean_mesh (apps/ICON.py:729-761), device tensors throughout"}
-            if res == 257:
+            if sched:
                 cold_cfg["reference_schedule"] = cold(lambda: ad(opt=opt, netG=eng, features=feats, proj_matrix=None))[0]
                 # the whole image in the reference's own mode (apps/ICON.py:729-761): schedule -> export_mesh -> clean_mesh
                 from icon_amd.recon import clean_mesh
@@ -496,6 +597,13 @@ def main():
                     img_stage.append(((t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3))
                 med = np.median(np.array(img_stage[1:]), 0)
                 cold_cfg["reference_mode_stages_warm"] = {"schedule": float(med[0]), "marching_cubes": float(med[1]), "clean_mesh": float(med[2])}
+                cold_cfg["reference_mode_mesh"] = {"faces_marching_cubes": int(fm.shape[0]), "schedule": sched,
+                                                   "schedule_points": int(sum(ad.last_stats.get("queries", []))),
+                                                   "native": bool(ad.last_stats.get("native", False))}
+                free_b, total_b = torch.cuda.mem_get_info(dev)
+                cold_cfg["hbm_gib"] = {"in_use_after_the_image": (total_b - free_b) / 2 ** 30, "torch_peak_allocated": torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                                       "note": "device memory in use by this process after the legs above (dense step + schedule + mesh extraction; the "
+                                               "library's workspaces only grow) and the peak of torch's own tensors"}
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fresh = [t.clone() for t in base]
             eng.set_mesh(*fresh)
@@ -523,11 +631,12 @@ def main():
                                           "k workgroups smaller (k CUs left to RCCL when sharded; DenseReconEngine(reserve_cus=k))"}
         except Exception as ex:
             extras["reserve_cus_cost"] = {"error": repr(ex)}
-        # (4) live parity sample against the checker
-        try:
-            extras["parity"] = parity_sample(a, res, occ, args.cmap_mode, eng=eng)
-        except Exception as ex:
-            extras["parity"] = {"error": repr(ex)}
+        # (4) live parity sample against the checker (CPU leg over the whole lattice: 257^3 only unless --full-extras)
+        if res <= 257 or args.full_extras:
+            try:
+                extras["parity"] = parity_sample(a, res, occ, args.cmap_mode, eng=eng)
+            except Exception as ex:
+                extras["parity"] = {"error": repr(ex)}
         # (5) how much of the volume depends on the tie rule of the unpinned nearest-triangle leaf
         try:
             def step_with(e):
@@ -560,6 +669,21 @@ def main():
                          "avg_launch_ms": stage[2],
                          "algorithmic_hbm_bytes_per_launch": ALGO_BYTES_PER_POINT * my_points},
         }
+        # box or build?  effective clock = shader cycles / wall time of the MLP kernel's workgroup 0 (s_memtime / s_memrealtime
+        # stamps inside the launch, last timed step); cycles_per_launch is the CODE's figure, the clock is the BOX's
+        if "error" not in detail:
+            out["roofline"].update({"effective_clock_mhz": detail["effective_clock_mhz"], "cycles_per_launch": detail["fused_cycles"],
+                                    "clock_note": "s_memtime / s_memrealtime stamps of the kernel's workgroup 0 in the last timed step: "
+                                                  "cycles_per_launch moves with the code, effective_clock_mhz with the box (nominal 2400)"})
+            out["config"]["stage_ms"]["nearest_kernel"] = detail["nearest_ms"]
+        else:
+            out["roofline"]["clock_note"] = detail["error"]
+        if isinstance(zero_ms, float):
+            out["roofline"].update({"mlp_zero_data_ms": zero_ms, "mlp_zero_data_points": 257 ** 3,
+                                    "zero_data_note": "standalone k_mlp_f16x3 (the fused kernel's chunk bodies) on all-zero rows and weights, 257^3 "
+                                                      "points, same run: the instruction stream's own time at the clock the box can hold"})
+        elif zero_ms is not None:
+            out["roofline"]["zero_data_note"] = zero_ms
         if sustained is not None and "error" not in sustained:
             # the library's f16 GEMM rate on this box, random operands, vs what the kernel ISSUES (3 f16 MFMA products per MAC)
             lib_peak = max(v["tflops"] for v in sustained.values())
@@ -574,6 +698,8 @@ def main():
             out["roofline"]["sustained_note"] = sustained["error"]
         if rank_stage is not None:
             out["config"]["rank_stage_ms"] = rank_stage
+        if dist_info is not None:
+            out["config"]["dist"] = dist_info
         if world > 1 and not args.replicas:
             out["config"]["reserve_cus"] = getattr(recon, "reserve_cus_effective", None)     # CUs the MLP grid left to the collective
             out["config"]["gather"] = "mesh" if mesh_exchange else "volume"

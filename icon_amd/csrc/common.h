@@ -382,7 +382,9 @@ struct icon_work {
     icon::CleanState *clean = nullptr;    // icon_clean_mesh scratch
     // optional stage timing: ev[0] start, ev[1] features done, ev[2] patch done, ev[3] MLP done
     bool prof = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ev[4], ev[5]: around the nearest-triangle search kernel alone
+    bool ev_search = false;
+    unsigned long long *d_clock = nullptr;   // [4] cycle / wall counters of the fused kernel's workgroup 0 (FusedGeom::clock)
     bool ev_valid = false;
 };
 

@@ -77,6 +77,10 @@ struct FusedGeom {
     const int64_t *block_offsets;        // exclusive scan of the outlier counts per 256 points of the linear order
     const unsigned long long *grp_mask;  // outlier ballot of every 64-point group of the linear order (4 per block)
     SignSrc sg;
+    // profiling (icon_work_profile): workgroup 0 brackets its run with the shader-cycle counter and the constant-rate wall
+    // counter - [0] s_memtime, [1] s_memrealtime at the start, [2], [3] at the end: cycles / wall time = the EFFECTIVE clock
+    // the matrix pipe ran at under this launch's load (bench.py roofline.effective_clock_mhz: separates a slow box from a slow build)
+    unsigned long long *clock;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -339,6 +343,10 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *Xs = reinterpret_cast<float *>(smem + kXsOff);
+    if (G.clock && blockIdx.x == 0 && threadIdx.x == 0) {
+        G.clock[0] = __builtin_readcyclecounter();              // s_memtime: shader cycles
+        G.clock[1] = __builtin_amdgcn_s_memrealtime();           // constant rate (hipDeviceAttributeWallClockRate)
+    }
 
     // ---- once per workgroup: resident layer-0 operands, side arrays, sign-list geometry ------------------
     issue_units(w.image, smem + kW0Off, kW0Bytes / 1024, wave0, lane0);
@@ -454,6 +462,10 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
             int ix, iy, iz;
             out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : (G.out_map ? (int64_t)G.out_map[oq] : oq)] = masked_result(y, maskf != 0.0f, w.flag);
         }
+    }
+    if (G.clock && blockIdx.x == 0 && threadIdx.x == 0) {
+        G.clock[2] = __builtin_readcyclecounter();
+        G.clock[3] = __builtin_amdgcn_s_memrealtime();
     }
 }
 
@@ -588,6 +600,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     G.N = N;
     G.near = work_near(work, mesh); G.code8 = work->d_code8;
     if (!lattice) { G.n_dev = work->q_n_dev; G.out_map = work->q_map; }
+    G.clock = work->prof ? work->d_clock : nullptr;
     G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;

@@ -706,11 +706,39 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     (void)hipFree(w->d_x); (void)hipFree(w->d_grp_mask); (void)hipFree(w->d_block_counts); (void)hipFree(w->d_block_offsets); (void)hipFree(w->d_scan_local); (void)hipFree(w->d_scan_part);
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_flag); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_lfast); if (w->h_err) (void)hipHostFree(w->h_err); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
-    for (int k = 0; k < 4; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+    for (int k = 0; k < 6; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
+    (void)hipFree(w->d_clock);
     icon::mc_destroy(w->mc);
     icon::clean_destroy(w->clean);
     icon::adaptive_destroy(w->ad);
     delete w;
+    return ICON_OK;
+}
+
+// out[0] = the nearest-triangle search kernel alone (ms; 0 when the call had none), out[1] = shader cycles and out[2] = wall
+// time (ms) of the fused kernel's workgroup 0 (s_memtime / s_memrealtime stamps), out[3] = out[1] / out[2] as MHz - the
+// EFFECTIVE clock under that launch's load.  Synchronises (on the call's last event).
+extern "C" int icon_work_profile_detail(icon_work_t *w, double out[4])
+{
+    ICON_ARG(w != nullptr && out != nullptr, "icon_work_profile_detail: null argument");
+    if (!w->prof || !w->ev_valid) return fail(ICON_ERR_STATE, "icon_work_profile_detail: no profiled call on this workspace");
+    ICON_HIP(hipEventSynchronize(w->ev[3]));
+    out[0] = out[1] = out[2] = out[3] = 0.0;
+    if (w->ev_search) {
+        float ms = 0.0f;
+        ICON_HIP(hipEventElapsedTime(&ms, w->ev[4], w->ev[5]));
+        out[0] = ms;
+    }
+    unsigned long long c[4] = {0, 0, 0, 0};
+    ICON_HIP(hipMemcpy(c, w->d_clock, sizeof(c), hipMemcpyDeviceToHost));
+    int dev = 0, khz = 0;
+    ICON_HIP(hipGetDevice(&dev));
+    ICON_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    if (c[2] > c[0] && c[3] > c[1] && khz > 0) {
+        out[1] = (double)(c[2] - c[0]);
+        out[2] = (double)(c[3] - c[1]) / (double)khz;
+        out[3] = out[1] / out[2] * 1e-3;
+    }
     return ICON_OK;
 }
 
@@ -725,7 +753,12 @@ extern "C" int icon_work_profile(icon_work_t *w, int enable)
 {
     ICON_ARG(w != nullptr, "icon_work_profile: work is null");
     if (enable && !w->ev[0])
-        for (int k = 0; k < 4; ++k) ICON_HIP(hipEventCreate(&w->ev[k]));
+        for (int k = 0; k < 6; ++k) ICON_HIP(hipEventCreate(&w->ev[k]));
+    if (enable && !w->d_clock) {
+        ICON_HIP(hipMalloc((void **)&w->d_clock, 4 * sizeof(unsigned long long)));
+        ICON_HIP(hipMemset(w->d_clock, 0, 4 * sizeof(unsigned long long)));
+    }
+    w->ev_search = false;
     w->prof = enable != 0;
     w->ev_valid = false;
     return ICON_OK;
@@ -931,10 +964,12 @@ int launch_nearest(const icon_mesh_t *mesh, const Calib &cal, const LatticeMap &
         const int nw = (!LATTICE || alt) ? 1 : ((share_env == 1 || share_env == 8 || share_env == 16) ? share_env : share_waves(nb * 4));
         ShareDbg dbg{};
         if (nw > 1) { const int rc = work_share_dbg(work, &dbg); if (rc) return rc; }
+        if (work->prof) (void)hipEventRecord(work->ev[4], st);
         if (nw == 16) hipLaunchKernelGGL(k_nearest_shared<16>, dim3((unsigned)nb * 4), dim3(16 * 64), 0, st, mesh->dev, L, near, sdf_clip, dbg);
         else if (nw == 8) hipLaunchKernelGGL(k_nearest_shared<8>, dim3((unsigned)nb * 4), dim3(8 * 64), 0, st, mesh->dev, L, near, sdf_clip, dbg);
         else if (alt) hipLaunchKernelGGL((k_nearest<LATTICE, true>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, work->tie_ulps, lf);
         else hipLaunchKernelGGL((k_nearest<LATTICE, false>), dim3((unsigned)nb), dim3(kBlock), 0, st, mesh->dev, cal, L, d_points, N, near, perm, sdf_clip, 0, lf);
+        if (work->prof) { (void)hipEventRecord(work->ev[5], st); work->ev_search = true; }
     }
     ICON_HIP(hipGetLastError());
     debug_sync(LATTICE ? "k_row_crossings + k_nearest<lattice>" : "nearest (points)", st);

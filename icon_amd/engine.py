@@ -303,6 +303,13 @@ class Workspace(_Handle):
     def profile(self, enable: bool = True) -> None:
         check(_lib.lib().icon_work_profile(self.h, C.c_int(int(enable))), "icon_work_profile")
 
+    def profile_detail(self) -> dict:
+        """of the most recent profiled call (icon_work_profile_detail): the search kernel alone, and the shader cycles / wall time
+        / effective clock of the fused MLP kernel's workgroup 0"""
+        out = (C.c_double * 4)()
+        check(_lib.lib().icon_work_profile_detail(self.h, out), "icon_work_profile_detail")
+        return {"nearest_ms": float(out[0]), "fused_cycles": float(out[1]), "fused_wall_ms": float(out[2]), "effective_clock_mhz": float(out[3])}
+
     def stage_ms(self):
         """(features_ms, patch_ms, mlp_ms) of the most recent call, from HIP events on its stream"""
         out = (C.c_float * 3)()

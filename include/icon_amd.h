@@ -182,6 +182,12 @@ int icon_work_profile(icon_work_t *work, int enable);
  * beside it.  n > 0 makes its grid n CUs smaller - the collective gets them; the MLP pays n / CUs.  Default 0. */
 int icon_work_set_reserve_cus(icon_work_t *work, int n);
 int icon_work_stage_ms(icon_work_t *work, float out_ms[3]);
+/* More of the same profiled call: out[0] = the nearest-triangle search kernel ALONE (ms, HIP events around its launch; 0 if
+ * the call had none), out[1] = shader cycles and out[2] = wall milliseconds of the fused MLP kernel's workgroup 0 (it brackets
+ * its run with s_memtime and the constant-rate s_memrealtime), out[3] = out[1] / out[2] in MHz: the EFFECTIVE clock the
+ * kernel ran at under its own load.  cycles = the code's invariant, MHz = the box's: bench.py prints both so that a slower
+ * line can be told from a slower build without PMC files.  Synchronises like icon_work_stage_ms. */
+int icon_work_profile_detail(icon_work_t *work, double out[4]);
 
 /* ---------------------------------------------------------------------------------------------
  * HGPIFuNet.query (lib/net/HGPIFuNet.py:268-367) for explicit points:

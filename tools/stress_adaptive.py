@@ -1,6 +1,9 @@
 """Stress: fresh meshes + the native schedule, many times; every volume must equal the first one bit for bit (the shared-walk
-search and the device mesh build are timing dependent in HOW they get there, never in the answer)."""
-import os, sys, time
+search and the device mesh build are timing dependent in HOW they get there, never in the answer), and no shared walk may
+report a hand-over it gave up on (icon_work_status; adaptive_eval raises by itself).  Every 10th iteration also the coarse
+slab calls (33^3 / 65^3: k_nearest_shared<16> / <8>), every 100th the five-level schedule of mcube_res=512.
+    N=4000 python tools/stress_adaptive.py        ->  one line "stress ok: ..." (or MISMATCH / the error, exit code 1)"""
+import os, socket, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from icon_amd import synth
@@ -9,7 +12,17 @@ a = synth.make_assets("body"); T = lambda x: torch.from_numpy(x).cuda()
 n = int(os.environ.get("N", "300"))
 v, f, cm, vs = T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis)
 feat = T(a.features)
-first = None
+first = {}
+n_slab = n_513 = 0
+
+
+def same(key, vol, extra=None):
+    if key not in first:
+        first[key] = (vol.clone(), extra)
+        return True
+    return torch.equal(vol.view(torch.int32), first[key][0].view(torch.int32)) and extra == first[key][1]
+
+
 t0 = time.perf_counter()
 for it in range(n):
     eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip) if it % 50 == 0 else eng
@@ -17,9 +30,20 @@ for it in range(n):
         eng.set_regressor({k: torch.from_numpy(x) for k, x in a.state_dict.items()})
     eng.set_mesh(v.clone(), f, cm, vs)            # a new tensor: a new device build every time
     vol, counts, pos = eng.adaptive_eval(feat, [33, 65, 129, 257])
-    if first is None:
-        first, c0 = vol.clone(), counts
-    elif not (torch.equal(vol.view(torch.int32), first.view(torch.int32)) and counts == c0):
-        print("MISMATCH at iteration", it, counts, c0, int((vol != first).sum())); sys.exit(1)
+    if not same("257", vol, counts):
+        print("MISMATCH at iteration", it, counts, first["257"][1], int((vol != first["257"][0]).sum())); sys.exit(1)
+    if it % 10 == 0:
+        for r in (33, 65):
+            if not same(f"slab{r}", eng.eval_slab(feat, r, 0, r)):
+                print("MISMATCH in the", r, "slab at iteration", it); sys.exit(1)
+        torch.cuda.synchronize()
+        eng._work().status()                      # raises if a shared walk of the slab calls reported
+        n_slab += 2
+    if it % 100 == 0:
+        vol, counts, pos = eng.adaptive_eval(feat, [33, 65, 129, 257, 513])
+        if not same("513", vol, counts):
+            print("MISMATCH in the 513 schedule at iteration", it, counts); sys.exit(1)
+        n_513 += 1
 torch.cuda.synchronize()
-print(f"stress ok: {n} meshes + schedules, {(time.perf_counter() - t0) / n * 1e3:.3f} ms each, counts {c0}")
+print(f"stress ok: {n} meshes + schedules on {socket.gethostname()} ({torch.cuda.get_device_name(0)}), {(time.perf_counter() - t0) / n * 1e3:.3f} ms each, "
+      f"counts {first['257'][1]}; + {n_slab} coarse slab calls, {n_513} five-level schedules {first['513'][1] if '513' in first else ''}; no shared-walk report")
