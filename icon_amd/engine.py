@@ -446,20 +446,36 @@ class IconQueryEngine:
         self._vol = vol_feat
 
     # ---- handle caches ---------------------------------------------------------------------------
-    def _work(self) -> Workspace:
-        if self.work is None:
-            self.work = Workspace()
-            self._work_tie = None
-        if self.tie_rule != self._work_tie:
+    split_features = True      # slab_features / slab_finish_gathered take ``work=1``: a second workspace, so that the two halves of a
+                               # Z-slab can each run phase 1 and exchange their outlier signs independently (recon._forward_sharded)
+
+    def _work(self, i: int = 0) -> Workspace:
+        """workspace ``i`` of this engine (0: every ordinary call; 1: the second half-slab of the sharded protocol)"""
+        if i == 0:
+            if self.work is None:
+                self.work = Workspace()
+                self._work_tie = None
+            w = self.work
+        else:
+            extra = self.__dict__.setdefault("_extra_works", {})
+            if i not in extra:
+                extra[i] = Workspace()
+                extra[i]._tie = None
+            w = extra[i]
+        have = self._work_tie if i == 0 else w._tie
+        if self.tie_rule != have:
             if self.tie_rule is None:
-                self.work.set_tie_rule(0, 0)
+                w.set_tie_rule(0, 0)
             else:
                 kind, ulps = self.tie_rule
                 if kind != "highest":
                     raise IconAmdError("tie_rule must be None or ('highest', ulps)")
-                self.work.set_tie_rule(1, int(ulps))
-            self._work_tie = self.tie_rule
-        return self.work
+                w.set_tie_rule(1, int(ulps))
+            if i == 0:
+                self._work_tie = self.tie_rule
+            else:
+                w._tie = self.tie_rule
+        return w
 
     def _mesh_handle(self) -> Optional[MeshHandle]:
         if self.prior_type != "icon":
@@ -824,7 +840,7 @@ class IconQueryEngine:
         return out, [int(hc[k]) for k in range(n)], bool(hc[n])
 
     @_guarded
-    def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None, msg=None):
+    def slab_features(self, im_feat, res: int, z0: int, z1: int, signs=None, count=None, msg=None, work: int = 0):
         """Phase 1 of the split protocol -> (signs int8 [cap] device, count int64 [1] device).  With ``msg`` (a
         contiguous int8 / uint8 device buffer of >= 8 + ceil(points / 4) bytes, e.g. this rank's slot of an all_gather
         input) the slab's exchange message [int64 K][2-bit packed signs] is written there instead and ``msg`` is returned."""
@@ -836,7 +852,7 @@ class IconQueryEngine:
             check(_lib.lib().icon_grid_slab_features_msg(
                 mesh.h if mesh is not None else C.c_void_p(0), feat.h, C.c_int(_lib.PRIOR[self.prior_type]),
                 C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
-                C.c_int(z1), ptr(msg), C.c_int64(msg.numel()), C.c_int(_lib.SEARCH[self.search]), self._work().h, _stream()),
+                C.c_int(z1), ptr(msg), C.c_int64(msg.numel()), C.c_int(_lib.SEARCH[self.search]), self._work(work).h, _stream()),
                 "icon_grid_slab_features_msg")
             return msg
         if signs is None:
@@ -848,7 +864,7 @@ class IconQueryEngine:
         check(_lib.lib().icon_grid_slab_features(
             mesh.h if mesh is not None else C.c_void_p(0), feat.h, C.c_int(_lib.PRIOR[self.prior_type]),
             C.c_float(np.float32(self.sdf_clip)), C.c_int(_lib.CMAP[self.cmap_mode]), C.c_int(res), C.c_int(z0),
-            C.c_int(z1), ptr(signs), ptr(count), C.c_int(_lib.SEARCH[self.search]), self._work().h, _stream()),
+            C.c_int(z1), ptr(signs), ptr(count), C.c_int(_lib.SEARCH[self.search]), self._work(work).h, _stream()),
             "icon_grid_slab_features")
         return signs, count
 
@@ -868,11 +884,12 @@ class IconQueryEngine:
 
     @_guarded
     def slab_finish_gathered(self, res: int, z0: int, z1: int, gathered: Optional[torch.Tensor], stride: int, world: int, rank: int,
-                             regressor=None, out=None, za: Optional[int] = None, zb: Optional[int] = None, device=None) -> torch.Tensor:
+                             regressor=None, out=None, za: Optional[int] = None, zb: Optional[int] = None, device=None, work: int = 0) -> torch.Tensor:
         """Phase 2 on the all_gather output itself: ``gathered`` bytes [world * stride], message r =
         [int64 count_r][2-bit packed signs_r] (slab_features(msg=...)); nothing is read back to the host.
         ``gathered=None``: no exchange (cmap_mode local / one rank).  Evaluates the planes [za, zb) of the slab
-        (default: all of it) into ``out`` [(z1-z0), res, res], the SLAB's buffer; may be called piece by piece."""
+        (default: all of it) into ``out`` [(z1-z0), res, res], the SLAB's buffer; may be called piece by piece.  ``work``: the
+        workspace phase 1 of THIS slab ran on (slab_features(work=...))."""
         mlp = self._mlp_handle(regressor)
         if out is None:
             out = torch.empty((z1 - z0, res, res), dtype=torch.float32, device=gathered.device if gathered is not None else device)
@@ -880,7 +897,7 @@ class IconQueryEngine:
         zb = z1 if zb is None else zb
         check(_lib.lib().icon_grid_slab_finish_gathered(
             mlp.h, C.c_int(res), C.c_int(z0), C.c_int(z1), C.c_int(za), C.c_int(zb), ptr(gathered), C.c_int64(stride),
-            C.c_int(world), C.c_int(rank), ptr(out), C.c_int(self._precision()), self._work().h, _stream()),
+            C.c_int(world), C.c_int(rank), ptr(out), C.c_int(self._precision()), self._work(work).h, _stream()),
             "icon_grid_slab_finish_gathered")
         return out
 

@@ -357,6 +357,8 @@ class DenseReconEngine(nn.Module):
             want = 16 if (self.overlap_gather and dist.get_backend(g) == "nccl") else 0
         if hasattr(be, "_work") and getattr(self, "_reserved", None) != want:
             be._work().set_reserve_cus(want)
+            if getattr(be, "split_features", False):
+                be._work(1).set_reserve_cus(want)
             self._reserved = want
         self.reserve_cus_effective = want
         parts = self._slab_cuts(be, res, dist, world, rank, dev)
@@ -379,7 +381,54 @@ class DenseReconEngine(nn.Module):
             out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
             return out, dist.all_gather_into_tensor(out, t, group=g, async_op=True)
 
-        if pieces:
+        # Split phase 1 (round 5): with the volume gathered in two halves anyway, each half-slab also runs ITS OWN geometry pass
+        # (its own workspace) and exchanges its own sign message - asynchronously: the first half's all_gather is in flight while
+        # k_nearest of the second half runs, instead of every rank's MLP waiting for one blocking exchange behind the whole
+        # slab's search.  A rank's outlier list is (first half) ++ (second half) in the lattice's order, so the 2 x world
+        # messages, interleaved [r0a, r0b, r1a, r1b, ...], are the very list of the unsplit protocol: the same bits.
+        split = bool(pieces and need_exchange and per_a < per and getattr(be, "split_features", False) and 2 * world <= 64)
+        order = []                                           # what was enqueued, in order (tests read it)
+        if split:
+            stride_h = 8 + ((per_a * res * res + 3) // 4 + 7) // 8 * 8
+            hkey = (res, world, rank, str(dev), per_a)
+            if getattr(self, "_shard_half_key", None) != hkey:
+                self._shard_half_msg = torch.zeros((2, stride_h), dtype=torch.int8, device=dev)
+                self._shard_half_key = hkey
+            zm = min(z1, z0 + per_a)
+            halves = ((z0, zm), (zm, z1))
+            got, waits = [], []
+            for hf, (a0, a1) in enumerate(halves):
+                m = self._shard_half_msg[hf]
+                m[:8].zero_()
+                if a1 > a0:
+                    be.slab_features(im_feat, res, a0, a1, msg=m, work=hf)
+                order.append(f"features_{'ab'[hf]}")
+                g_h, hd = gather_async(m)
+                order.append(f"gather_signs_{'ab'[hf]}" + ("" if hd is None else "_async"))
+                got.append(g_h)
+                waits.append(hd)
+            for hd in waits:
+                if hd is not None:
+                    hd.wait()
+            order.append("wait_signs")
+            gathered = torch.stack([got[0].view(world, stride_h), got[1].view(world, stride_h)], 1).reshape(-1)   # [world, 2, stride_h]
+            vols = []
+            for hf, (a0, a1) in enumerate(halves):
+                if a1 > a0:
+                    be.slab_finish_gathered(res, a0, a1, gathered, stride_h, 2 * world, 2 * rank + hf, out=slab[a0 - z0: a1 - z0], device=dev, work=hf)
+                order.append(f"finish_{'ab'[hf]}")
+                v_h, hd = gather_async(slab[:per_a] if hf == 0 else slab[per_a:])
+                order.append(f"gather_volume_{'ab'[hf]}" + ("" if hd is None else "_async"))
+                vols.append(v_h)
+                handles.append(hd)
+            for hd in handles:
+                if hd is not None:
+                    hd.wait()
+            allv = torch.empty((world, per, res, res), dtype=torch.float32, device=vols[0].device)
+            allv[:, :per_a] = vols[0].view(world, per_a, res, res)
+            allv[:, per_a:] = vols[1].view(world, per - per_a, res, res)
+            self.last_stats = dict(exchanged_bytes=2 * stride_h * world, collectives=4, slabs=parts, split_features=True, order=order)
+        elif pieces:
             gathered = None
             if need_exchange:
                 # ONE collective, no host synchronisation: every rank contributes a fixed-size message; phase 1 writes

@@ -42,6 +42,8 @@ def main():
                 vol = rec(opt=opt, netG=eng, features=feats, proj_matrix=None)
                 slabs = rec.last_stats["slabs"]
                 assert len(slabs) == world and slabs[0][0] == 0 and slabs[-1][1] == res
+                # overlapped gather + the tiled cmap rule: phase 1 ran per half-slab on two workspaces with its own sign exchange
+                assert bool(rec.last_stats.get("split_features")) == (overlap and cmap_mode == "reference"), rec.last_stats
                 if rank == 0:
                     e1 = engine()
                     one = DenseReconEngine(query_func=query_func, resolutions=[res], align_corners=True, engine=e1, shard=False).to(dev)

@@ -25,9 +25,12 @@ class OracleBackend:
     """eval_slab / slab_features / slab_finish with the oracle; asserts that what the distributed
     driver hands to slab_finish is exactly the global outlier list of the whole lattice."""
     prior_type = "icon"
+    split_features = False     # True: the driver may run phase 1 per half-slab on workspaces 0 / 1 (the HIP engine's protocol since round 5)
 
-    def __init__(self, a, cmap_mode):
+    def __init__(self, a, cmap_mode, split=False):
         self.a, self.cmap_mode = a, cmap_mode
+        self.split_features = split
+        self.phase1 = {}           # workspace -> the slab its phase 1 ran on
         pts = synth.lattice_points(RES)
         self.full, _ = orc.query_icon(a.smpl_verts[0], a.smpl_faces[0], a.smpl_cmap[0], a.smpl_vis[0], a.features,
                                       orc.Mlp(a.state_dict), pts, sdf_clip=a.sdf_clip,
@@ -49,8 +52,9 @@ class OracleBackend:
             return out
         return t
 
-    def slab_features(self, im_feat, res, z0, z1, signs=None, count=None, msg=None):
+    def slab_features(self, im_feat, res, z0, z1, signs=None, count=None, msg=None, work=0):
         self.calls.append(("features", z0, z1))
+        self.phase1[work] = (z0, z1)
         lst = self._local_list(z0, z1)
         if msg is not None:
             # the exchange message of the single-collective protocol: [int64 K][2 bits per sign (sign + 1), 4 per byte]
@@ -73,12 +77,13 @@ class OracleBackend:
         count[0] = len(lst)
         return signs, count
 
-    def slab_finish_gathered(self, res, z0, z1, gathered, stride, world, rank, out=None, za=None, zb=None, device=None):
+    def slab_finish_gathered(self, res, z0, z1, gathered, stride, world, rank, out=None, za=None, zb=None, device=None, work=0):
         """the single-collective protocol: message r = [int64 count_r][2-bit packed signs_r ...] at r * stride;
-        evaluates the planes [za, zb) of the slab into out (the slab's buffer)"""
+        evaluates the planes [za, zb) of the slab into out (the slab's buffer).  (Split phase 1: `world` / `rank` count HALF-slabs.)"""
         za = z0 if za is None else za
         zb = z1 if zb is None else zb
         assert z0 <= za < zb <= z1
+        assert self.phase1.get(work) == (z0, z1), "phase 2 on a workspace whose phase 1 ran on another slab"
         self.calls.append(("finish", z0, z1, za, zb))
         if gathered is not None:
             assert gathered.element_size() == 1 and gathered.numel() == world * stride and stride % 8 == 0
@@ -115,14 +120,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=False):
+def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=False, split=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         a = assets("ico")
-        be = OracleBackend(a, cmap_mode)
+        be = OracleBackend(a, cmap_mode, split=split)
         be.cmap_mode = cmap_mode
         if skew:
             # replicas of the SMPL tensors that differ between ranks (here grossly): every rank would derive another
@@ -153,6 +158,19 @@ def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=Fa
         else:
             z0, z1, _ = slab_bounds(RES, world, rank)
         kinds = [c[0] for c in be.calls]
+        did_split = bool(recon.last_stats.get("split_features"))
+        if did_split:
+            # phase 1 per half-slab, each half's sign exchange asynchronous and enqueued BEFORE the next half's search; one wait
+            # for both; then the halves are finished and their volume gathers started in turn
+            order = recon.last_stats["order"]
+            ok = ok and [o.replace("_async", "") for o in order] == ["features_a", "gather_signs_a", "features_b", "gather_signs_b", "wait_signs",
+                                                                    "finish_a", "gather_volume_a", "finish_b", "gather_volume_b"]
+            ok = ok and all(o.endswith("_async") for o in order if o.startswith("gather_"))     # CPU tensors under gloo: really asynchronous
+            halves = sorted({c[1:3] for c in be.calls})
+            ok = ok and halves[0][0] == z0 and halves[-1][1] == z1 and all(a[1] == b[0] for a, b in zip(halves[:-1], halves[1:]))
+            ok = ok and kinds == ["features"] * kinds.count("features") + ["finish"] * kinds.count("finish") and 1 <= kinds.count("features") <= 2
+            q.put((rank, bool(ok), kinds + ["split"]))
+            return
         ok = ok and all(c[1:3] == (z0, z1) for c in be.calls)
         if legacy:
             ok = ok and (kinds == (["features", "finish", "eval"] if cmap_mode == "reference" else ["eval"]))
@@ -167,17 +185,21 @@ def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=Fa
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("cmap_mode,legacy,overlap,skew", [("reference", False, True, False), ("reference", False, False, False),
-                                                           ("reference", True, True, False), ("local", False, True, False),
-                                                           ("local", True, True, False), ("reference", False, True, True)])
+@pytest.mark.parametrize("cmap_mode,legacy,overlap,skew,split", [("reference", False, True, False, False), ("reference", False, False, False, False),
+                                                                 ("reference", True, True, False, False), ("local", False, True, False, False),
+                                                                 ("local", True, True, False, False), ("reference", False, True, True, False),
+                                                                 ("reference", False, True, False, True), ("reference", False, True, True, True),
+                                                                 ("local", False, True, False, True), ("reference", False, False, False, True)])
 @pytest.mark.parametrize("world", [2, 3])
-def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, world):
-    """packed sign messages, the two-half volume gather, the legacy host-side exchange, and ranks whose replicas of
-    the body disagree (rank 0's cut is broadcast)"""
+def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, split, world):
+    """packed sign messages, the two-half volume gather, the legacy host-side exchange, ranks whose replicas of
+    the body disagree (rank 0's cut is broadcast), and - split - phase 1 per half-slab with ASYNCHRONOUS sign exchanges
+    (the first half's all_gather in flight while the second half is searched): 2 x world messages interleaved into the
+    very list of the unsplit protocol (the backend asserts the global list, the offsets and the workspace pairing)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, legacy, overlap, skew)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, legacy, overlap, skew, split)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=180) for _ in range(world)]
@@ -186,6 +208,8 @@ def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, world):
         assert p.exitcode == 0
     assert sorted(r[0] for r in res) == list(range(world))
     assert all(r[1] for r in res), res
+    if split and cmap_mode == "reference" and overlap:
+        assert all(r[2][-1] == "split" for r in res), res          # the split protocol really ran on every rank
 
 
 def standin_slab_mesh(buf, z0, res, zc0, zc1, halo, level):
