@@ -324,6 +324,9 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="N > 1: CUs the persistent MLP kernel leaves to the RCCL kernels of the overlapped all_gather (DenseReconEngine "
                          "reserve_cus); -1 = the engine's default (16 over RCCL with the overlapped gather, else 0)")
+    ap.add_argument("--no-overlap-gather", action="store_true",
+                    help="N > 1, sharded: one blocking sign exchange and ONE volume all_gather after the whole slab instead of the "
+                         "split / overlapped protocol (DenseReconEngine overlap_gather=False) - the A/B leg of tools/scale_round.sh")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-extras", action="store_true",
                     help="also run the whole-lattice CPU checker legs (parity sample, mesh vs oracle) above 257^3 (513^3: about a minute)")
@@ -389,7 +392,8 @@ def main():
     feats = [T(a.features)]
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions={257: [33, 65, 129, 257], 513: [33, 65, 129, 257, 513]}.get(res, [res]), align_corners=True,
-                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
+                             balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, overlap_gather=not args.no_overlap_gather,
+                             reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
     opt = SimpleNamespace(num_views=1)
 
     mesh_exchange = bool(args.mesh_exchange and world > 1 and not args.replicas)
@@ -409,6 +413,9 @@ def main():
     for _ in range(args.warmup):
         step()
     eng._work().profile(True)
+    two_works = world > 1 and not args.replicas and not args.no_overlap_gather and not mesh_exchange
+    if two_works:
+        eng._work(1).profile(True)                      # split phase 1: the second half-slab runs on its own workspace
     stage = np.zeros(3)
 
     def barrier():
@@ -423,6 +430,11 @@ def main():
         # stage_ms waits on this step's last event (the MLP) - the same point the reference's
         # `(occupancys > 0.5).sum() == 0` check already synchronises on
         stage += np.array(eng._work().stage_ms())
+        if two_works and recon.last_stats.get("split_features"):
+            try:
+                stage += np.array(eng._work(1).stage_ms())     # the rank's stage times = both half-slabs
+            except Exception:
+                pass                                    # (a rank whose slab fits the first half: no call on workspace 1)
     barrier()
     elapsed = time.perf_counter() - t0
     my_elapsed = elapsed
@@ -436,6 +448,8 @@ def main():
     except Exception as ex:
         detail = {"error": repr(ex)}
     eng._work().profile(False)
+    if two_works:
+        eng._work(1).profile(False)
     if mesh_exchange:                                   # the step returned (verts, faces): what marching cubes on the volume gives
         assert occ is not None and occ[0].shape[1] == 3 and occ[1].shape[1] == 3 and occ[1].shape[0] > 0
     else:
@@ -703,6 +717,8 @@ def main():
         if world > 1 and not args.replicas:
             out["config"]["reserve_cus"] = getattr(recon, "reserve_cus_effective", None)     # CUs the MLP grid left to the collective
             out["config"]["gather"] = "mesh" if mesh_exchange else "volume"
+            out["config"]["overlap_gather"] = not args.no_overlap_gather
+            out["config"]["split_features"] = bool(recon.last_stats.get("split_features", False))
             if mesh_exchange:
                 out["config"]["exchanged_bytes_per_step"] = recon.last_stats.get("exchanged_bytes")
         if not args.no_cpu_baseline and world == 1 and args.prior == "icon":
