@@ -147,7 +147,26 @@ def largest_component(verts: np.ndarray, faces: np.ndarray):
 
 
 def largest_component_by_faces(verts, faces):
-    """lib/dataset/mesh_util.py:778-791 with trimesh's connectivity spelled out in plain Python (the checker of icon_clean_mesh;
+    """The rule, as published (trimesh 3.x - the package is absent here; stated from its source, NOT run):
+      lib/dataset/mesh_util.py:778-791   mesh_lst = trimesh.Trimesh(verts, faces).split(only_watertight=False)
+                                         comp_num = [m.vertices.shape[0] for m in mesh_lst]
+                                         mesh_clean = mesh_lst[comp_num.index(max(comp_num))]      -> FIRST of several largest
+      trimesh/base.py  Trimesh.split  -> graph.split(self, only_watertight=False)
+      trimesh/graph.py split:   adjacency = mesh.face_adjacency;  min_len = 1 (4 only when only_watertight)
+                                components = connected_components(edges=adjacency, nodes=arange(len(faces)), min_len=1)
+                                return mesh.submesh(components, only_watertight=False)          -> one mesh per component, in order
+      trimesh/graph.py face_adjacency: edges sorted per face, grouping.group_rows(edges_sorted, require_count=2) - two faces are
+                                adjacent iff they share an edge used by EXACTLY two faces (an edge of 1 or of 3+ faces joins nothing)
+      trimesh/graph.py connected_components (scipy engine: csgraph.connected_components labels, grouping.group(labels)): the
+                                components come out in order of their label = of the lowest-numbered face each contains; a face
+                                without any adjacency is a component of its own (min_len = 1)
+      submesh: faces keep their relative order, vertices are the referenced ones in ascending index order, renumbered
+    so: most distinct vertices wins, ties go to the component holding the lowest face index - the rule below and icon_clean_mesh's.
+    NOT restated (and a difference if it ever matters): Trimesh(verts, faces) is built with process=True, which first MERGES
+    vertices at identical positions (merge_vertices) - marching cubes emits coincident vertices only where a lattice value equals
+    the level exactly (a handful per 1.4e8 values, tests/test_gpu_round5.py) - and drops NaN / inf vertices.
+
+    lib/dataset/mesh_util.py:778-791 with trimesh's connectivity spelled out in plain Python (the checker of icon_clean_mesh;
     largest_component above unites faces through shared VERTICES - the two agree except at marching-cubes pinch points):
     faces are adjacent when they share an edge that EXACTLY two faces use (graph.face_adjacency: grouping.group_rows(edges,
     require_count=2)); components of that graph; the one with the most distinct vertices wins (ties: the one holding the

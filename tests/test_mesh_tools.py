@@ -158,3 +158,91 @@ def test_chamfer_p2s_on_the_hip_closest_point_engine():
     assert abs(c - c_ref) <= 0.03 * c_ref + 0.02, (c, c_ref)
     assert 0.5 * c <= p <= 2.0 * c
     assert 2.0 <= c <= 6.0                                            # radii differ by 0.03, centres by 0.055 -> a few x100 units
+
+
+# ---------------------------------------------------------------------------------------------
+# the product's generated case table against the CLASSIC published table (oracle/mc_classic.py: what PyMCubes implements,
+# lib/common/seg3d_lossless.py:592) - the triangulation stays unpinned (no PyMCubes here), but the gap is a LIST
+# ---------------------------------------------------------------------------------------------
+def _product_mesher(vol, level):
+    """icon_export_mesh on one cube: export_mesh drops the first plane of every axis and returns (x, y, z) = array axes (2, 1, 0)"""
+    P = np.zeros(tuple(s + 1 for s in vol.shape), np.float32)
+    P[1:, 1:, 1:] = vol
+    v, f = export_mesh_numpy(P, level)
+    return v.numpy()[:, ::-1].copy(), f.numpy()
+
+
+def test_classic_table_is_mechanically_valid():
+    """the table is written out from the published one - so it is checked, not trusted: triangles only on cut edges, every cut
+    edge used, closed fans, face segments that depend on the face's corner bits only (neighbouring cubes agree); and the classic
+    algorithm on random volumes gives a closed, consistently oriented surface whose vertex set is every edge crossing"""
+    from oracle import mc_classic
+    r = mc_classic.validate_table()
+    assert r["ok"], r["problems"][:5]
+    assert r["separates_set_corners"]                       # on an ambiguous face the SET corners are cut off from each other
+    rng = np.random.RandomState(5)
+    for n, level in ((9, 0.5), (12, 0.37)):
+        vol = rng.rand(n, n, n).astype(np.float32)
+        for below in (True, False):
+            v, f = mc_classic.marching_cubes(vol, level, set_below=below)
+            P = np.zeros((n + 1,) * 3, np.float32)
+            P[1:, 1:, 1:] = vol
+            assert mc_check.same_point_set(v[:, ::-1], mc_check.edge_crossings(P, level))
+            t = mc_check.topology(v, f, n)
+            assert t["one_cube"] and t["used_all"] and t["oriented"] and t["closed"], (n, below, t)
+
+
+def test_product_table_vs_classic_table():
+    """Per cube configuration (Bourke's numbering; PyMCubes reads a numpy array's axes (0,1,2) as the cube's (x,y,z)): does the
+    product's generated table give the classic table's triangle SET, the same surface loops with other diagonals, or another
+    surface?  Under the reading "bit set = corner ABOVE the level": the same loops in all 256 configurations (the product cuts
+    the inside corners of an ambiguous face off from each other - Bourke's rule for his set corners), 107 identical triangle sets.
+    Under "bit set = corner BELOW the level" (Bourke's text, PyMCubes as recalled): 120 configurations with an ambiguous face
+    are resolved the other way round.  DESIGN.md section 4.5 lists them; this test pins the list."""
+    from oracle import mc_classic
+    above = mc_classic.compare_tables(mc_classic.TRI_TABLE, mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=True))
+    assert above["topology"] == [] and len(above["same"]) == 107 and len(above["triangulation"]) == 149
+    below = mc_classic.compare_tables(mc_classic.TRI_TABLE, mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=False))
+    assert len(below["topology"]) == 120 and len(below["same"]) == 54 and len(below["triangulation"]) == 82
+    # a configuration differs in topology under the second reading exactly when one of its faces is ambiguous
+    amb = [c for c in range(256) if any([(c >> m) & 1 for m in f] in ([1, 0, 1, 0], [0, 1, 0, 1]) for f in mc_classic.FACES.tolist())]
+    assert sorted(below["topology"]) == amb
+    # orientation: the reference flips PyMCubes' faces (seg3d_lossless.py:594: faces[:, [0, 2, 1]]); wherever the triangle sets agree
+    # the product's winding is the classic winding under ONE of the two readings consistently
+    def cyc(t):
+        t = list(t); k = t.index(min(t)); return tuple(t[k:] + t[:k])
+    prod = mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=False)
+    for c in below["same"]:
+        assert {cyc(t[[0, 2, 1]]) for t in mc_classic.TRI_TABLE[c]} == {cyc(t) for t in prod[c]}, c
+
+
+def test_classic_marching_cubes_on_the_body_volume():
+    """the reference's own dense 33^3 volume: the classic algorithm and the product give the SAME vertex set (every edge
+    crossing) under either reading of the case bit; under "set = above the level" also the same number of faces (the same loops in
+    every configuration: a loop of k crossings is k - 2 triangles however it is cut); under "set = below" the 28 cells of this
+    volume with an ambiguous face (of the 629 cells the surface passes through at this coarse resolution) are where the two
+    surfaces differ - and nowhere else"""
+    from oracle import mc_classic
+    body = golden("seg3d_body_dense33.npz")["occ"]
+    pv, pf = export_mesh_numpy(body, 0.5)
+    pv = pv.numpy()[:, ::-1].astype(np.float64)                 # -> array-index order of the cropped volume
+    s = body[1:, 1:, 1:] > 0.5
+    idx = np.zeros(tuple(n - 1 for n in s.shape), np.int64)
+    n0, n1, n2 = s.shape
+    for m, (dx, dy, dz) in enumerate(mc_classic.CORNERS):
+        idx |= s[dx:n0 - 1 + dx, dy:n1 - 1 + dy, dz:n2 - 1 + dz].astype(np.int64) << m
+    amb = [c for c in range(256) if any([(c >> m) & 1 for m in f] in ([1, 0, 1, 0], [0, 1, 0, 1]) for f in mc_classic.FACES.tolist())]
+    n_amb = int(np.isin(idx, amb).sum())
+    n_surface = int(((idx > 0) & (idx < 255)).sum())
+    assert n_amb == 28 and n_surface == 629
+    for below in (True, False):
+        cv, cf = mc_classic.marching_cubes(body[1:, 1:, 1:], 0.5, set_below=below)
+        assert mc_check.same_point_set(cv, pv)
+        if not below:
+            assert len(cf) == len(pf)
+            # ... and outside the configurations whose diagonals differ, the same triangles: compare as sets of vertex-position triples
+            key = lambda v, f: {tuple(sorted(map(tuple, np.round(v[t] * 4096).astype(np.int64).tolist()))) for t in f}
+            a, b = key(cv, cf), key(pv, pf.numpy())
+            assert len(a & b) > 0.3 * len(a)
+        else:
+            assert abs(len(cf) - len(pf)) <= 2 * n_amb
