@@ -9,7 +9,7 @@ timeout 1500 python -X faulthandler -m pytest tests -m gpu -x -q > gpurun_out/${
 timeout 600 python bench.py > gpurun_out/${T}_bench.log 2>&1; tail -1 gpurun_out/${T}_bench.log | cut -c1-400
 timeout 600 python bench.py --prior pamir --no-cpu-baseline > gpurun_out/${T}_bench_pamir.log 2>&1; tail -1 gpurun_out/${T}_bench_pamir.log | cut -c1-300
 timeout 600 python bench.py --precision f32 --no-cpu-baseline --no-extras --steps 3 --warmup 1 > gpurun_out/${T}_bench_f32.log 2>&1; tail -1 gpurun_out/${T}_bench_f32.log | cut -c1-300
-timeout 600 python bench.py --res 513 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/${T}_bench_513.log 2>&1; tail -1 gpurun_out/${T}_bench_513.log | cut -c1-300
+timeout 600 python bench.py --res 513 --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/${T}_bench_513.log 2>&1; tail -1 gpurun_out/${T}_bench_513.log | cut -c1-300
 fi
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_stats -- python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extras > $R/gpurun_out/${T}_stats.log 2>&1
@@ -38,5 +38,6 @@ python tools/rocprof_summary.py stats $(find gpurun_out/${T}_meshbuild -name "*.
 grep "^build 1[0-9]" gpurun_out/${T}_meshbuild.log | cut -c1-170 | head -3
 python tools/time_coarse.py 2>/dev/null | grep "^slab" > gpurun_out/${T}_coarse_slabs.txt; cat gpurun_out/${T}_coarse_slabs.txt
 python tools/trav_stats.py 2>/dev/null | grep "^33\|^65\|^129\|^257" | cut -c1-250 > gpurun_out/${T}_traversal_stats.txt
-for k in 1 2 3; do python tools/stress_adaptive.py 2>/dev/null | grep "stress ok\|MISMATCH"; done > gpurun_out/${T}_stress.txt; cat gpurun_out/${T}_stress.txt
+(echo "box $(cat /proc/sys/kernel/random/boot_id)"; N=${STRESS_N:-4000} python tools/stress_adaptive.py 2>&1 | tail -2) > gpurun_out/${T}_stress.txt; cat gpurun_out/${T}_stress.txt
+python tools/time_mesh_extract.py 2>/dev/null | tail -8 > gpurun_out/${T}_mesh_extract.txt
 find gpurun_out -name "*.db" -delete
