@@ -1,5 +1,5 @@
 #!/bin/bash
-# Same-box A/B of the geometry pre-pass: the round-4 tree (build_ab/r04, made by `git archive 534525d | tar -x` + make) against
+# Same-box A/B of the geometry pre-pass: the round-3 / round-4 trees (build_ab/r03, r04: `git archive 3a678e2 | 534525d | tar -x` + make) against
 # this tree with and without the per-call tile record (ICON_AMD_LATTICE_FAST); kernel times from rocprofv3, interleaved twice.
 #   usage: gpurun -- 'bash tools/ab_r05.sh <tag>'
 T=${1:-ab5}
@@ -14,6 +14,7 @@ run() {   # name, bench path, env...
   find $R/gpurun_out/${T}_$n -name "*.db" -delete
 }
 for rep in 1 2; do
+  [ -d $R/build_ab/r03 ] && run r03_$rep $R/build_ab/r03/bench.py A=1
   run r04_$rep $R/build_ab/r04/bench.py A=1
   run slow_$rep $R/bench.py ICON_AMD_LATTICE_FAST=0
   run fast_$rep $R/bench.py ICON_AMD_LATTICE_FAST=1
