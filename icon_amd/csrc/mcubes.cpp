@@ -13,8 +13,10 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "common.h"
@@ -80,6 +82,300 @@ void triangulate(const std::vector<int> &loop, std::vector<std::array<int, 3>> &
     if (!clip(poly, out, true)) { poly = loop; clip(poly, out, false); }
 }
 
+// ---- the CLASSIC table (round 5, the default) ------------------------------------------------------------------------------
+// Both meshers the reference calls - PyMCubes above 256^3 (lib/common/seg3d_lossless.py:592), kaolin's voxelgrids_to_
+// trianglemeshes at 256^3 (:599) - are the classic marching cubes with the published 256-case triangle table (Lorensen & Cline
+// 1987 as tabulated by Bloyd / Bourke, "Polygonising a scalar field", public domain): bit m of the case index is set when corner
+// m lies BELOW the level (PyMCubes: v[m] <= isovalue), corners 0..7 at (x,y,z) = 000 100 110 010 001 101 111 011, edge e between
+// kClassicEdge[e], and PyMCubes reads a numpy array's axes (0, 1, 2) as the cube's (x, y, z).  The generated table below (rounds
+// 1-4) cuts the INSIDE corners of an ambiguous face off from each other; the classic one cuts the corners BELOW the level off -
+// the opposite decision in the 120 configurations that have an ambiguous face (0.14 % of the surface cells of the 513^3 test
+// volume), and other diagonals in 82 more.  With this table a cube is triangulated exactly as the published algorithm does it
+// (tests/test_mesh_tools.py::test_product_table_is_the_classic_table against the checker's own restatement; neither package is in this image,
+// so "as the reference's meshers do it" remains unverified).  Row: triangle count, then up to 5 x 3 edge ids.
+// ICON_AMD_MC_TABLE=generated selects the table of rounds 1-4.
+const int8_t kClassic[256][16] = {
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 8, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 1, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 1, 8, 3, 9, 8, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 1, 2, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 8, 3, 1, 2, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 9, 2, 10, 0, 2, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 2, 8, 3, 2, 10, 8, 10, 9, 8, 0, 0, 0, 0, 0, 0},
+    {1, 3, 11, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 11, 2, 8, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 1, 9, 0, 2, 3, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 1, 11, 2, 1, 9, 11, 9, 8, 11, 0, 0, 0, 0, 0, 0},
+    {2, 3, 10, 1, 11, 10, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 0, 10, 1, 0, 8, 10, 8, 11, 10, 0, 0, 0, 0, 0, 0},
+    {3, 3, 9, 0, 3, 11, 9, 11, 10, 9, 0, 0, 0, 0, 0, 0},
+    {2, 9, 8, 10, 10, 8, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 4, 7, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 4, 3, 0, 7, 3, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 1, 9, 8, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 4, 1, 9, 4, 7, 1, 7, 3, 1, 0, 0, 0, 0, 0, 0},
+    {2, 1, 2, 10, 8, 4, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 3, 4, 7, 3, 0, 4, 1, 2, 10, 0, 0, 0, 0, 0, 0},
+    {3, 9, 2, 10, 9, 0, 2, 8, 4, 7, 0, 0, 0, 0, 0, 0},
+    {4, 2, 10, 9, 2, 9, 7, 2, 7, 3, 7, 9, 4, 0, 0, 0},
+    {2, 8, 4, 7, 3, 11, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 11, 4, 7, 11, 2, 4, 2, 0, 4, 0, 0, 0, 0, 0, 0},
+    {3, 9, 0, 1, 8, 4, 7, 2, 3, 11, 0, 0, 0, 0, 0, 0},
+    {4, 4, 7, 11, 9, 4, 11, 9, 11, 2, 9, 2, 1, 0, 0, 0},
+    {3, 3, 10, 1, 3, 11, 10, 7, 8, 4, 0, 0, 0, 0, 0, 0},
+    {4, 1, 11, 10, 1, 4, 11, 1, 0, 4, 7, 11, 4, 0, 0, 0},
+    {4, 4, 7, 8, 9, 0, 11, 9, 11, 10, 11, 0, 3, 0, 0, 0},
+    {3, 4, 7, 11, 4, 11, 9, 9, 11, 10, 0, 0, 0, 0, 0, 0},
+    {1, 9, 5, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 9, 5, 4, 0, 8, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 5, 4, 1, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 8, 5, 4, 8, 3, 5, 3, 1, 5, 0, 0, 0, 0, 0, 0},
+    {2, 1, 2, 10, 9, 5, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 3, 0, 8, 1, 2, 10, 4, 9, 5, 0, 0, 0, 0, 0, 0},
+    {3, 5, 2, 10, 5, 4, 2, 4, 0, 2, 0, 0, 0, 0, 0, 0},
+    {4, 2, 10, 5, 3, 2, 5, 3, 5, 4, 3, 4, 8, 0, 0, 0},
+    {2, 9, 5, 4, 2, 3, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 0, 11, 2, 0, 8, 11, 4, 9, 5, 0, 0, 0, 0, 0, 0},
+    {3, 0, 5, 4, 0, 1, 5, 2, 3, 11, 0, 0, 0, 0, 0, 0},
+    {4, 2, 1, 5, 2, 5, 8, 2, 8, 11, 4, 8, 5, 0, 0, 0},
+    {3, 10, 3, 11, 10, 1, 3, 9, 5, 4, 0, 0, 0, 0, 0, 0},
+    {4, 4, 9, 5, 0, 8, 1, 8, 10, 1, 8, 11, 10, 0, 0, 0},
+    {4, 5, 4, 0, 5, 0, 11, 5, 11, 10, 11, 0, 3, 0, 0, 0},
+    {3, 5, 4, 8, 5, 8, 10, 10, 8, 11, 0, 0, 0, 0, 0, 0},
+    {2, 9, 7, 8, 5, 7, 9, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 9, 3, 0, 9, 5, 3, 5, 7, 3, 0, 0, 0, 0, 0, 0},
+    {3, 0, 7, 8, 0, 1, 7, 1, 5, 7, 0, 0, 0, 0, 0, 0},
+    {2, 1, 5, 3, 3, 5, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 9, 7, 8, 9, 5, 7, 10, 1, 2, 0, 0, 0, 0, 0, 0},
+    {4, 10, 1, 2, 9, 5, 0, 5, 3, 0, 5, 7, 3, 0, 0, 0},
+    {4, 8, 0, 2, 8, 2, 5, 8, 5, 7, 10, 5, 2, 0, 0, 0},
+    {3, 2, 10, 5, 2, 5, 3, 3, 5, 7, 0, 0, 0, 0, 0, 0},
+    {3, 7, 9, 5, 7, 8, 9, 3, 11, 2, 0, 0, 0, 0, 0, 0},
+    {4, 9, 5, 7, 9, 7, 2, 9, 2, 0, 2, 7, 11, 0, 0, 0},
+    {4, 2, 3, 11, 0, 1, 8, 1, 7, 8, 1, 5, 7, 0, 0, 0},
+    {3, 11, 2, 1, 11, 1, 7, 7, 1, 5, 0, 0, 0, 0, 0, 0},
+    {4, 9, 5, 8, 8, 5, 7, 10, 1, 3, 10, 3, 11, 0, 0, 0},
+    {5, 5, 7, 0, 5, 0, 9, 7, 11, 0, 1, 0, 10, 11, 10, 0},
+    {5, 11, 10, 0, 11, 0, 3, 10, 5, 0, 8, 0, 7, 5, 7, 0},
+    {2, 11, 10, 5, 7, 11, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 10, 6, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 8, 3, 5, 10, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 9, 0, 1, 5, 10, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 1, 8, 3, 1, 9, 8, 5, 10, 6, 0, 0, 0, 0, 0, 0},
+    {2, 1, 6, 5, 2, 6, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 1, 6, 5, 1, 2, 6, 3, 0, 8, 0, 0, 0, 0, 0, 0},
+    {3, 9, 6, 5, 9, 0, 6, 0, 2, 6, 0, 0, 0, 0, 0, 0},
+    {4, 5, 9, 8, 5, 8, 2, 5, 2, 6, 3, 2, 8, 0, 0, 0},
+    {2, 2, 3, 11, 10, 6, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 11, 0, 8, 11, 2, 0, 10, 6, 5, 0, 0, 0, 0, 0, 0},
+    {3, 0, 1, 9, 2, 3, 11, 5, 10, 6, 0, 0, 0, 0, 0, 0},
+    {4, 5, 10, 6, 1, 9, 2, 9, 11, 2, 9, 8, 11, 0, 0, 0},
+    {3, 6, 3, 11, 6, 5, 3, 5, 1, 3, 0, 0, 0, 0, 0, 0},
+    {4, 0, 8, 11, 0, 11, 5, 0, 5, 1, 5, 11, 6, 0, 0, 0},
+    {4, 3, 11, 6, 0, 3, 6, 0, 6, 5, 0, 5, 9, 0, 0, 0},
+    {3, 6, 5, 9, 6, 9, 11, 11, 9, 8, 0, 0, 0, 0, 0, 0},
+    {2, 5, 10, 6, 4, 7, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 4, 3, 0, 4, 7, 3, 6, 5, 10, 0, 0, 0, 0, 0, 0},
+    {3, 1, 9, 0, 5, 10, 6, 8, 4, 7, 0, 0, 0, 0, 0, 0},
+    {4, 10, 6, 5, 1, 9, 7, 1, 7, 3, 7, 9, 4, 0, 0, 0},
+    {3, 6, 1, 2, 6, 5, 1, 4, 7, 8, 0, 0, 0, 0, 0, 0},
+    {4, 1, 2, 5, 5, 2, 6, 3, 0, 4, 3, 4, 7, 0, 0, 0},
+    {4, 8, 4, 7, 9, 0, 5, 0, 6, 5, 0, 2, 6, 0, 0, 0},
+    {5, 7, 3, 9, 7, 9, 4, 3, 2, 9, 5, 9, 6, 2, 6, 9},
+    {3, 3, 11, 2, 7, 8, 4, 10, 6, 5, 0, 0, 0, 0, 0, 0},
+    {4, 5, 10, 6, 4, 7, 2, 4, 2, 0, 2, 7, 11, 0, 0, 0},
+    {4, 0, 1, 9, 4, 7, 8, 2, 3, 11, 5, 10, 6, 0, 0, 0},
+    {5, 9, 2, 1, 9, 11, 2, 9, 4, 11, 7, 11, 4, 5, 10, 6},
+    {4, 8, 4, 7, 3, 11, 5, 3, 5, 1, 5, 11, 6, 0, 0, 0},
+    {5, 5, 1, 11, 5, 11, 6, 1, 0, 11, 7, 11, 4, 0, 4, 11},
+    {5, 0, 5, 9, 0, 6, 5, 0, 3, 6, 11, 6, 3, 8, 4, 7},
+    {4, 6, 5, 9, 6, 9, 11, 4, 7, 9, 7, 11, 9, 0, 0, 0},
+    {2, 10, 4, 9, 6, 4, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 4, 10, 6, 4, 9, 10, 0, 8, 3, 0, 0, 0, 0, 0, 0},
+    {3, 10, 0, 1, 10, 6, 0, 6, 4, 0, 0, 0, 0, 0, 0, 0},
+    {4, 8, 3, 1, 8, 1, 6, 8, 6, 4, 6, 1, 10, 0, 0, 0},
+    {3, 1, 4, 9, 1, 2, 4, 2, 6, 4, 0, 0, 0, 0, 0, 0},
+    {4, 3, 0, 8, 1, 2, 9, 2, 4, 9, 2, 6, 4, 0, 0, 0},
+    {2, 0, 2, 4, 4, 2, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 8, 3, 2, 8, 2, 4, 4, 2, 6, 0, 0, 0, 0, 0, 0},
+    {3, 10, 4, 9, 10, 6, 4, 11, 2, 3, 0, 0, 0, 0, 0, 0},
+    {4, 0, 8, 2, 2, 8, 11, 4, 9, 10, 4, 10, 6, 0, 0, 0},
+    {4, 3, 11, 2, 0, 1, 6, 0, 6, 4, 6, 1, 10, 0, 0, 0},
+    {5, 6, 4, 1, 6, 1, 10, 4, 8, 1, 2, 1, 11, 8, 11, 1},
+    {4, 9, 6, 4, 9, 3, 6, 9, 1, 3, 11, 6, 3, 0, 0, 0},
+    {5, 8, 11, 1, 8, 1, 0, 11, 6, 1, 9, 1, 4, 6, 4, 1},
+    {3, 3, 11, 6, 3, 6, 0, 0, 6, 4, 0, 0, 0, 0, 0, 0},
+    {2, 6, 4, 8, 11, 6, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 7, 10, 6, 7, 8, 10, 8, 9, 10, 0, 0, 0, 0, 0, 0},
+    {4, 0, 7, 3, 0, 10, 7, 0, 9, 10, 6, 7, 10, 0, 0, 0},
+    {4, 10, 6, 7, 1, 10, 7, 1, 7, 8, 1, 8, 0, 0, 0, 0},
+    {3, 10, 6, 7, 10, 7, 1, 1, 7, 3, 0, 0, 0, 0, 0, 0},
+    {4, 1, 2, 6, 1, 6, 8, 1, 8, 9, 8, 6, 7, 0, 0, 0},
+    {5, 2, 6, 9, 2, 9, 1, 6, 7, 9, 0, 9, 3, 7, 3, 9},
+    {3, 7, 8, 0, 7, 0, 6, 6, 0, 2, 0, 0, 0, 0, 0, 0},
+    {2, 7, 3, 2, 6, 7, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 2, 3, 11, 10, 6, 8, 10, 8, 9, 8, 6, 7, 0, 0, 0},
+    {5, 2, 0, 7, 2, 7, 11, 0, 9, 7, 6, 7, 10, 9, 10, 7},
+    {5, 1, 8, 0, 1, 7, 8, 1, 10, 7, 6, 7, 10, 2, 3, 11},
+    {4, 11, 2, 1, 11, 1, 7, 10, 6, 1, 6, 7, 1, 0, 0, 0},
+    {5, 8, 9, 6, 8, 6, 7, 9, 1, 6, 11, 6, 3, 1, 3, 6},
+    {2, 0, 9, 1, 11, 6, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 7, 8, 0, 7, 0, 6, 3, 11, 0, 11, 6, 0, 0, 0, 0},
+    {1, 7, 11, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 7, 6, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 3, 0, 8, 11, 7, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 0, 1, 9, 11, 7, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 8, 1, 9, 8, 3, 1, 11, 7, 6, 0, 0, 0, 0, 0, 0},
+    {2, 10, 1, 2, 6, 11, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 1, 2, 10, 3, 0, 8, 6, 11, 7, 0, 0, 0, 0, 0, 0},
+    {3, 2, 9, 0, 2, 10, 9, 6, 11, 7, 0, 0, 0, 0, 0, 0},
+    {4, 6, 11, 7, 2, 10, 3, 10, 8, 3, 10, 9, 8, 0, 0, 0},
+    {2, 7, 2, 3, 6, 2, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 7, 0, 8, 7, 6, 0, 6, 2, 0, 0, 0, 0, 0, 0, 0},
+    {3, 2, 7, 6, 2, 3, 7, 0, 1, 9, 0, 0, 0, 0, 0, 0},
+    {4, 1, 6, 2, 1, 8, 6, 1, 9, 8, 8, 7, 6, 0, 0, 0},
+    {3, 10, 7, 6, 10, 1, 7, 1, 3, 7, 0, 0, 0, 0, 0, 0},
+    {4, 10, 7, 6, 1, 7, 10, 1, 8, 7, 1, 0, 8, 0, 0, 0},
+    {4, 0, 3, 7, 0, 7, 10, 0, 10, 9, 6, 10, 7, 0, 0, 0},
+    {3, 7, 6, 10, 7, 10, 8, 8, 10, 9, 0, 0, 0, 0, 0, 0},
+    {2, 6, 8, 4, 11, 8, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 3, 6, 11, 3, 0, 6, 0, 4, 6, 0, 0, 0, 0, 0, 0},
+    {3, 8, 6, 11, 8, 4, 6, 9, 0, 1, 0, 0, 0, 0, 0, 0},
+    {4, 9, 4, 6, 9, 6, 3, 9, 3, 1, 11, 3, 6, 0, 0, 0},
+    {3, 6, 8, 4, 6, 11, 8, 2, 10, 1, 0, 0, 0, 0, 0, 0},
+    {4, 1, 2, 10, 3, 0, 11, 0, 6, 11, 0, 4, 6, 0, 0, 0},
+    {4, 4, 11, 8, 4, 6, 11, 0, 2, 9, 2, 10, 9, 0, 0, 0},
+    {5, 10, 9, 3, 10, 3, 2, 9, 4, 3, 11, 3, 6, 4, 6, 3},
+    {3, 8, 2, 3, 8, 4, 2, 4, 6, 2, 0, 0, 0, 0, 0, 0},
+    {2, 0, 4, 2, 4, 6, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 1, 9, 0, 2, 3, 4, 2, 4, 6, 4, 3, 8, 0, 0, 0},
+    {3, 1, 9, 4, 1, 4, 2, 2, 4, 6, 0, 0, 0, 0, 0, 0},
+    {4, 8, 1, 3, 8, 6, 1, 8, 4, 6, 6, 10, 1, 0, 0, 0},
+    {3, 10, 1, 0, 10, 0, 6, 6, 0, 4, 0, 0, 0, 0, 0, 0},
+    {5, 4, 6, 3, 4, 3, 8, 6, 10, 3, 0, 3, 9, 10, 9, 3},
+    {2, 10, 9, 4, 6, 10, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 4, 9, 5, 7, 6, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 0, 8, 3, 4, 9, 5, 11, 7, 6, 0, 0, 0, 0, 0, 0},
+    {3, 5, 0, 1, 5, 4, 0, 7, 6, 11, 0, 0, 0, 0, 0, 0},
+    {4, 11, 7, 6, 8, 3, 4, 3, 5, 4, 3, 1, 5, 0, 0, 0},
+    {3, 9, 5, 4, 10, 1, 2, 7, 6, 11, 0, 0, 0, 0, 0, 0},
+    {4, 6, 11, 7, 1, 2, 10, 0, 8, 3, 4, 9, 5, 0, 0, 0},
+    {4, 7, 6, 11, 5, 4, 10, 4, 2, 10, 4, 0, 2, 0, 0, 0},
+    {5, 3, 4, 8, 3, 5, 4, 3, 2, 5, 10, 5, 2, 11, 7, 6},
+    {3, 7, 2, 3, 7, 6, 2, 5, 4, 9, 0, 0, 0, 0, 0, 0},
+    {4, 9, 5, 4, 0, 8, 6, 0, 6, 2, 6, 8, 7, 0, 0, 0},
+    {4, 3, 6, 2, 3, 7, 6, 1, 5, 0, 5, 4, 0, 0, 0, 0},
+    {5, 6, 2, 8, 6, 8, 7, 2, 1, 8, 4, 8, 5, 1, 5, 8},
+    {4, 9, 5, 4, 10, 1, 6, 1, 7, 6, 1, 3, 7, 0, 0, 0},
+    {5, 1, 6, 10, 1, 7, 6, 1, 0, 7, 8, 7, 0, 9, 5, 4},
+    {5, 4, 0, 10, 4, 10, 5, 0, 3, 10, 6, 10, 7, 3, 7, 10},
+    {4, 7, 6, 10, 7, 10, 8, 5, 4, 10, 4, 8, 10, 0, 0, 0},
+    {3, 6, 9, 5, 6, 11, 9, 11, 8, 9, 0, 0, 0, 0, 0, 0},
+    {4, 3, 6, 11, 0, 6, 3, 0, 5, 6, 0, 9, 5, 0, 0, 0},
+    {4, 0, 11, 8, 0, 5, 11, 0, 1, 5, 5, 6, 11, 0, 0, 0},
+    {3, 6, 11, 3, 6, 3, 5, 5, 3, 1, 0, 0, 0, 0, 0, 0},
+    {4, 1, 2, 10, 9, 5, 11, 9, 11, 8, 11, 5, 6, 0, 0, 0},
+    {5, 0, 11, 3, 0, 6, 11, 0, 9, 6, 5, 6, 9, 1, 2, 10},
+    {5, 11, 8, 5, 11, 5, 6, 8, 0, 5, 10, 5, 2, 0, 2, 5},
+    {4, 6, 11, 3, 6, 3, 5, 2, 10, 3, 10, 5, 3, 0, 0, 0},
+    {4, 5, 8, 9, 5, 2, 8, 5, 6, 2, 3, 8, 2, 0, 0, 0},
+    {3, 9, 5, 6, 9, 6, 0, 0, 6, 2, 0, 0, 0, 0, 0, 0},
+    {5, 1, 5, 8, 1, 8, 0, 5, 6, 8, 3, 8, 2, 6, 2, 8},
+    {2, 1, 5, 6, 2, 1, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {5, 1, 3, 6, 1, 6, 10, 3, 8, 6, 5, 6, 9, 8, 9, 6},
+    {4, 10, 1, 0, 10, 0, 6, 9, 5, 0, 5, 6, 0, 0, 0, 0},
+    {2, 0, 3, 8, 5, 6, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 10, 5, 6, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 11, 5, 10, 7, 5, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 11, 5, 10, 11, 7, 5, 8, 3, 0, 0, 0, 0, 0, 0, 0},
+    {3, 5, 11, 7, 5, 10, 11, 1, 9, 0, 0, 0, 0, 0, 0, 0},
+    {4, 10, 7, 5, 10, 11, 7, 9, 8, 1, 8, 3, 1, 0, 0, 0},
+    {3, 11, 1, 2, 11, 7, 1, 7, 5, 1, 0, 0, 0, 0, 0, 0},
+    {4, 0, 8, 3, 1, 2, 7, 1, 7, 5, 7, 2, 11, 0, 0, 0},
+    {4, 9, 7, 5, 9, 2, 7, 9, 0, 2, 2, 11, 7, 0, 0, 0},
+    {5, 7, 5, 2, 7, 2, 11, 5, 9, 2, 3, 2, 8, 9, 8, 2},
+    {3, 2, 5, 10, 2, 3, 5, 3, 7, 5, 0, 0, 0, 0, 0, 0},
+    {4, 8, 2, 0, 8, 5, 2, 8, 7, 5, 10, 2, 5, 0, 0, 0},
+    {4, 9, 0, 1, 5, 10, 3, 5, 3, 7, 3, 10, 2, 0, 0, 0},
+    {5, 9, 8, 2, 9, 2, 1, 8, 7, 2, 10, 2, 5, 7, 5, 2},
+    {2, 1, 3, 5, 3, 7, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 0, 8, 7, 0, 7, 1, 1, 7, 5, 0, 0, 0, 0, 0, 0},
+    {3, 9, 0, 3, 9, 3, 5, 5, 3, 7, 0, 0, 0, 0, 0, 0},
+    {2, 9, 8, 7, 5, 9, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 5, 8, 4, 5, 10, 8, 10, 11, 8, 0, 0, 0, 0, 0, 0},
+    {4, 5, 0, 4, 5, 11, 0, 5, 10, 11, 11, 3, 0, 0, 0, 0},
+    {4, 0, 1, 9, 8, 4, 10, 8, 10, 11, 10, 4, 5, 0, 0, 0},
+    {5, 10, 11, 4, 10, 4, 5, 11, 3, 4, 9, 4, 1, 3, 1, 4},
+    {4, 2, 5, 1, 2, 8, 5, 2, 11, 8, 4, 5, 8, 0, 0, 0},
+    {5, 0, 4, 11, 0, 11, 3, 4, 5, 11, 2, 11, 1, 5, 1, 11},
+    {5, 0, 2, 5, 0, 5, 9, 2, 11, 5, 4, 5, 8, 11, 8, 5},
+    {2, 9, 4, 5, 2, 11, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 2, 5, 10, 3, 5, 2, 3, 4, 5, 3, 8, 4, 0, 0, 0},
+    {3, 5, 10, 2, 5, 2, 4, 4, 2, 0, 0, 0, 0, 0, 0, 0},
+    {5, 3, 10, 2, 3, 5, 10, 3, 8, 5, 4, 5, 8, 0, 1, 9},
+    {4, 5, 10, 2, 5, 2, 4, 1, 9, 2, 9, 4, 2, 0, 0, 0},
+    {3, 8, 4, 5, 8, 5, 3, 3, 5, 1, 0, 0, 0, 0, 0, 0},
+    {2, 0, 4, 5, 1, 0, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 8, 4, 5, 8, 5, 3, 9, 0, 5, 0, 3, 5, 0, 0, 0},
+    {1, 9, 4, 5, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 4, 11, 7, 4, 9, 11, 9, 10, 11, 0, 0, 0, 0, 0, 0},
+    {4, 0, 8, 3, 4, 9, 7, 9, 11, 7, 9, 10, 11, 0, 0, 0},
+    {4, 1, 10, 11, 1, 11, 4, 1, 4, 0, 7, 4, 11, 0, 0, 0},
+    {5, 3, 1, 4, 3, 4, 8, 1, 10, 4, 7, 4, 11, 10, 11, 4},
+    {4, 4, 11, 7, 9, 11, 4, 9, 2, 11, 9, 1, 2, 0, 0, 0},
+    {5, 9, 7, 4, 9, 11, 7, 9, 1, 11, 2, 11, 1, 0, 8, 3},
+    {3, 11, 7, 4, 11, 4, 2, 2, 4, 0, 0, 0, 0, 0, 0, 0},
+    {4, 11, 7, 4, 11, 4, 2, 8, 3, 4, 3, 2, 4, 0, 0, 0},
+    {4, 2, 9, 10, 2, 7, 9, 2, 3, 7, 7, 4, 9, 0, 0, 0},
+    {5, 9, 10, 7, 9, 7, 4, 10, 2, 7, 8, 7, 0, 2, 0, 7},
+    {5, 3, 7, 10, 3, 10, 2, 7, 4, 10, 1, 10, 0, 4, 0, 10},
+    {2, 1, 10, 2, 8, 7, 4, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 4, 9, 1, 4, 1, 7, 7, 1, 3, 0, 0, 0, 0, 0, 0},
+    {4, 4, 9, 1, 4, 1, 7, 0, 8, 1, 8, 7, 1, 0, 0, 0},
+    {2, 4, 0, 3, 7, 4, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 4, 8, 7, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 9, 10, 8, 10, 11, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 3, 0, 9, 3, 9, 11, 11, 9, 10, 0, 0, 0, 0, 0, 0},
+    {3, 0, 1, 10, 0, 10, 8, 8, 10, 11, 0, 0, 0, 0, 0, 0},
+    {2, 3, 1, 10, 11, 3, 10, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 1, 2, 11, 1, 11, 9, 9, 11, 8, 0, 0, 0, 0, 0, 0},
+    {4, 3, 0, 9, 3, 9, 11, 1, 2, 9, 2, 11, 9, 0, 0, 0},
+    {2, 0, 2, 11, 8, 0, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 3, 2, 11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {3, 2, 3, 8, 2, 8, 10, 10, 8, 9, 0, 0, 0, 0, 0, 0},
+    {2, 9, 10, 2, 0, 9, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {4, 2, 3, 8, 2, 8, 10, 0, 1, 8, 1, 10, 8, 0, 0, 0},
+    {1, 1, 10, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {2, 1, 3, 8, 9, 1, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 9, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {1, 0, 3, 8, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+    {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0},
+};
+const int kClassicCorner[8][3] = {{0, 0, 0}, {1, 0, 0}, {1, 1, 0}, {0, 1, 0}, {0, 0, 1}, {1, 0, 1}, {1, 1, 1}, {0, 1, 1}};
+const int kClassicEdge[12][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {4, 5}, {5, 6}, {6, 7}, {7, 4}, {0, 4}, {1, 5}, {2, 6}, {3, 7}};
+
+void build_classic()
+{
+    // Bourke corner m at (bx, by, bz) = array axes (0, 1, 2) of the volume [z][y][x]: our corner id x + 2 y + 4 z with x = bz, y = by, z = bx
+    int ours[8];
+    for (int m = 0; m < 8; ++m) ours[m] = kClassicCorner[m][2] + 2 * kClassicCorner[m][1] + 4 * kClassicCorner[m][0];
+    for (int c = 0; c < 256; ++c) {                          // c: OUR case index (bit k = our corner k is inside, occ > level)
+        int cb = 0;                                          // the classic index: bit m = Bourke corner m is NOT inside (v <= level)
+        for (int m = 0; m < 8; ++m) if (!((c >> ours[m]) & 1)) cb |= 1 << m;
+        g_case_tris[c].clear();
+        for (int k = 0; k < kClassic[cb][0]; ++k) {
+            int e[3];
+            for (int q = 0; q < 3; ++q) {
+                const int be = kClassic[cb][1 + 3 * k + q];
+                e[q] = g_edge_of[ours[kClassicEdge[be][0]]][ours[kClassicEdge[be][1]]];
+            }
+            // the reference swaps the vertex columns to (x, y, z) and flips the winding (seg3d_lossless.py:593-594: faces[:, [0, 2, 1]])
+            g_case_tris[c].push_back({e[0], e[2], e[1]});
+        }
+    }
+}
+
 void build_tables()
 {
     int ne = 0;
@@ -89,6 +385,8 @@ void build_tables()
             const int b = a | bit;
             if (b != a) { g_edges[ne] = {a, b}; g_edge_of[a][b] = g_edge_of[b][a] = ne; ++ne; }
         }
+    const char *which = getenv("ICON_AMD_MC_TABLE");
+    if (!(which && std::string(which) == "generated")) { build_classic(); return; }
     for (int c = 0; c < 256; ++c) {
         // directed segments (from edge -> to edge), inside region on the left seen from outside
         int next[12];

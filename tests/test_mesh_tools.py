@@ -7,11 +7,16 @@ characteristic; clean_mesh against a numpy restatement of lib/dataset/mesh_util.
 against the reference's own output (tests/golden/display_33.npz, made by running Seg3dLossless.display
 verbatim - tools/make_golden.py section g).
 """
+import json
+import os
+import subprocess
+import sys
+
 import numpy as np
 import pytest
 import torch
 
-from common import assets, golden
+from common import ROOT, assets, golden
 from icon_amd.recon import DenseReconEngine, export_mesh_numpy
 from oracle import mc_check
 
@@ -192,36 +197,53 @@ def test_classic_table_is_mechanically_valid():
             assert t["one_cube"] and t["used_all"] and t["oriented"] and t["closed"], (n, below, t)
 
 
-def test_product_table_vs_classic_table():
-    """Per cube configuration (Bourke's numbering; PyMCubes reads a numpy array's axes (0,1,2) as the cube's (x,y,z)): does the
-    product's generated table give the classic table's triangle SET, the same surface loops with other diagonals, or another
-    surface?  Under the reading "bit set = corner ABOVE the level": the same loops in all 256 configurations (the product cuts
-    the inside corners of an ambiguous face off from each other - Bourke's rule for his set corners), 107 identical triangle sets.
-    Under "bit set = corner BELOW the level" (Bourke's text, PyMCubes as recalled): 120 configurations with an ambiguous face
-    are resolved the other way round.  DESIGN.md section 4.5 lists them; this test pins the list."""
+def _cyc(t):
+    t = list(t); k = t.index(min(t)); return tuple(t[k:] + t[:k])
+
+
+def test_product_table_is_the_classic_table():
+    """Round 5: the product's case table IS the published classic table, read as PyMCubes reads a numpy array (axes (0,1,2) =
+    the cube's (x,y,z), bit set = corner at or below the level) and wound as the reference leaves it (faces[:, [0, 2, 1]],
+    lib/common/seg3d_lossless.py:594): per cube configuration the same triangles, the same winding - all 256."""
     from oracle import mc_classic
-    above = mc_classic.compare_tables(mc_classic.TRI_TABLE, mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=True))
-    assert above["topology"] == [] and len(above["same"]) == 107 and len(above["triangulation"]) == 149
-    below = mc_classic.compare_tables(mc_classic.TRI_TABLE, mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=False))
-    assert len(below["topology"]) == 120 and len(below["same"]) == 54 and len(below["triangulation"]) == 82
-    # a configuration differs in topology under the second reading exactly when one of its faces is ambiguous
-    amb = [c for c in range(256) if any([(c >> m) & 1 for m in f] in ([1, 0, 1, 0], [0, 1, 0, 1]) for f in mc_classic.FACES.tolist())]
-    assert sorted(below["topology"]) == amb
-    # orientation: the reference flips PyMCubes' faces (seg3d_lossless.py:594: faces[:, [0, 2, 1]]); wherever the triangle sets agree
-    # the product's winding is the classic winding under ONE of the two readings consistently
-    def cyc(t):
-        t = list(t); k = t.index(min(t)); return tuple(t[k:] + t[:k])
     prod = mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=False)
-    for c in below["same"]:
-        assert {cyc(t[[0, 2, 1]]) for t in mc_classic.TRI_TABLE[c]} == {cyc(t) for t in prod[c]}, c
+    r = mc_classic.compare_tables(mc_classic.TRI_TABLE, prod)
+    assert len(r["same"]) == 256, {k: v[:8] for k, v in r.items() if k != "same"}
+    for c in range(256):
+        assert {_cyc(t[[0, 2, 1]]) for t in mc_classic.TRI_TABLE[c]} == {_cyc(t) for t in prod[c]}, c
+
+
+def test_generated_table_vs_classic_table():
+    """The table of rounds 1-4 (ICON_AMD_MC_TABLE=generated: per-face marching squares, the INSIDE corners of an ambiguous face
+    cut off from each other, ear-clipped loops) against the classic one, per configuration - the list DESIGN.md section 4.5
+    quotes.  Under the reading "bit set = corner ABOVE the level": the same surface loops in all 256 configurations, 107 identical
+    triangle sets, other diagonals in 149.  Under "bit set = corner BELOW the level" (Bourke's text; PyMCubes and kaolin as
+    recalled): the 120 configurations with an ambiguous face are resolved the other way round, 82 more differ in diagonals."""
+    code = ("import sys, json, numpy as np\n"
+            "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "from oracle import mc_classic\n"
+            "from test_mesh_tools import _product_mesher\n"
+            "out = {}\n"
+            "for name, inside in (('above', True), ('below', False)):\n"
+            "    r = mc_classic.compare_tables(mc_classic.TRI_TABLE, mc_classic.case_tris_from_mesher(_product_mesher, set_is_inside=inside))\n"
+            "    out[name] = r\n"
+            "print('RESULT' + json.dumps(out))\n") % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, ICON_AMD_MC_TABLE="generated")
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("RESULT")][-1][6:])
+    above, below = out["above"], out["below"]
+    assert above["topology"] == [] and len(above["same"]) == 107 and len(above["triangulation"]) == 149
+    assert len(below["topology"]) == 120 and len(below["same"]) == 54 and len(below["triangulation"]) == 82
+    from oracle import mc_classic
+    amb = [c for c in range(256) if any([(c >> m) & 1 for m in f] in ([1, 0, 1, 0], [0, 1, 0, 1]) for f in mc_classic.FACES.tolist())]
+    assert sorted(below["topology"]) == amb          # they part exactly where a face is ambiguous
 
 
 def test_classic_marching_cubes_on_the_body_volume():
-    """the reference's own dense 33^3 volume: the classic algorithm and the product give the SAME vertex set (every edge
-    crossing) under either reading of the case bit; under "set = above the level" also the same number of faces (the same loops in
-    every configuration: a loop of k crossings is k - 2 triangles however it is cut); under "set = below" the 28 cells of this
-    volume with an ambiguous face (of the 629 cells the surface passes through at this coarse resolution) are where the two
-    surfaces differ - and nowhere else"""
+    """the reference's own dense 33^3 volume: the classic algorithm (oracle/mc_classic.py, read as PyMCubes reads the array) and the
+    product give the same vertex set AND the same triangles - compared as sets of vertex-position triples, all of them, the 28
+    cells of this volume with an ambiguous face (of the 629 the surface passes through) included"""
     from oracle import mc_classic
     body = golden("seg3d_body_dense33.npz")["occ"]
     pv, pf = export_mesh_numpy(body, 0.5)
@@ -232,17 +254,11 @@ def test_classic_marching_cubes_on_the_body_volume():
     for m, (dx, dy, dz) in enumerate(mc_classic.CORNERS):
         idx |= s[dx:n0 - 1 + dx, dy:n1 - 1 + dy, dz:n2 - 1 + dz].astype(np.int64) << m
     amb = [c for c in range(256) if any([(c >> m) & 1 for m in f] in ([1, 0, 1, 0], [0, 1, 0, 1]) for f in mc_classic.FACES.tolist())]
-    n_amb = int(np.isin(idx, amb).sum())
-    n_surface = int(((idx > 0) & (idx < 255)).sum())
-    assert n_amb == 28 and n_surface == 629
-    for below in (True, False):
-        cv, cf = mc_classic.marching_cubes(body[1:, 1:, 1:], 0.5, set_below=below)
-        assert mc_check.same_point_set(cv, pv)
-        if not below:
-            assert len(cf) == len(pf)
-            # ... and outside the configurations whose diagonals differ, the same triangles: compare as sets of vertex-position triples
-            key = lambda v, f: {tuple(sorted(map(tuple, np.round(v[t] * 4096).astype(np.int64).tolist()))) for t in f}
-            a, b = key(cv, cf), key(pv, pf.numpy())
-            assert len(a & b) > 0.3 * len(a)
-        else:
-            assert abs(len(cf) - len(pf)) <= 2 * n_amb
+    assert int(np.isin(idx, amb).sum()) == 28 and int(((idx > 0) & (idx < 255)).sum()) == 629
+    cv, cf = mc_classic.marching_cubes(body[1:, 1:, 1:], 0.5, set_below=True)
+    assert mc_check.same_point_set(cv, pv) and len(cf) == len(pf)
+    key = lambda v, f: {tuple(sorted(map(tuple, np.round(v[t] * 4096).astype(np.int64).tolist()))) for t in f}
+    assert key(cv, cf) == key(pv, pf.numpy())
+    # the other reading of the case bit differs, and only by what those 28 cells can hold
+    ov, of = mc_classic.marching_cubes(body[1:, 1:, 1:], 0.5, set_below=False)
+    assert mc_check.same_point_set(ov, pv) and key(ov, of) != key(pv, pf.numpy()) and abs(len(of) - len(pf)) <= 2 * 28
