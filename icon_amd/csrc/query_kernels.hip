@@ -812,7 +812,7 @@ int share_waves_override()
 int work_share_dbg(icon_work *w, ShareDbg *out)
 {
     if (!w->h_err) {
-        ICON_HIP(hipHostMalloc((void **)&w->h_err, 8 * sizeof(int), hipHostMallocMapped));
+        ICON_HIP(hipHostMalloc((void **)&w->h_err, 8 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable));   // (portable: a process may drive several devices)
         memset(w->h_err, 0, 8 * sizeof(int));
     }
     void *dev = nullptr;

@@ -67,6 +67,15 @@ def test_argument_errors_have_messages():
     assert rc == 1 and b"null" in lib.icon_last_error()
     nv, nf = C.c_int64(0), C.c_int64(0)
     assert lib.icon_export_mesh(None, C.c_int(5), C.c_float(0.5), None, C.byref(nv), None, C.byref(nf)) == 1
+    # round 5: the test switches are refused by name / range, a fresh workspace has nothing to report (no device needed for either)
+    assert lib.icon_debug_set_option(b"no_such_switch", C.c_int(1)) == 1 and b"unknown key" in lib.icon_last_error()
+    assert lib.icon_debug_set_option(b"share_ring", C.c_int(3)) == 1 and lib.icon_debug_set_option(b"share_ring", C.c_int(0)) == 0
+    assert lib.icon_debug_set_option(None, C.c_int(1)) == 1
+    assert lib.icon_work_status(None) == 1
+    w = C.c_void_p(0)
+    assert lib.icon_work_create(C.byref(w)) == 0 and lib.icon_work_status(w) == 0 and lib.icon_work_destroy(w) == 0
+    out = (C.c_double * 4)()
+    assert lib.icon_work_profile_detail(None, out) == 1
 
 
 def test_product_never_touches_the_oracle():
