@@ -16,6 +16,7 @@
 //   k_mc_faces    : per cube - triangles with vertex ids looked up through the first-index array
 #include "common.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -122,6 +123,68 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_classify(const float *__restric
     }
 }
 
+// The same pass with FOUR consecutive cells of an x-row per thread (n % 4 == 0: every standard size, n = 256 / 512): the 4 cells'
+// 32 corners are 20 distinct values (5 along x in each of the 4 rows around the cells), the row addresses and the cell index are
+// computed once, flags / triangle counts leave as one aligned 32-bit word each.  A 513^3 volume is 134 M cells: the one-cell
+// form took 0.67 ms there (8 loads + a full index decode per cell; 0.8 TB/s of the 540 MB it has to read), the reference's
+// default mcube_res = 512 makes that the common case.  256 threads = the same 1,024-cell blocks as above (block_tot, the scan
+// and the emit passes are unchanged); bit-for-bit the same flags / counts (tests compare device and host marching cubes as sets).
+__global__ __launch_bounds__(kMcBlock / 4) void k_mc_classify4(const float *__restrict__ occ, int res, float level, int64_t npts,
+                                                              uint8_t *__restrict__ flags, uint8_t *__restrict__ ntri,
+                                                              unsigned long long *__restrict__ block_tot, int zc0, int zc1, int halo)
+{
+    __shared__ unsigned wsum[kMcBlock / 4 / 64];
+    const int n = res - 1;
+    const int64_t i = ((int64_t)blockIdx.x * (kMcBlock / 4) + threadIdx.x) * 4;      // first of this thread's four cells (same row: n % 4 == 0)
+    unsigned mine = 0;
+    if (i < npts) {
+        int x, y, z; mc_cell(i, n, x, y, z);
+        const bool own = z >= zc0 && z < zc1, hal = halo && z == zc1;
+        uint32_t f4 = 0, t4 = 0;
+        if (own || hal) {
+            const float *p0 = occ + ((size_t)(z + 1) * res + (y + 1)) * res + (x + 1);
+            const size_t dy = y + 1 < n ? (size_t)res : 0, dz = (z + 1 < n && own) ? (size_t)res * res : 0;
+            const int last = (x + 4 < n) ? 4 : 3;                 // the corner beyond the row's last cell repeats the last one (dx = 0 there)
+            bool in[4][5];                                        // [row: (y, z), (y+1, z), (y, z+1), (y+1, z+1)][x .. x+4]
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float *q = p0 + ((r & 1) ? dy : 0) + ((r & 2) ? dz : 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) in[r][k] = q[k] > level;
+                in[r][4] = q[last] > level;
+            }
+            const bool cube_row = own && y + 1 < n && z + 1 < n;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool has_x = x + k + 1 < n;
+                uint32_t f = in[0][k] ? 8u : 0u;
+                if (has_x && in[0][k + 1] != in[0][k]) f |= 1u;
+                if (y + 1 < n && in[1][k] != in[0][k]) f |= 2u;
+                if (own && z + 1 < n && in[2][k] != in[0][k]) f |= 4u;
+                uint32_t t = 0;
+                if (cube_row && has_x) {
+                    const int c = (in[0][k] ? 1 : 0) | (in[0][k + 1] ? 2 : 0) | (in[1][k] ? 4 : 0) | (in[1][k + 1] ? 8 : 0) |
+                                  (in[2][k] ? 16 : 0) | (in[2][k + 1] ? 32 : 0) | (in[3][k] ? 64 : 0) | (in[3][k + 1] ? 128 : 0);
+                    t = (uint32_t)(uint8_t)c_mc.tri[c][0];
+                }
+                f4 |= f << (8 * k); t4 |= t << (8 * k);
+                mine += (unsigned)__popc(f & 7u) | (t << 16);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(flags + i) = f4;            // i % 4 == 0 and the arrays come from hipMalloc: aligned
+        *reinterpret_cast<uint32_t *>(ntri + i) = t4;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long nv = 0, nt = 0;
+        for (int k = 0; k < kMcBlock / 4 / 64; ++k) { nv += wsum[k] & 0xffffu; nt += wsum[k] >> 16; }
+        block_tot[blockIdx.x] = nv | (nt << 32);
+    }
+}
+
 __device__ __forceinline__ unsigned long long mc_count(const uint8_t *flags, const uint8_t *ntri, int64_t i, int64_t npts)
 {
     if (i >= npts) return 0ull;
@@ -185,6 +248,59 @@ __global__ __launch_bounds__(1024) void k_mc_scanblocks(const unsigned long long
     if (threadIdx.x == 0) { totals[0] = carry & 0xffffffffull; totals[1] = carry >> 32; totals[2] = (unsigned long long)n_active; }
 }
 
+// The same scan in two parallel passes (round 5): a 513^3 volume has 131,072 block totals and the one-workgroup form above walks them
+// in 16 rounds - 124 us, as much as the face pass.  k_mc_scan_local: one workgroup per 8,192 totals, prefix inside the chunk +
+// the chunk's total; k_mc_scan_apply: every workgroup adds the totals of the chunks before it (<= 64 of them: summed by one wave),
+// appends its non-empty blocks to the active list (any order) and the last chunk writes the grand totals.
+constexpr int kMcChunk = 8192, kMcMaxChunks = 4096;
+__global__ __launch_bounds__(1024) void k_mc_scan_local(const unsigned long long *__restrict__ block_tot, unsigned long long *__restrict__ block_off,
+                                                        int64_t nblocks, unsigned long long *__restrict__ chunk_tot, unsigned long long *totals)
+{
+    __shared__ unsigned long long wtot[16];
+    if (blockIdx.x == 0 && threadIdx.x == 0) totals[2] = 0ull;   // the active-list counter of k_mc_scan_apply
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t i = (int64_t)blockIdx.x * kMcChunk + (int64_t)threadIdx.x * 8;
+    unsigned long long v[8], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = i + k < nblocks ? block_tot[i + k] : 0ull; sum += v[k]; }
+    unsigned long long incl = sum;
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+    if (lane == 63) wtot[w] = incl;
+    __syncthreads();
+    unsigned long long before = 0, all = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { const unsigned long long t = wtot[q]; before += q < w ? t : 0ull; all += t; }
+    unsigned long long run = before + incl - sum;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { if (i + k < nblocks) block_off[i + k] = run; run += v[k]; }
+    if (threadIdx.x == 0) chunk_tot[blockIdx.x] = all;
+}
+__global__ __launch_bounds__(1024) void k_mc_scan_apply(const unsigned long long *__restrict__ block_tot, unsigned long long *__restrict__ block_off,
+                                                        int64_t nblocks, const unsigned long long *__restrict__ chunk_tot, int nchunks,
+                                                        unsigned long long *totals, int32_t *__restrict__ active)
+{
+    __shared__ unsigned long long base_s;
+    if (threadIdx.x < 64) {                                      // the chunks before this one (and, for the last chunk, all of them)
+        unsigned long long b = 0, a = 0;
+        for (int c = threadIdx.x; c < nchunks; c += 64) { const unsigned long long t = chunk_tot[c]; a += t; b += c < (int)blockIdx.x ? t : 0ull; }
+        for (int d = 32; d >= 1; d >>= 1) { b += __shfl_xor(b, d); a += __shfl_xor(a, d); }
+        if (threadIdx.x == 0) {
+            base_s = b;
+            if ((int)blockIdx.x == nchunks - 1) { totals[0] = a & 0xffffffffull; totals[1] = a >> 32; }
+        }
+    }
+    __syncthreads();
+    const unsigned long long base = base_s;
+    const int64_t i0 = (int64_t)blockIdx.x * kMcChunk + (int64_t)threadIdx.x * 8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int64_t i = i0 + k;
+        if (i >= nblocks) break;
+        block_off[i] += base;
+        if (block_tot[i]) active[atomicAdd(&totals[2], 1ull)] = (int32_t)i;
+    }
+}
+
 __global__ __launch_bounds__(kMcBlock) void k_mc_vertices(const float *__restrict__ occ, int res, float level, int64_t npts,
                                                           const uint8_t *__restrict__ flags, const uint8_t *__restrict__ ntri,
                                                           const int32_t *__restrict__ active,
@@ -246,7 +362,7 @@ __global__ __launch_bounds__(kMcBlock) void k_mc_faces(int res, int64_t npts, co
 
 struct McDevState {
     uint8_t *flags = nullptr, *ntri = nullptr;
-    unsigned long long *block_sums = nullptr, *block_tot = nullptr, *totals = nullptr;
+    unsigned long long *block_sums = nullptr, *block_tot = nullptr, *totals = nullptr, *chunk_tot = nullptr;
     int32_t *active = nullptr; int64_t n_active = 0;      // blocks holding a vertex or a triangle
     int32_t *first_vertex = nullptr, *first_tri = nullptr;
     int64_t cap = 0;
@@ -255,7 +371,7 @@ struct McDevState {
 
 static void mc_free(McDevState *s)
 {
-    (void)hipFree(s->flags); (void)hipFree(s->ntri); (void)hipFree(s->block_sums); (void)hipFree(s->block_tot); (void)hipFree(s->totals); (void)hipFree(s->active);
+    (void)hipFree(s->flags); (void)hipFree(s->ntri); (void)hipFree(s->block_sums); (void)hipFree(s->block_tot); (void)hipFree(s->totals); (void)hipFree(s->chunk_tot); (void)hipFree(s->active);
     (void)hipFree(s->first_vertex); (void)hipFree(s->first_tri);
     *s = McDevState();
 }
@@ -295,13 +411,24 @@ extern "C" int icon_mc_count_range(const float *d_occ, int res, float level, int
         ICON_HIP(hipMalloc((void **)&s->block_sums, (size_t)nblk * sizeof(unsigned long long)));
         ICON_HIP(hipMalloc((void **)&s->block_tot, (size_t)nblk * sizeof(unsigned long long)));
         ICON_HIP(hipMalloc((void **)&s->totals, 4 * sizeof(unsigned long long)));
+        ICON_HIP(hipMalloc((void **)&s->chunk_tot, (size_t)kMcMaxChunks * sizeof(unsigned long long)));
         ICON_HIP(hipMalloc((void **)&s->active, (size_t)nblk * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&s->first_vertex, (size_t)npts * sizeof(int32_t)));
         ICON_HIP(hipMalloc((void **)&s->first_tri, (size_t)npts * sizeof(int32_t)));
         s->cap = npts;
     }
-    hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot, zc0, zc1, halo);
-    hipLaunchKernelGGL(k_mc_scanblocks, dim3(1), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->totals, s->active);
+    static const bool one_cell = getenv("ICON_AMD_MC_CLASSIFY1") != nullptr;         // A/B: the one-cell-per-thread form
+    if ((res - 1) % 4 == 0 && !one_cell)
+        hipLaunchKernelGGL(k_mc_classify4, dim3((unsigned)nblk), dim3(kMcBlock / 4), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot, zc0, zc1, halo);
+    else
+        hipLaunchKernelGGL(k_mc_classify, dim3((unsigned)nblk), dim3(kMcBlock), 0, st, d_occ, res, level, npts, s->flags, s->ntri, s->block_tot, zc0, zc1, halo);
+    const int64_t nchunks = (nblk + kMcChunk - 1) / kMcChunk;
+    if (nchunks >= 2 && nchunks <= kMcMaxChunks) {
+        hipLaunchKernelGGL(k_mc_scan_local, dim3((unsigned)nchunks), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->chunk_tot, s->totals);
+        hipLaunchKernelGGL(k_mc_scan_apply, dim3((unsigned)nchunks), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->chunk_tot, (int)nchunks, s->totals, s->active);
+    } else {
+        hipLaunchKernelGGL(k_mc_scanblocks, dim3(1), dim3(1024), 0, st, s->block_tot, s->block_sums, nblk, s->totals, s->active);
+    }
     ICON_HIP(hipGetLastError());
     unsigned long long h[3];
     ICON_HIP(hipMemcpyAsync(h, s->totals, sizeof(h), hipMemcpyDeviceToHost, st));

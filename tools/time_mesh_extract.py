@@ -13,6 +13,8 @@ feat = T(a.features)
 def sync(): torch.cuda.synchronize()
 # SCHEDULE="33,65,129,257,513": the shipped default mcube_res=512 (configs/icon-filter.yaml:23)
 for sched in ([33, 65, 129, 257], [33, 65, 129, 257, 513]):
+  if os.environ.get("ONLY") and int(os.environ["ONLY"]) != sched[-1]:
+      continue
   for rep in range(int(os.environ.get("REPEAT", "3"))):
     ts = [0.0, 0.0, 0.0]
     n = 10
