@@ -464,7 +464,11 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
             if ((rc = device_cu_count(&n_cu))) return rc;
             // the number of blocks is known on the device only: a grid that fills the wave slots, every workgroup loops
             const int share_env = share_waves_override();        // diagnostics: 1 = one wave per block
-            const int nw = (share_env == 1 || share_env == 4 || share_env == 8 || share_env == 16) ? share_env : kShareWavesMany;
+            // wavefronts per shared walk by level: the candidates of a level grow ~4x with the resolution, the walks get shorter -
+            // measured per level of the [33 .. 513] schedule (us, NW = 16 / 8 / 4 / 1): 65^3 75 / 97 / 160 / 462, 129^3 183 / 123 /
+            // 142 / 311, 257^3 381 / 221 / 150 / 196 (tools/share_probe.sh): few long walks want many waves each, many walks few
+            const int by_level = r <= 65 ? kShareWavesFew : (r <= 129 ? kShareWavesMany : 4);
+            const int nw = (share_env == 1 || share_env == 4 || share_env == 8 || share_env == 16) ? share_env : by_level;
             ShareDbg dbg{};
             if ((rc = work_share_dbg(work, &dbg))) return rc;
 #define ICON_AD_NEAREST(PP, NW) hipLaunchKernelGGL((k_ad_nearest<PP, NW>), dim3((unsigned)(n_cu * 32 / (NW == 1 ? 4 : NW))), dim3(NW == 1 ? 256 : NW * 64), 0, st, \
