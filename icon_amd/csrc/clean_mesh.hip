@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_cm_init(CleanCtx c)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < c.F) { c.parent[i] = (int)i; c.comp_verts[i] = 0; }
-    if (i < c.V) c.keep_v[i] = 0;
+    if (i < c.V) { c.keep_v[i] = 0; c.remap[i] = 0x7fffffff; }    // remap doubles as "smallest label among the vertex's faces" until the emit passes
     if (i == 0) { *c.best = 0ull; c.totals[0] = c.totals[1] = c.totals[2] = 0; }
 }
 
@@ -131,20 +131,21 @@ __global__ __launch_bounds__(256) void k_cm_flatten(CleanCtx c)
     c.label[i] = x;
 }
 
-// vertices per component = distinct (label, vertex) incidences
-__global__ __launch_bounds__(256) void k_cm_sizes(CleanCtx c)
+// vertices per component = distinct (label, vertex) incidences.  Round 4 pushed all 3 F incidences through the hash table (287 us
+// for the 551,000 faces of a 513^3 surface); but a vertex of a marching-cubes surface lies in ONE component unless it is a pinch
+// point, so (round 5): the smallest label among a vertex's faces (k_cm_vmin: one atomicMin per incidence on a [V] array) counts
+// the vertex once for that component, and only the incidences whose face carries ANOTHER label - the pinch vertices, a handful - go
+// through the table to be counted once per (label, vertex).  The same numbers, whatever the mesh (triangle soups included).
+__global__ __launch_bounds__(256) void k_cm_vmin(CleanCtx c)
 {
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    bool fresh = false;
-    int L = -1;
-    if (t < 3 * c.F && c.totals[2] == 0) {
-        const int64_t f = t / 3;
-        L = c.label[f];
-        const int64_t v = c.faces[t];
-        (void)hash_slot(c.keys, c.mask, (unsigned long long)L * (unsigned long long)c.V + (unsigned long long)v, &fresh);
-    }
-    // one atomic per wave and label (a body surface is one component: 58,000 increments of ONE counter otherwise)
-    bool todo = fresh;
+    if (t >= 3 * c.F || c.totals[2]) return;
+    atomicMin(&c.remap[c.faces[t]], c.label[t / 3]);
+}
+
+// one atomic per wave and label (a body surface is one component: 58,000 increments of ONE counter otherwise)
+__device__ __forceinline__ void cm_count_labels(const CleanCtx &c, bool todo, int L)
+{
     while (__any(todo)) {
         const unsigned long long m = __ballot(todo);
         const int leader = __ffsll((long long)m) - 1;
@@ -153,6 +154,25 @@ __global__ __launch_bounds__(256) void k_cm_sizes(CleanCtx c)
         if ((int)(threadIdx.x & 63) == leader) atomicAdd(&c.comp_verts[Lr], __popcll(same));
         todo = todo && L != Lr;
     }
+}
+
+__global__ __launch_bounds__(256) void k_cm_sizes(CleanCtx c)
+{
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = c.totals[2] == 0;
+    // (a) every referenced vertex, for the smallest label among its faces
+    int L = (ok && t < c.V) ? c.remap[t] : 0x7fffffff;
+    cm_count_labels(c, L != 0x7fffffff, L);
+    // (b) the incidences under any OTHER label: once per (label, vertex)
+    bool fresh = false;
+    L = -1;
+    if (ok && t < 3 * c.F) {
+        L = c.label[t / 3];
+        const int64_t v = c.faces[t];
+        if (L != c.remap[v])
+            (void)hash_slot(c.keys, c.mask, (unsigned long long)L * (unsigned long long)c.V + (unsigned long long)v, &fresh);
+    }
+    cm_count_labels(c, fresh, L);
 }
 
 __global__ __launch_bounds__(256) void k_cm_best(CleanCtx c)
@@ -314,7 +334,8 @@ extern "C" int icon_clean_mesh(const float *d_verts, int64_t V, const int64_t *d
     hipLaunchKernelGGL(k_cm_unite, dim3(g3F), dim3(256), 0, st, c);
     ICON_HIP(hipMemsetAsync(c.keys, 0xff, (size_t)slots * 8, st));             // the table serves the incidence count next
     hipLaunchKernelGGL(k_cm_flatten, dim3(gF), dim3(256), 0, st, c);
-    hipLaunchKernelGGL(k_cm_sizes, dim3(g3F), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cm_vmin, dim3(g3F), dim3(256), 0, st, c);
+    hipLaunchKernelGGL(k_cm_sizes, dim3(std::max(g3F, gV)), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_cm_best, dim3(gF), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_cm_flags, dim3(gF), dim3(256), 0, st, c);
     hipLaunchKernelGGL(k_cm_count_v, dim3(gV), dim3(256), 0, st, c);
