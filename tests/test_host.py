@@ -438,3 +438,23 @@ def test_python_sources_bind_every_name_they_load():
              glob.glob(os.path.join(root, "tools", "*.py")) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")])
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_names.py")] + sorted(files), capture_output=True, text=True)
     assert r.returncode == 0, r.stdout
+
+
+def test_multiply_high_division_is_exact():
+    """csrc/geom_device.h udiv_magic / udiv_fast (the tile decode of k_nearest's per-call record): q = mulhi(n, floor(2^32 / d)) is
+    floor(n / d) or one less for EVERY 32-bit n - one compare-and-increment repairs it; d == 1 uses 2^32 - 1.  Checked here in
+    exact integer arithmetic over the divisors a lattice can produce and adversarial numerators."""
+    rng = np.random.RandomState(5)
+    ds = list(range(1, 400)) + [2 ** k for k in range(1, 20)] + [2 ** k - 1 for k in range(2, 20)] + [2 ** k + 1 for k in range(2, 20)] \
+        + rng.randint(1, 1 << 20, 300).tolist()
+    for d in ds:
+        m = (1 << 32) // d if d > 1 else (1 << 32) - 1
+        assert m < (1 << 32)
+        ns = np.concatenate([np.arange(0, 4 * d + 4), (1 << 32) - 1 - np.arange(0, 2 * d + 2), rng.randint(0, 1 << 32, 200),
+                             (rng.randint(0, (1 << 32) // d + 1, 200) * d), (rng.randint(1, (1 << 32) // d + 1, 200) * d - 1)]).astype(np.int64)
+        ns = ns[(ns >= 0) & (ns < (1 << 32))]
+        q = (ns * m) >> 32
+        assert ((q == ns // d) | (q == ns // d - 1)).all(), d
+        q = q + ((ns - q * d) >= d)
+        assert (q == ns // d).all(), d
+
