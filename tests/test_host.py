@@ -452,9 +452,10 @@ def test_multiply_high_division_is_exact():
         assert m < (1 << 32)
         ns = np.concatenate([np.arange(0, 4 * d + 4), (1 << 32) - 1 - np.arange(0, 2 * d + 2), rng.randint(0, 1 << 32, 200),
                              (rng.randint(0, (1 << 32) // d + 1, 200) * d), (rng.randint(1, (1 << 32) // d + 1, 200) * d - 1)]).astype(np.int64)
-        ns = ns[(ns >= 0) & (ns < (1 << 32))]
-        q = (ns * m) >> 32
-        assert ((q == ns // d) | (q == ns // d - 1)).all(), d
-        q = q + ((ns - q * d) >= d)
-        assert (q == ns // d).all(), d
+        ns = ns[(ns >= 0) & (ns < (1 << 32))].astype(np.uint64)        # n * m < 2^64: exact in uint64
+        q = (ns * np.uint64(m)) >> np.uint64(32)
+        want = ns // np.uint64(d)
+        assert ((q == want) | (q + np.uint64(1) == want)).all(), d
+        q = q + ((ns - q * np.uint64(d)) >= np.uint64(d)).astype(np.uint64)
+        assert (q == want).all(), d
 
