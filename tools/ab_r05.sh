@@ -1,7 +1,9 @@
 #!/bin/bash
 # Same-box A/B of the geometry pre-pass: the round-3 / round-4 trees (build_ab/r03, r04: `git archive 3a678e2 | 534525d | tar -x` + make) against
 # this tree with and without the per-call tile record (ICON_AMD_LATTICE_FAST); kernel times from rocprofv3, interleaved twice.
-#   usage: gpurun -- 'bash tools/ab_r05.sh <tag>'
+#   prepare (once, in the build container; build_ab/ is git-ignored but travels with the gpurun snapshot):
+#     for t in r03:3a678e2 r04:534525d; do d=build_ab/${t%%:*}; mkdir -p $d && git archive ${t##*:} | tar -x -C $d && make -j8 -C $d/icon_amd/csrc; done
+#   usage: gpurun -- 'bash tools/ab_r05.sh <tag>'        (profiles/r05_ab_nearest.txt is one such session)
 T=${1:-ab5}
 R=$PWD
 mkdir -p gpurun_out
@@ -15,7 +17,7 @@ run() {   # name, bench path, env...
 }
 for rep in 1 2; do
   [ -d $R/build_ab/r03 ] && run r03_$rep $R/build_ab/r03/bench.py A=1
-  run r04_$rep $R/build_ab/r04/bench.py A=1
+  [ -d $R/build_ab/r04 ] && run r04_$rep $R/build_ab/r04/bench.py A=1
   run slow_$rep $R/bench.py ICON_AMD_LATTICE_FAST=0
   run fast_$rep $R/bench.py ICON_AMD_LATTICE_FAST=1
 done
