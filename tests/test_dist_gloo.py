@@ -212,6 +212,28 @@ def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, split, world):
         assert all(r[2][-1] == "split" for r in res), res          # the split protocol really ran on every rank
 
 
+@pytest.mark.parametrize("world", [4, 8])
+@pytest.mark.parametrize("split", [True, False])
+def test_zslab_sharding_gloo_many_ranks(world, split):
+    """the rank counts of the scaling run (N = 4, 8; the driver measures 1 / 2 / 4 / 8): slabs of two or three planes at this
+    resolution - half-slabs of one plane, second halves that are EMPTY on the ranks with the shorter slab - through the split
+    and the unsplit protocol; every rank assembles the oracle's volume bit for bit and the backend asserts the global sign list"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, "reference", q, False, True, False, split)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    if split:
+        assert all(r[2][-1] == "split" for r in res), res
+
+
 def standin_slab_mesh(buf, z0, res, zc0, zc1, halo, level):
     """A stand-in for the slab triangulation with marching cubes' OWNERSHIP structure (what the exchange protocol depends on): a cell
     owns the crossings of its +x / +y / +z edges (keys 3 * cell + direction, the halo layer only its x / y edges), and its faces -
