@@ -413,7 +413,7 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
         assert p.returncode != 0 and "need 2 HIP devices" in p.stderr
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_real_ranks_on_one_gpu_run_the_hip_slab_kernels(world):
     """SURVEY.md section 8e under REAL ranks: `world` processes (torch.distributed.run, gloo - they share this box's one GPU) each
     run the HIP kernels of their Z-slab through the sharded protocol of DenseReconEngine (packed 2-bit sign messages, one
