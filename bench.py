@@ -447,6 +447,10 @@ def main():
         detail = eng._work().profile_detail()          # of the LAST timed step: search kernel alone, cycles / effective clock of the MLP kernel
     except Exception as ex:
         detail = {"error": repr(ex)}
+    try:
+        wg = eng._work().profile_workgroups()           # of the same launch: one record per workgroup of the persistent grid
+    except Exception as ex:
+        wg = repr(ex)
     eng._work().profile(False)
     if two_works:
         eng._work(1).profile(False)
@@ -692,6 +696,24 @@ def main():
             out["config"]["stage_ms"]["nearest_kernel"] = detail["nearest_ms"]
         else:
             out["roofline"]["clock_note"] = detail["error"]
+        # where the launch ends: the kernel is a persistent grid (one workgroup per CU) and finishes with its slowest workgroup.
+        # Every workgroup stamps its start / end (s_memrealtime) and its cycles (s_memtime) and names its XCD (HW_REG_XCC_ID)
+        if isinstance(wg, np.ndarray) and len(wg):
+            span, xcd, mhz = wg[:, 2], wg[:, 0].astype(int), wg[:, 3] / wg[:, 2] * 1e-3
+            out["roofline"].update({
+                "wg_span_ms": {"min": float(span.min()), "median": float(np.median(span)), "max": float(span.max())},
+                "per_xcd_clock_mhz": [float(mhz[xcd == x].mean()) if (xcd == x).any() else None for x in range(8)],
+                "per_xcd_tiles": [int(wg[xcd == x, 4].sum()) for x in range(8)],
+                "tail_ms": float(stage[2] - np.median(span)),
+                "tail_inside_kernel_ms": float((wg[:, 1] + span).max() - np.median(span)),
+                "workgroups": int(len(wg)), "tiles_per_workgroup": {"min": int(wg[:, 4].min()), "max": int(wg[:, 4].max())},
+                "partition": "static runs + a pool (15 % of the tiles) drawn in groups of 2 by the workgroups that finish first "
+                             "(icon_work_set_steal); the XCDs hold different clocks under the power limit - per_xcd_clock_mhz - and take "
+                             "tiles in that proportion - per_xcd_tiles",
+                "wg_note": "last timed step.  tail_ms = avg_launch_ms (HIP events around the kernel and its two 5-us companions) - the median "
+                           "workgroup span; tail_inside_kernel_ms = last workgroup's end - first workgroup's start - median span"})
+        elif not isinstance(wg, np.ndarray):
+            out["roofline"]["wg_note"] = wg
         if isinstance(zero_ms, float):
             out["roofline"].update({"mlp_zero_data_ms": zero_ms, "mlp_zero_data_points": 257 ** 3,
                                     "zero_data_note": "standalone k_mlp_f16x3 (the fused kernel's chunk bodies) on all-zero rows and weights, 257^3 "

@@ -9,6 +9,8 @@
 #include "../../include/icon_amd.h"
 
 namespace icon {
+constexpr int kWgRec = 6;                // words per workgroup record behind icon_work::d_clock[4]: 4 stamps, (XCC_ID << 32 | HW_ID), tiles done
+constexpr int kMaxProfGrid = 1024;       // workgroups with a record (the fused kernel's grid is one per CU)
 
 // ---- error handling -------------------------------------------------------------------------
 void set_error(const std::string &msg);
@@ -384,7 +386,13 @@ struct icon_work {
     bool prof = false;
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // ev[4], ev[5]: around the nearest-triangle search kernel alone
     bool ev_search = false;
-    unsigned long long *d_clock = nullptr;   // [4] cycle / wall counters of the fused kernel's workgroup 0 (FusedGeom::clock)
+    unsigned long long *d_clock = nullptr;   // [4] cycle / wall counters of the fused kernel's workgroup 0 + [kWgRec] per workgroup (FusedGeom::clock)
+    mutable int clock_grid = 0;                      // grid of the most recent profiled launch of the fused kernel (records behind d_clock[4])
+    double clock_kernel_ms = 0.0;
+    // the fused kernel's tile partition (icon_work_set_steal): the last steal_permille / 1000 of the tiles are not assigned
+    // to a workgroup up front but drawn in contiguous groups of steal_grp by whoever finishes its static run first
+    unsigned int *d_steal = nullptr;         // [2] ticket counter, finished-workgroup counter (self-cleaning, fused_f16x3.hip)
+    int steal_permille = 150, steal_grp = 2;
     bool ev_valid = false;
 };
 

@@ -79,9 +79,29 @@ struct FusedGeom {
     SignSrc sg;
     // profiling (icon_work_profile): workgroup 0 brackets its run with the shader-cycle counter and the constant-rate wall
     // counter - [0] s_memtime, [1] s_memrealtime at the start, [2], [3] at the end: cycles / wall time = the EFFECTIVE clock
-    // the matrix pipe ran at under this launch's load (bench.py roofline.effective_clock_mhz: separates a slow box from a slow build)
+    // the matrix pipe ran at under this launch's load (bench.py roofline.effective_clock_mhz: separates a slow box from a slow build).
+    // Behind them EVERY workgroup leaves a record of kWgRec words at [4 + kWgRec * blockIdx.x]: the same four stamps, the
+    // hardware ids (XCC_ID, HW_ID) and the tiles it evaluated (static run + stolen) - icon_work_profile_workgroups: the span of
+    // every workgroup, the clock of every XCD, the tail of the launch (kernel time - median span)
     unsigned long long *clock;
+    // static-plus-stealing partition: the tiles [0, steal_from) are cut into one contiguous run per workgroup as before; the
+    // tiles behind them are handed out in contiguous groups of steal_grp from steal[0] (a ticket counter; steal[1] counts the
+    // workgroups that have finished - the last one zeroes both, so the pair is clean for the next launch on the stream without
+    // a memset).  steal == nullptr: the whole launch is static (SMALL variants, device-side N).
+    unsigned int *steal;
+    int64_t steal_from;
+    int steal_grp;
 };
+// the workgroup's draw state: six LDS words in the slack behind the side arrays
+constexpr int kPoolOff = kSideOff + kSideFloats * 4;
+enum { kPoolNext = 0, kPoolOrigin, kPoolGroup, kPoolTiles, kPoolDone, kPoolWords };
+static_assert(kPoolOff + 4 * kPoolWords <= kSideOff + 4352, "the draw state lives in the slack behind the side arrays");
+
+__device__ __forceinline__ void wg_stamp(unsigned long long *rec)
+{
+    rec[0] = __builtin_readcyclecounter();                   // s_memtime: shader cycles
+    rec[1] = __builtin_amdgcn_s_memrealtime();               // constant rate (hipDeviceAttributeWallClockRate)
+}
 
 // ---------------------------------------------------------------------------------------------
 // k_sign: outlier flag, sign, inside flag and in_cube flag of every point (icon prior), 1 byte.  Reads only
@@ -343,9 +363,9 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane0 = threadIdx.x & 63, wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     float *Xs = reinterpret_cast<float *>(smem + kXsOff);
-    if (G.clock && blockIdx.x == 0 && threadIdx.x == 0) {
-        G.clock[0] = __builtin_readcyclecounter();              // s_memtime: shader cycles
-        G.clock[1] = __builtin_amdgcn_s_memrealtime();           // constant rate (hipDeviceAttributeWallClockRate)
+    if (G.clock && threadIdx.x == 0) {
+        if (blockIdx.x == 0) wg_stamp(G.clock);
+        if (blockIdx.x < kMaxProfGrid) wg_stamp(G.clock + 4 + kWgRec * blockIdx.x);
     }
 
     // ---- once per workgroup: resident layer-0 operands, side arrays, sign-list geometry ------------------
@@ -365,14 +385,40 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     // workgroup stays on one XCD - interleaved over the grid, those lines were fetched into two L2s (105 vs 91 MB of HBM
     // reads per 257^3 launch when the tiles stopped being 1 KiB-aligned runs of the linear order)
     const int tp = (SMALL && G.N <= (int64_t)(kTilePts / 2) * gridDim.x) ? kTilePts / 2 : kTilePts;       // points per tile (wave-uniform)
-    const int64_t ntiles = (G.N + tp - 1) / tp;
-    const int64_t per = ntiles / gridDim.x, rem = ntiles % gridDim.x;
-    int64_t tile = (int64_t)blockIdx.x * per + min((int64_t)blockIdx.x, rem);
-    const int64_t tile_end = uniform64(tile + per + ((int64_t)blockIdx.x < rem ? 1 : 0));
-    tile = uniform64(tile);
+    const int ntiles = (int)((G.N + tp - 1) / tp);                  // N < 2^31 (checked by the launcher)
+    // the static part: [0, nstat) in one contiguous run per workgroup; behind it the pool the early finishers draw from.
+    // What the draws need (pool origin, group size, tile count) and the workgroup's draw state live in six LDS words, not in
+    // scalar registers: the MFMA body below spills its scalars into vector lanes, and 64 spilled scalars are one more vector
+    // register than the kernel has (measured: 66 spills = 20 bytes of scratch per lane)
+    const bool stealing = !SMALL && G.steal != nullptr;
+    const int nstat = stealing ? (int)G.steal_from : ntiles;
+    const int per = nstat / (int)gridDim.x, rem = nstat % (int)gridDim.x;
+    int tile = (int)blockIdx.x * per + min((int)blockIdx.x, rem);
+    int tile_end = __builtin_amdgcn_readfirstlane(tile + per + ((int)blockIdx.x < rem ? 1 : 0));
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    volatile int *pool = reinterpret_cast<volatile int *>(smem + kPoolOff);
+    if (!SMALL) {
+        if (threadIdx.x == 0) {
+            pool[kPoolOrigin] = nstat; pool[kPoolGroup] = G.steal_grp; pool[kPoolTiles] = ntiles; pool[kPoolDone] = 0;
+            int nb = 0;                                      // (any value >= 0: the pool is open)
+            if (stealing && tile >= tile_end) {              // no static run at all (fewer static tiles than workgroups): draw now
+                nb = nstat + (int)atomicAdd(G.steal, 1u) * G.steal_grp;
+                if (nb >= ntiles) nb = -1;
+            }
+            pool[kPoolNext] = nb;
+        }
+        __syncthreads();
+        if (stealing && tile >= tile_end) {
+            const int nb = __builtin_amdgcn_readfirstlane(pool[kPoolNext]);
+            __syncthreads();                                 // (every wave has read the word before a draw of the loop rewrites it)
+            if (nb >= 0) { tile = nb; tile_end = min(nb + G.steal_grp, ntiles); }
+        }
+    }
     if (tile < tile_end) issue_chunk(w.image, smem, 0, wave0, lane0);
 
-    for (; tile < tile_end; ++tile) {
+    // `nb`: the first tile of the group drawn while the LAST tile of the current run is in flight (-1: none, or no draw) - one
+    // returned atomic of wave 4, which has no work item in the feature phase; the barrier that publishes the tile publishes it
+    for (int nb = -1; tile < tile_end;) {
         // Everything derived from the thread index is re-derived per tile from an opaque copy: hoisted out of
         // the loop, those ~20 lane-dependent addresses would have to stay live across the 250-register MFMA
         // body, i.e. be spilled to scratch (measured: 1.5 GB of scratch writes per 257^3 launch).
@@ -382,13 +428,20 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const int j = lane & 31, h = lane >> 5;
         // ---- feature phase: waves 0-3, one work item per thread -> Xs[t][16] -----------------------------
         const int t = tid;
+        const bool draw = !SMALL && stealing && tile + 1 == tile_end;       // wave-uniform: this is the run's last tile
+        if (!SMALL && draw && t == 256 && pool[kPoolNext] >= 0) {
+            const int g = pool[kPoolOrigin] + (int)atomicAdd(G.steal, 1u) * pool[kPoolGroup];
+            pool[kPoolNext] = g < pool[kPoolTiles] ? g : -1;    // -1: the pool is empty, this workgroup draws no more
+        }
         const bool worker = t < tp;                             // wave-uniform
-        int64_t q = tile * tp + (worker ? t : 0);
+        int64_t q = (int64_t)tile * tp + (worker ? t : 0);
         if (q >= G.N) q = G.N - 1;                               // padding lanes of the last tile recompute its last item
         if (worker) build_row<PRIOR, LATTICE>(G, q, Xs + t * kXRow, K, rank0);
         __syncthreads();          // tile visible; chunk 0 (and, the first time, W0 + side arrays) landed
 
-        const bool more = tile + 1 < tile_end;                  // the first chunks of the next tile ride on the last ones
+        nb = (!SMALL && draw) ? __builtin_amdgcn_readfirstlane(pool[kPoolNext]) : -1;
+        if (!SMALL && tid == 0) pool[kPoolDone] = pool[kPoolDone] + 1;
+        const bool more = tile + 1 < tile_end || nb >= 0;       // the first chunks of the next tile ride on the last ones
         if (SMALL && wave >= (tp >> 5)) {
             // a wave without points (128-point tiles): its share of the weight stream, the same barriers as the body below
             for (int c = 0; c < 16; ++c) {
@@ -402,6 +455,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
             issue_chunk(w.image, smem + kBufBytes, 19, wave, lane);
             ICON_CHUNK_BARRIER();
             if (more) issue_chunk(w.image, smem, 0, wave, lane);
+            ++tile;
             continue;
         }
         // ---- MLP: one wave = 32 points, lane (j,h) holds input slots 8h..8h+7 of point j ------------------
@@ -457,15 +511,32 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         const float y = apply_last_op((part + other) + w.b3, w.last_op);
         // where this point's occupancy goes is re-derived from the work item (a handful of integer instructions):
         // nothing lane-dependent lives across the MFMA body
-        const int64_t oq = tile * tp + pt;
+        const int64_t oq = (int64_t)tile * tp + pt;
         if (h == 0 && oq < G.N) {
             int ix, iy, iz;
             out[LATTICE ? lattice_item(G, oq, ix, iy, iz) : (G.out_map ? (int64_t)G.out_map[oq] : oq)] = masked_result(y, maskf != 0.0f, w.flag);
         }
+        // the next tile: the one behind this, or the first of the group drawn during this one
+        if (!SMALL && nb >= 0) {
+            tile = nb;
+            tile_end = min(nb + __builtin_amdgcn_readfirstlane(pool[kPoolGroup]), __builtin_amdgcn_readfirstlane(pool[kPoolTiles]));
+        } else ++tile;
     }
-    if (G.clock && blockIdx.x == 0 && threadIdx.x == 0) {
-        G.clock[2] = __builtin_readcyclecounter();
-        G.clock[3] = __builtin_amdgcn_s_memrealtime();
+    if (!SMALL && stealing && threadIdx.x == 0) {
+        // the last workgroup to finish leaves the pair clean for the next launch (every draw of this launch precedes its
+        // workgroup's arrival here in program order; agent-scope atomics on both words)
+        __threadfence();
+        if (atomicAdd(G.steal + 1, 1u) == gridDim.x - 1) { atomicExch(G.steal, 0u); atomicExch(G.steal + 1, 0u); }
+    }
+    if (G.clock && threadIdx.x == 0 && blockIdx.x < kMaxProfGrid) {
+        if (blockIdx.x == 0) wg_stamp(G.clock + 2);
+        unsigned long long *rec = G.clock + 4 + kWgRec * blockIdx.x;
+        wg_stamp(rec + 2);
+        unsigned xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        rec[4] = ((unsigned long long)xcc << 32) | hw;
+        rec[5] = SMALL ? 0ull : (unsigned long long)pool[kPoolDone];
     }
 }
 
@@ -601,6 +672,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     G.near = work_near(work, mesh); G.code8 = work->d_code8;
     if (!lattice) { G.n_dev = work->q_n_dev; G.out_map = work->q_map; }
     G.clock = work->prof ? work->d_clock : nullptr;
+    G.steal = nullptr; G.steal_from = 0; G.steal_grp = 1;
     G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;
@@ -632,6 +704,13 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     // one persistent workgroup per CU (LDS-bound: 132 KiB, all registers).  Multi-GPU: a collective's kernels cannot co-reside
     // with it on a CU - icon_work_set_reserve_cus leaves some CUs to them
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, std::max(n_cu - work->reserve_cus, 1));
+    if (!small && work->d_steal && work->steal_permille > 0 && ntiles > (int64_t)grid) {
+        // static-plus-stealing: a workgroup's span depends on its planes (the clip band costs more per tile than the far
+        // field) and on its XCD's clock under the power limit; the launch ends with the slowest one.  The pool evens it out.
+        G.steal = work->d_steal; G.steal_grp = work->steal_grp;
+        G.steal_from = ntiles - ntiles * work->steal_permille / 1000;
+    }
+    if (G.clock) work->clock_grid = (int)std::min<unsigned>(grid, (unsigned)kMaxProfGrid);
 #define ICON_FUSED(P, L_, ID, ...)                                                                                         \
     do {                                                                                                                   \
         if ((rc = once_per_device(ID, [] { return hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_f16x3<P, L_, ##__VA_ARGS__>),   \

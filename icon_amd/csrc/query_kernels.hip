@@ -707,7 +707,7 @@ extern "C" int icon_work_destroy(icon_work_t *w)
     (void)hipFree(w->d_signs); (void)hipFree(w->d_total); (void)hipFree(w->d_flag); (void)hipFree(w->d_seg); (void)hipFree(w->d_row_count); (void)hipFree(w->d_row_slots); (void)hipFree(w->d_lfast); if (w->h_err) (void)hipHostFree(w->h_err); (void)hipFree(w->d_near16); (void)hipFree(w->d_near_hi); (void)hipFree(w->d_near_d2); (void)hipFree(w->d_code8);
     (void)hipFree(w->d_sort_keys); (void)hipFree(w->d_sort_idx); (void)hipFree(w->d_sort_tmp);
     for (int k = 0; k < 6; ++k) if (w->ev[k]) (void)hipEventDestroy(w->ev[k]);
-    (void)hipFree(w->d_clock);
+    (void)hipFree(w->d_clock); (void)hipFree(w->d_steal);
     icon::mc_destroy(w->mc);
     icon::clean_destroy(w->clean);
     icon::adaptive_destroy(w->ad);
@@ -742,6 +742,45 @@ extern "C" int icon_work_profile_detail(icon_work_t *w, double out[4])
     return ICON_OK;
 }
 
+// The workgroup records of the most recent profiled launch of the fused kernel.  rec[5 * b + ...] for workgroup b:
+// [0] XCC id, [1] start (ms after the earliest workgroup's start), [2] span (ms, constant-rate counter), [3] shader cycles,
+// [4] tiles evaluated.  *n = workgroups of that launch (at most cap are written).  Synchronises like icon_work_stage_ms.
+extern "C" int icon_work_profile_workgroups(icon_work_t *w, double *rec, int cap, int *n)
+{
+    ICON_ARG(w != nullptr && rec != nullptr && n != nullptr && cap >= 0, "icon_work_profile_workgroups: bad argument");
+    if (!w->prof || !w->ev_valid) return fail(ICON_ERR_STATE, "icon_work_profile_workgroups: no profiled call on this workspace");
+    ICON_HIP(hipEventSynchronize(w->ev[3]));
+    const int g = std::min(w->clock_grid, kMaxProfGrid);
+    *n = g;
+    if (g <= 0) return ICON_OK;
+    std::vector<unsigned long long> c((size_t)kWgRec * g);
+    ICON_HIP(hipMemcpy(c.data(), w->d_clock + 4, c.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    int dev = 0, khz = 0;
+    ICON_HIP(hipGetDevice(&dev));
+    ICON_HIP(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev));
+    ICON_ARG(khz > 0, "icon_work_profile_workgroups: the device reports no wall clock rate");
+    unsigned long long t0 = ~0ull;
+    for (int b = 0; b < g; ++b) t0 = std::min(t0, c[(size_t)kWgRec * b + 1]);
+    for (int b = 0; b < g && b < cap; ++b) {
+        const unsigned long long *r = &c[(size_t)kWgRec * b];
+        rec[5 * b + 0] = (double)(r[4] >> 32);
+        rec[5 * b + 1] = (double)(r[1] - t0) / (double)khz;
+        rec[5 * b + 2] = (double)(r[3] - r[1]) / (double)khz;
+        rec[5 * b + 3] = (double)(r[2] - r[0]);
+        rec[5 * b + 4] = (double)r[5];
+    }
+    return ICON_OK;
+}
+
+// permille of the fused kernel's tiles that are drawn dynamically (0 = the static partition of rounds 1-5), in contiguous
+// groups of `group` tiles.  Any setting gives the same volume bit for bit (a tile's result does not depend on who evaluates it).
+extern "C" int icon_work_set_steal(icon_work_t *w, int permille, int group)
+{
+    ICON_ARG(w != nullptr && permille >= 0 && permille <= 1000 && group >= 1 && group <= 4096, "icon_work_set_steal: bad argument");
+    w->steal_permille = permille; w->steal_grp = group;
+    return ICON_OK;
+}
+
 extern "C" int icon_work_set_reserve_cus(icon_work_t *w, int n)
 {
     ICON_ARG(w != nullptr && n >= 0, "icon_work_set_reserve_cus: bad argument");
@@ -755,9 +794,11 @@ extern "C" int icon_work_profile(icon_work_t *w, int enable)
     if (enable && !w->ev[0])
         for (int k = 0; k < 6; ++k) ICON_HIP(hipEventCreate(&w->ev[k]));
     if (enable && !w->d_clock) {
-        ICON_HIP(hipMalloc((void **)&w->d_clock, 4 * sizeof(unsigned long long)));
-        ICON_HIP(hipMemset(w->d_clock, 0, 4 * sizeof(unsigned long long)));
+        const size_t bytes = (size_t)(4 + kWgRec * kMaxProfGrid) * sizeof(unsigned long long);
+        ICON_HIP(hipMalloc((void **)&w->d_clock, bytes));
+        ICON_HIP(hipMemset(w->d_clock, 0, bytes));
     }
+    w->clock_grid = 0;
     w->ev_search = false;
     w->prof = enable != 0;
     w->ev_valid = false;
@@ -884,6 +925,10 @@ int ensure_work(icon_work *w, int64_t n_points, bool need_x)
     }
     if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
     if (!w->d_flag) ICON_HIP(hipMalloc((void **)&w->d_flag, sizeof(int)));
+    if (!w->d_steal) {
+        ICON_HIP(hipMalloc((void **)&w->d_steal, 2 * sizeof(unsigned int)));
+        ICON_HIP(hipMemset(w->d_steal, 0, 2 * sizeof(unsigned int)));     // (synchronous with respect to the host: ordered before any launch)
+    }
     if (!w->d_seg) ICON_HIP(hipMalloc((void **)&w->d_seg, (kMaxWorld + 1) * sizeof(int64_t)));
     return ICON_OK;
 }

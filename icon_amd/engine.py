@@ -310,6 +310,21 @@ class Workspace(_Handle):
         check(_lib.lib().icon_work_profile_detail(self.h, out), "icon_work_profile_detail")
         return {"nearest_ms": float(out[0]), "fused_cycles": float(out[1]), "fused_wall_ms": float(out[2]), "effective_clock_mhz": float(out[3])}
 
+    def profile_workgroups(self):
+        """of the most recent profiled call (icon_work_profile_workgroups): one row per workgroup of the fused MLP kernel's
+        persistent grid - XCD id, start (ms after the first start), span (ms), shader cycles, tiles evaluated"""
+        import numpy as np
+        cap = 1024
+        out = (C.c_double * (5 * cap))()
+        n = C.c_int(0)
+        check(_lib.lib().icon_work_profile_workgroups(self.h, out, C.c_int(cap), C.byref(n)), "icon_work_profile_workgroups")
+        return np.frombuffer(out, dtype=np.float64)[:5 * min(n.value, cap)].reshape(-1, 5).copy()
+
+    def set_steal(self, permille: int, group: int = 2) -> None:
+        """the fused MLP kernel's tile partition: the last ``permille``/1000 of a launch's tiles are drawn dynamically in
+        contiguous groups of ``group`` tiles (0 = all static); the result does not depend on it"""
+        check(_lib.lib().icon_work_set_steal(self.h, C.c_int(int(permille)), C.c_int(int(group))), "icon_work_set_steal")
+
     def stage_ms(self):
         """(features_ms, patch_ms, mlp_ms) of the most recent call, from HIP events on its stream"""
         out = (C.c_float * 3)()

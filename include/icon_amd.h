@@ -188,6 +188,16 @@ int icon_work_stage_ms(icon_work_t *work, float out_ms[3]);
  * kernel ran at under its own load.  cycles = the code's invariant, MHz = the box's: bench.py prints both so that a slower
  * line can be told from a slower build without PMC files.  Synchronises like icon_work_stage_ms. */
 int icon_work_profile_detail(icon_work_t *work, double out[4]);
+/* ... and what EVERY workgroup of that launch of the fused MLP kernel did (it is a persistent grid of one workgroup per CU;
+ * the launch ends with the slowest one).  rec[5 b + 0] = the XCD (HW_REG_XCC_ID) workgroup b ran on, [1] = its start in ms
+ * after the earliest start, [2] = its span in ms (constant-rate counter), [3] = its shader cycles, [4] = the tiles of 256
+ * lattice points it evaluated (static run + drawn from the pool).  *n = workgroups of the launch; at most cap records are
+ * written.  bench.py derives roofline.wg_span_ms / per_xcd_clock_mhz / tail_ms from it. */
+int icon_work_profile_workgroups(icon_work_t *work, double *rec, int cap, int *n);
+/* The fused MLP kernel's tile partition: the first (1000 - permille) / 1000 of a launch's tiles are cut into one contiguous
+ * run per workgroup, the rest is a pool that workgroups draw from in contiguous groups of `group` tiles as they finish.
+ * permille = 0: all static.  Default 150, 2.  The result does not depend on the setting (bit for bit). */
+int icon_work_set_steal(icon_work_t *work, int permille, int group);
 
 /* ---------------------------------------------------------------------------------------------
  * HGPIFuNet.query (lib/net/HGPIFuNet.py:268-367) for explicit points:

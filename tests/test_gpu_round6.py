@@ -1,0 +1,130 @@
+"""GPU tests of round 6: the static-plus-stealing tile partition of the fused MLP kernel (any split of the tiles into a
+static part and a pool drawn in groups gives the same volume bit for bit, the ticket pair cleans itself), the per-workgroup
+profile records (icon_work_profile_workgroups)."""
+import numpy as np
+import pytest
+import torch
+
+from common import assets, vol_assets
+from icon_amd import synth
+from test_gpu_parity import T, dev, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def body():
+    return assets("body")
+
+
+def bits(t):
+    return t.contiguous().view(torch.int32)
+
+
+# ---------------------------------------------------------------------------------------------
+# k_fused_f16x3: static runs + a pool of tiles drawn by whoever finishes first
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cmap_mode", ["reference", "local"])
+def test_steal_partition_is_free(body, cmap_mode):
+    """a tile's result does not depend on which workgroup evaluates it or when: every (pool share, group size) reproduces the
+    all-static volume of rounds 1-5 bit for bit - incl. everything pooled (no static run: the first group is drawn before
+    the loop), one-tile groups (a draw per tile), groups larger than the pool (one workgroup takes it whole), and a slab that
+    is not the whole lattice.  NaN-prefilled outputs: a tile nobody evaluated would show."""
+    feat = T(body.features)
+    eng = make_engine(body, cmap_mode=cmap_mode)
+    res = 129                                     # 127^3 interior points = 8,002 tiles of 256 > 256 workgroups
+    w = eng._work()
+    w.set_steal(0, 1)
+    want = eng.eval_slab(feat, res, 0, res).clone()
+    want_part = eng.eval_slab(feat, res, 40, 97).clone()
+    assert float(want.max()) > 0.5 and torch.isfinite(want).all()
+    for permille, group in [(100, 2), (100, 1), (37, 3), (500, 8), (1000, 1), (1000, 7), (1000, 4096), (999, 2), (1, 1)]:
+        w.set_steal(permille, group)
+        for rep in range(2):                      # twice: the second launch finds the ticket pair as the first left it (clean)
+            out = torch.full((res, res, res), float("nan"), device=dev())
+            eng.eval_slab(feat, res, 0, res, out=out)
+            assert torch.equal(bits(out), bits(want)), (permille, group, rep)
+        out = torch.full((57, res, res), float("nan"), device=dev())
+        eng.eval_slab(feat, res, 40, 97, out=out)
+        assert torch.equal(bits(out), bits(want_part)), (permille, group, "part")
+    w.set_steal(150, 2)
+
+
+@pytest.mark.parametrize("prior", ["pamir", "pifu"])
+def test_steal_partition_is_free_other_priors(prior):
+    """the pamir / pifu instantiations of the kernel share the loop"""
+    from icon_amd.engine import IconQueryEngine
+    feat, vol, sd = vol_assets(prior)
+    eng = IconQueryEngine(prior_type=prior)
+    if vol is not None:
+        eng.set_volume_features(T(vol))
+    eng.set_regressor({k: torch.from_numpy(v) for k, v in sd.items()})
+    f = T(feat)
+    res = 129
+    w = eng._work()
+    w.set_steal(0, 1)
+    want = eng.eval_slab(f, res, 0, res).clone()
+    assert torch.isfinite(want).all() and float(want.abs().max()) > 0
+    for permille, group in [(100, 2), (1000, 1), (333, 5)]:
+        w.set_steal(permille, group)
+        out = torch.full((res, res, res), float("nan"), device=dev())
+        eng.eval_slab(f, res, 0, res, out=out)
+        assert torch.equal(bits(out), bits(want)), (permille, group)
+
+
+def test_steal_with_reserved_cus_and_split_slab(body):
+    """a smaller grid (icon_work_set_reserve_cus) and the split slab protocol's piecewise launches draw from the same pair"""
+    feat = T(body.features)
+    eng = make_engine(body)
+    res = 129
+    w = eng._work()
+    w.set_steal(0, 1)
+    want = eng.eval_slab(feat, res, 0, res).clone()
+    w.set_steal(250, 3)
+    for reserve in (16, 200, 255):
+        w.set_reserve_cus(reserve)
+        out = torch.full((res, res, res), float("nan"), device=dev())
+        eng.eval_slab(feat, res, 0, res, out=out)
+        assert torch.equal(bits(out), bits(want)), reserve
+    w.set_reserve_cus(0)
+    eng.slab_features(feat, res, 0, res)
+    out = torch.full((res, res, res), float("nan"), device=dev())
+    for za, zb in [(0, 50), (50, 51), (51, 129)]:
+        eng.slab_finish_gathered(res, 0, res, None, 0, 1, 0, out=out, za=za, zb=zb)
+    assert torch.equal(bits(out), bits(want))
+    w.set_steal(150, 2)
+
+
+def test_workgroup_profile_records(body):
+    """icon_work_profile_workgroups: one record per workgroup of the persistent grid - its XCD, when it started, how long it
+    ran, its shader cycles, the tiles it evaluated.  The tiles add up to the launch's; with a pool the counts differ between
+    workgroups, all static they differ by at most one; block b runs on XCD b mod 8 (observed placement, not a contract:
+    only that all 8 XCDs appear is asserted)."""
+    feat = T(body.features)
+    eng = make_engine(body)
+    res = 161
+    ntiles = -(-(res - 2) ** 3 // 256)
+    w = eng._work()
+    w.profile(True)
+    try:
+        for permille in (0, 100):
+            w.set_steal(permille, 2)
+            eng.eval_slab(feat, res, 0, res)
+            rec = w.profile_workgroups()
+            d = w.profile_detail()
+            assert rec.shape[1] == 5 and rec.shape[0] >= 64
+            assert int(rec[:, 4].sum()) == ntiles, (permille, rec[:, 4].sum(), ntiles)
+            assert set(rec[:, 0].astype(int)) == set(range(8))
+            assert (rec[:, 2] > 0).all() and (rec[:, 3] > 0).all() and (rec[:, 1] >= 0).all() and rec[:, 1].min() == 0
+            mhz = rec[:, 3] / rec[:, 2] * 1e-3
+            assert (mhz > 300).all() and (mhz < 3000).all(), (mhz.min(), mhz.max())
+            # workgroup 0's record is the one profile_detail reports
+            assert abs(rec[0, 3] - d["fused_cycles"]) <= 1e-3 * d["fused_cycles"] + 2000
+            if permille == 0:
+                assert rec[:, 4].max() - rec[:, 4].min() <= 1
+            else:
+                static = (ntiles - ntiles * permille // 1000) // rec.shape[0]
+                assert rec[:, 4].min() >= static
+    finally:
+        w.profile(False)
+        w.set_steal(150, 2)
