@@ -537,7 +537,7 @@ def main():
         #     queried, last level interpolated) on the same engine: second baseline line + the "reference mesh"
         sched = {257: [33, 65, 129, 257], 513: [33, 65, 129, 257, 513]}.get(res)      # apps/ICON.py:62-72 for mcube_res 256 / 512
         if sched:
-            ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+            ad = AdaptiveReconEngine(faster=True, query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                                      resolutions=sched, align_corners=True).to(dev)
             for _ in range(2):
                 vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)

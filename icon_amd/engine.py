@@ -440,6 +440,15 @@ class IconQueryEngine:
     @classmethod
     def attach(cls, netG, **kw) -> "IconQueryEngine":
         """Replace ``netG.query`` by the HIP path; everything else on netG is untouched."""
+        # lib/net/HGPIFuNet.py:32 ``maskout = False`` is a MODULE constant read inside query() (:337-342: with it the sdf
+        # channel of every point whose selected image features sum to exactly 0 is overwritten with -1).  Nothing upstream
+        # sets it; a fork that does would get another smpl_feat from its own query() than from this one - refuse instead of
+        # diverging silently
+        import sys
+        mod = sys.modules.get(type(netG).__module__)
+        if mod is not None and getattr(mod, "maskout", False):
+            raise IconAmdError(f"attach: {type(netG).__module__}.maskout is set (lib/net/HGPIFuNet.py:32,337-342 overwrites the sdf "
+                               "channel of points without image features with it); the HIP query evaluates the shipped maskout = False path only")
         eng = cls(prior_type=netG.prior_type, sdf_clip=netG.sdf_clip,
                   smpl_feats=getattr(netG, "smpl_feats", ("sdf", "norm", "vis", "cmap")),
                   res_layers=getattr(netG.if_regressor, "res_layers", (2, 3, 4)), **kw)

@@ -88,7 +88,8 @@ def lattice_coords(res, b_min, b_max, align_corners: bool, device) -> torch.Tens
 class DenseReconEngine(nn.Module):
     """Signature-compatible with ``Seg3dLossless.__init__`` (lib/common/seg3d_lossless.py:37-51);
     the adaptive-only knobs (``faster``, ``use_cuda_impl``, ``use_shadow``, ``visualize``, ``debug``)
-    are accepted and ignored.  Extra keyword arguments:
+    are accepted and ignored (every lattice point is evaluated: there is no schedule to choose; ``AdaptiveReconEngine``
+    refuses ``faster=False``).  Extra keyword arguments:
 
     engine        an ``IconQueryEngine`` (otherwise one is attached to ``netG`` on first call)
     process_group torch.distributed group to shard over (default: WORLD if initialised)
@@ -724,6 +725,19 @@ class AdaptiveReconEngine(DenseReconEngine):
     tests/golden/seg3d_body_adaptive_33_65.npz).  The grid bookkeeping is torch plumbing, as upstream;
     the queries go through ``query_func`` -> ``IconQueryEngine.query`` (HIP).
     """
+
+    def __init__(self, *args, **kwargs):
+        # ``faster`` is the 11th parameter of Seg3dLossless.__init__ behind self (lib/common/seg3d_lossless.py:37-51) and ours
+        faster = args[10] if len(args) > 10 else kwargs.get("faster", False)
+        if not faster:
+            raise IconAmdError(
+                "AdaptiveReconEngine evaluates Seg3dLossless._forward_faster (lib/common/seg3d_lossless.py:152-265) and needs "
+                "faster=True, as the reference's only call site passes it (apps/ICON.py:89).  faster=False - the constructor default "
+                "upstream and here - selects the lossless schedule Seg3dLossless._forward (:267-478: re-query the neighbours of every "
+                "voxel whose inferred value contradicts the interpolated one), which this package does not implement; upstream's own "
+                "_forward raises IndexError at its second level under every PyTorch since 1.5 (float tensors used as indices, :343: "
+                "coords_accum = coords / stride).  DenseReconEngine evaluates every lattice point and needs no schedule.")
+        super().__init__(*args, **kwargs)
 
     def forward_mesh(self, **kwargs):
         """``export_mesh(self.forward(**kwargs))`` - the mesh of THIS class's coarse-to-fine volume on every rank.  (The inherited

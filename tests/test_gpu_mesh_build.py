@@ -163,7 +163,7 @@ def test_full_query_on_a_mesh_whose_ray_bins_overflowed():
     vol = eng.eval_slab(T(a.features), 33, 0, 33).cpu().numpy().ravel()
     ref33, _ = orc.query_icon(v, f, cm, vs, a.features, omlp, S.lattice_points(33), sdf_clip=a.sdf_clip)
     assert np.abs(vol - ref33).max() <= 1e-4 * max(1.0, float(np.abs(ref33).max()))
-    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True)
+    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True, faster=True)
     call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None)
     nat, host = AdaptiveReconEngine(**kw).to(dev()), AdaptiveReconEngine(**kw).to(dev())
     host.native = False

@@ -696,7 +696,7 @@ def test_adaptive_recon_matches_reference_volume(body):
     recon.lattice_level0 = True
     # three levels: the middle one queries only the boundary band - against the reference's volume again
     g3 = golden("seg3d_body_adaptive_17_33_65.npz")
-    recon3 = AdaptiveReconEngine(query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
+    recon3 = AdaptiveReconEngine(faster=True, query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
     vol3 = recon3(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
     q = recon3.last_stats["queries"]
     assert q[0] == 17 ** 3 and 0 < q[1] < 33 ** 3 // 2
@@ -716,7 +716,7 @@ def test_adaptive_recon_257_matches_reference_schedule(body):
     from types import SimpleNamespace
     g = golden("seg3d_body_adaptive_257.npz")
     eng = make_engine(body)
-    ad = AdaptiveReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
+    ad = AdaptiveReconEngine(faster=True, query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions=[int(r) for r in g["resolutions"]], align_corners=True).to(dev())
     vol = ad(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
     assert vol.shape == (257, 257, 257)
@@ -742,7 +742,7 @@ def test_native_schedule_equals_host_driven_schedule(body, res_list, cmap_mode):
     from icon_amd.recon import AdaptiveReconEngine
     from types import SimpleNamespace
     eng = make_engine(body, cmap_mode=cmap_mode)
-    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=res_list, align_corners=True)
+    kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=res_list, align_corners=True, faster=True)
     call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(body.features)], proj_matrix=None)
     nat = AdaptiveReconEngine(**kw).to(dev())
     host = AdaptiveReconEngine(**kw).to(dev())
@@ -788,7 +788,7 @@ def test_native_schedule_returns_none_like_the_reference(body):
     a.state_dict["filters.3.bias"] = a.state_dict["filters.3.bias"] - 100.0
     eng = make_engine(a)
     for native in (True, False):
-        r = AdaptiveReconEngine(query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
+        r = AdaptiveReconEngine(faster=True, query_func=query_func, resolutions=[17, 33, 65], align_corners=True).to(dev())
         r.native = native
         assert r(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None) is None
 

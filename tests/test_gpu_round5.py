@@ -248,7 +248,7 @@ def test_bad_mesh_is_reported_by_the_call_that_used_it(body):
     with pytest.raises(IconAmdError, match="PREVIOUS SMPL mesh"):
         eng.eval_slab(feat, 33, 0, 33)
     assert float(eng.eval_slab(feat, 33, 0, 33).max()) > 0.5       # the good mesh is bound and evaluated
-    ad = AdaptiveReconEngine(query_func=query_func, resolutions=[33, 65], align_corners=True, engine=eng).to(dev())
+    ad = AdaptiveReconEngine(faster=True, query_func=query_func, resolutions=[33, 65], align_corners=True, engine=eng).to(dev())
     assert ad(opt=SimpleNamespace(num_views=1), netG=eng, features=[feat], proj_matrix=None) is not None and ad.last_stats["native"] is True
 
 

@@ -847,7 +847,7 @@ def test_mesh_with_more_slots_than_15_bits(body, precision):
         from types import SimpleNamespace
         from icon_amd.engine import query_func
         from icon_amd.recon import AdaptiveReconEngine
-        kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True)
+        kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[17, 33, 65], align_corners=True, faster=True)
         call = dict(opt=SimpleNamespace(num_views=1), netG=eng, features=[T(a.features)], proj_matrix=None)
         nat, host = AdaptiveReconEngine(**kw).to(dev()), AdaptiveReconEngine(**kw).to(dev())
         host.native = False

@@ -459,3 +459,48 @@ def test_multiply_high_division_is_exact():
         q = q + ((ns - q * np.uint64(d)) >= np.uint64(d)).astype(np.uint64)
         assert (q == want).all(), d
 
+
+
+def test_adaptive_engine_refuses_the_lossless_schedule():
+    """Seg3dLossless(faster=False) - the constructor default upstream (lib/common/seg3d_lossless.py:48) - selects _forward
+    (:267-478), which is not implemented here: the engine says so instead of running _forward_faster under that name
+    (positional form included: faster is the 11th parameter, :37-51).  The dense engine has no schedule and takes either."""
+    from icon_amd.recon import AdaptiveReconEngine, DenseReconEngine
+    from icon_amd._lib import IconAmdError
+    qf = lambda **kw: None
+    for kw in (dict(), dict(faster=False)):
+        with pytest.raises(IconAmdError, match=r"faster=True.*_forward \(:267-478"):
+            AdaptiveReconEngine(query_func=qf, resolutions=[17, 33], align_corners=True, **kw)
+    with pytest.raises(IconAmdError, match="lossless"):
+        AdaptiveReconEngine(qf, ((-1.0, 1.0, -1.0),), ((1.0, -1.0, 1.0),), (17, 33), 1, 0.5, True, False, False, False, False)
+    AdaptiveReconEngine(qf, ((-1.0, 1.0, -1.0),), ((1.0, -1.0, 1.0),), (17, 33), 1, 0.5, True, False, False, False, True)
+    AdaptiveReconEngine(query_func=qf, resolutions=[17, 33], align_corners=True, faster=True)
+    DenseReconEngine(query_func=qf, resolutions=[17], align_corners=True)
+    DenseReconEngine(query_func=qf, resolutions=[17], align_corners=True, faster=True)
+
+
+def test_attach_refuses_a_network_module_with_maskout_set():
+    """lib/net/HGPIFuNet.py:32 `maskout` is a module constant query() reads (:337-342); attach() looks at the module that
+    defines type(netG) and refuses a truthy one"""
+    import types
+    from types import SimpleNamespace
+    from icon_amd.engine import IconQueryEngine
+    from icon_amd._lib import IconAmdError
+    mod = types.ModuleType("fake_hgpifunet")
+    mod.maskout = False
+    exec("class Net:\n    pass\n", mod.__dict__)
+    sys.modules["fake_hgpifunet"] = mod
+    try:
+        def net():
+            n = mod.Net()
+            n.prior_type, n.sdf_clip, n.smpl_feats = "icon", 0.05, ("sdf", "norm", "vis", "cmap")
+            n.if_regressor = SimpleNamespace(res_layers=(2, 3, 4))
+            return n
+        n = net()
+        eng = IconQueryEngine.attach(n)
+        assert n.query == eng.query
+        mod.maskout = True
+        with pytest.raises(IconAmdError, match="maskout"):
+            IconQueryEngine.attach(net())
+    finally:
+        del sys.modules["fake_hgpifunet"]

@@ -88,6 +88,22 @@ def test_chamfer_dense_vs_adaptive_cpu(ref):
     assert c <= 3.2, c          # half a voxel: the voxel size at 33^3 is 6.25 on this x100 scale
 
 
+def test_reference_lossless_schedule_is_dead_code(ref):
+    """Seg3dLossless(faster=False) - the constructor default, lib/common/seg3d_lossless.py:48 - runs _forward (:267-478).
+    Under this image's PyTorch (and every one since true division of integer tensors, 1.5) its second level indexes with
+    float tensors (:296 coords_accum = coords / stride; :343) and raises: the mode cannot have been used with the pinned
+    torch either.  AdaptiveReconEngine refuses faster=False with this reason (tests/test_host.py) instead of running
+    _forward_faster under its name; the one level that does run (a single resolution) is the dense evaluation."""
+    def qf(points, **kw):                                       # batch_eval hands over [1, N, 3] and expects [1, C, N] (:125-144)
+        return ((points ** 2).sum(2).sqrt()[:, None] < 0.6).float()
+    kw = dict(query_func=qf, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], align_corners=True, balance_value=0.5)
+    with pytest.raises(IndexError, match="indices"):
+        ref.Seg3dLossless(resolutions=[17, 33], faster=False, **kw)()
+    one = ref.Seg3dLossless(resolutions=[17], faster=False, **kw)()
+    fast = ref.Seg3dLossless(resolutions=[17], faster=True, **kw)()
+    assert torch.equal(one, fast) and one.shape == (17, 17, 17)
+
+
 def test_reference_transforms_branch_is_dead_code(ref):
     """lib/net/geometry.py:57-60: orthogonal(points, calibs, transforms) raises for the documented [B,2,3]
     layout and for a bare [2,3] matrix alike, so HGPIFuNet.query(transforms=...) has no behaviour to mirror;
@@ -328,6 +344,17 @@ def test_attach_reads_the_reference_network(ref):
         assert hasattr(netG.if_regressor, name), name
     assert set(ATTACH_SMPL_KEYS) <= set(netG.smpl_feat_dict)
     original = netG.query
+    # the module constant query() reads (HGPIFuNet.py:32,337-342): shipped False; a truthy one is refused
+    import sys
+    ref_mod = sys.modules[type(netG).__module__]
+    assert ref_mod.maskout is False
+    ref_mod.maskout = True
+    try:
+        with pytest.raises(IconAmdError, match="maskout"):
+            IconQueryEngine.attach(netG)
+    finally:
+        ref_mod.maskout = False
+    assert netG.query == original
     eng = IconQueryEngine.attach(netG)
     assert eng.netG is netG and netG.icon_amd_engine is eng and netG.query == eng.query and netG.query != original
     assert eng.prior_type == "icon" == netG.prior_type

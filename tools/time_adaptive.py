@@ -11,7 +11,7 @@ eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip)
 eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
 eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
 feats = [T(a.features)]; opt = SimpleNamespace(num_views=1)
-kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[33, 65, 129, 257], align_corners=True)
+kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[33, 65, 129, 257], align_corners=True, faster=True)
 which = os.environ.get("WHICH", "dense,adaptive,host").split(",")
 for name, cls in (("dense", DenseReconEngine), ("adaptive", AdaptiveReconEngine), ("host", AdaptiveReconEngine)):
     if name not in which:
