@@ -366,17 +366,22 @@ struct ShareLds {
 };
 __host__ __device__ constexpr size_t share_lds_bytes(int nw) { return sizeof(ShareLds) + (size_t)nw * 64 * 8; }
 
-// first error wins (system scope: the record lives in host memory); lane 0 of the reporting wave only
+// first error wins (system scope: the record lives in host memory); lane 0 of the reporting wave only.  The host reads the
+// record without synchronising (work_check_err): the winner first CLAIMS word 0 with kShareErrClaimed - which the host treats
+// as "nothing reported yet" -, writes the details, fences, and only then stores the code, so that a code is never seen
+// ahead of its details
+constexpr int kShareErrClaimed = -1;
 __device__ __forceinline__ void share_report(const ShareDbg &dbg, int code, int ticket, const ShareLds &S)
 {
     if (!dbg.err) return;
     int expected = 0;
-    if (__hip_atomic_compare_exchange_strong(dbg.err, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+    if (__hip_atomic_compare_exchange_strong(dbg.err, &expected, kShareErrClaimed, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
         dbg.err[1] = (int)blockIdx.x; dbg.err[2] = ticket;
         dbg.err[3] = *(volatile const int *)&S.head; dbg.err[4] = *(volatile const int *)&S.tail;
         dbg.err[5] = *(volatile const int *)&S.avail; dbg.err[6] = *(volatile const int *)&S.active;
         dbg.err[7] = (int)(threadIdx.x >> 6);
         __threadfence_system();
+        __hip_atomic_store(dbg.err, code, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -583,7 +588,7 @@ __device__ __forceinline__ Nearest nearest_packet_alt(const MeshDev &m, f3 p, bo
 //      lane per triangle, the wave minimum of the (d^2, face) keys goes through one LDS atomic.
 // Same S2 distance, same key, same pruning bound as the other traversals -> same results.
 // point mode: batches below this size go one wavefront per point, larger ones through Morton-ordered packets
-// (measured crossover on MI355X, tools/time_query_points.py: 60k points 0.42 vs 0.67 ms, 200k ~1.4 vs 0.70 ms)
+// (measured crossover on MI355X in round 2: 60k points 0.42 vs 0.67 ms, 200k ~1.4 vs 0.70 ms)
 constexpr int64_t kPacketMinPoints = 98304;
 constexpr int kCoopWaves = 4;                  // wavefronts (= points) per workgroup
 constexpr int kCoopLeaves = 256;               // leaf list (ref, box distance)

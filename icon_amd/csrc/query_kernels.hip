@@ -868,7 +868,7 @@ int work_check_err(icon_work *w)
     if (!w || !w->h_err) return ICON_OK;
     volatile int *e = w->h_err;
     const int code = e[0];
-    if (code == 0) return ICON_OK;
+    if (code == 0 || code == kShareErrClaimed) return ICON_OK;     // (claimed: a wave is still writing the details - the next look reports it)
     char buf[320];
     static const char *what[] = {"", "a wave waited in vain for the node of its queue ticket (lost or abandoned push)",
                                  "a wave waited in vain for its ring slot to be cleared (ring a full turn behind)",

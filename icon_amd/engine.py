@@ -529,10 +529,20 @@ class IconQueryEngine:
     def poll_mesh_status(self, wait: bool = False) -> None:
         """Raise if the device build of the bound mesh has reported bad input (face naming a missing vertex, non-finite
         coordinate).  A host read of a pinned word - callers invoke it wherever they have just synchronised (the counts of
-        adaptive_eval, the None test of reconEngine.forward, marching cubes), so every mesh is checked by the end of ITS image."""
+        adaptive_eval, the None test of reconEngine.forward), so every mesh is checked by the end of ITS image."""
         m = getattr(self, "_mesh", None)
         if m is not None and not m.checked and m.h:
             m.status(wait)
+
+    def poll_work_status(self) -> None:
+        """Raise if a shared-walk search launched on one of this engine's workspaces gave up on a hand-over (icon_work_status:
+        a host read of each workspace's error record).  Like poll_mesh_status, for callers that have just synchronised: the
+        volume of THAT call is the suspect one - without this the record would only surface when the next call on the
+        workspace refuses to start (query_kernels.hip: ensure_work), one image late."""
+        works = [self.work] + list(self.__dict__.get("_extra_works", {}).values())
+        for w in works:
+            if w is not None and w.h:
+                w.status()
 
     def mesh_z_range(self):
         """(z_min, z_max) of the bound SMPL vertices in world coordinates (one D2H read per mesh, cached):

@@ -198,8 +198,13 @@ class DenseReconEngine(nn.Module):
         else:
             occ = self._forward_sharded(be, im_feat, res, dist, world, rank)
         occ = self._none_if_empty(occ)               # (reads a count back: the stream is idle after it)
+        # ... so every launch of this call has reported: bad SMPL input (device mesh build) and a shared-walk search that gave
+        # up raise HERE, with this image's volume, not one image late.  Sharded: every collective of the step has completed on
+        # every rank by now - a rank that raises leaves the others consistent (they meet the error at the next rendezvous)
         if hasattr(be, "poll_mesh_status"):
-            be.poll_mesh_status()                    # ... so the device mesh build has reported: bad SMPL input raises HERE, not one image late
+            be.poll_mesh_status()
+        if hasattr(be, "poll_work_status"):
+            be.poll_work_status()
         return occ
 
     def forward_mesh(self, **kwargs):

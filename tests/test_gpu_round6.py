@@ -128,3 +128,32 @@ def test_workgroup_profile_records(body):
     finally:
         w.profile(False)
         w.set_steal(150, 2)
+
+
+# ---------------------------------------------------------------------------------------------
+# a shared-walk search that gave up is reported by the forward() that used it
+# ---------------------------------------------------------------------------------------------
+def test_dense_forward_reports_a_lost_hand_over_with_its_own_image(body):
+    """reconEngine.forward synchronises for its None test and then polls the mesh AND the workspaces: with the injected lost
+    push (tests/test_gpu_round5.py) the dense 33^3 forward of THIS image raises - before, the suspect volume was returned and
+    the NEXT image's call was refused instead - and the engine works again once the fault is off."""
+    from types import SimpleNamespace
+    from icon_amd.engine import IconAmdError, query_func
+    from icon_amd.recon import DenseReconEngine
+    from test_gpu_round5 import set_option
+    feat = [T(body.features)]
+    eng = make_engine(body)
+    recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[33],
+                             align_corners=True, engine=eng).to(dev())
+    opt = SimpleNamespace(num_views=1)
+    want = recon(opt=opt, netG=eng, features=feat, proj_matrix=None).clone()
+    set_option("share_spin_log2", 10)
+    set_option("share_lose_push", 3)
+    try:
+        with pytest.raises(IconAmdError, match="shared-walk search"):
+            recon(opt=opt, netG=eng, features=feat, proj_matrix=None)
+    finally:
+        set_option("share_lose_push", 0)
+        set_option("share_spin_log2", 0)
+    got = recon(opt=opt, netG=eng, features=feat, proj_matrix=None)          # the report cleared the record: no refusal one image late
+    assert torch.equal(bits(got), bits(want))

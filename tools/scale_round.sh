@@ -52,5 +52,5 @@ for r in rows:
     if len(r) == 2:
         print(f"| {r[0]} | {r[1]} |")
         continue
-    print("| " + " | ".join(str(v) for v in r) + f" | {float(r[7]) / base:.2f} |" if base else " | - |")
+    print("| " + " | ".join(str(v) for v in r) + (f" | {float(r[7]) / base:.2f} |" if base else " | - |"))
 PY
