@@ -200,3 +200,50 @@ def largest_component_by_faces(verts, faces):
     keep_v[f[keep_f].reshape(-1)] = True
     remap = np.cumsum(keep_v) - 1
     return v[keep_v], remap[f[keep_f]].astype(np.int32)
+
+
+def largest_component_scipy(verts, faces):
+    """lib/dataset/mesh_util.py:778-791 through the ENGINE trimesh itself calls - scipy.sparse.csgraph.connected_components on
+    the face-adjacency graph - with trimesh's own bookkeeping around it restated step by step (trimesh is absent here, scipy is
+    not; tests/test_mesh_tools.py pins largest_component_by_faces - the plain-Python checker of icon_clean_mesh - against this):
+      geometry.faces_to_edges      edges = faces[:, [0,1,1,2,2,0]].reshape(-1, 2), edge k belongs to face k // 3
+      graph.face_adjacency         edges sorted per row; grouping.group_rows(edges_sorted, require_count=2): rows that occur
+                                   EXACTLY twice; adjacency = the two faces of each such row (a face adjacent to itself dropped)
+      graph.connected_components   engine 'scipy': coo_matrix over the F faces, csgraph.connected_components(directed=False)
+                                   -> labels; grouping.group(labels, min_len=1): order = labels.argsort(); one group per label
+                                   value in ascending label order - scipy numbers components in order of their lowest node, so
+                                   components come out ordered by the lowest face index each holds.  Inside a group the faces
+                                   are in ARGSORT order: numpy's default sort is not stable, so the face order inside a
+                                   submesh is whatever that sort leaves (ascending whenever it happens to be stable)
+      Trimesh.submesh / util.submesh   vertices = the referenced ones in ascending index order (np.unique), faces renumbered
+                                   in the group's order
+      clean_mesh                   comp_num = vertices per component; index(max) = the FIRST of several largest
+    -> (verts float32, faces int32, faces_in_ascending_order: bool)"""
+    from scipy.sparse import coo_matrix, csgraph
+    v = np.asarray(verts, np.float32)
+    f = np.asarray(faces, np.int64).reshape(-1, 3)
+    F = len(f)
+    edges = f[:, [0, 1, 1, 2, 2, 0]].reshape(-1, 2)
+    edges_face = np.repeat(np.arange(F), 3)
+    es = np.sort(edges, axis=1)
+    key = es[:, 0] * (int(f.max()) + 1) + es[:, 1]                 # grouping.hashable_rows packs integer rows into one int64 like this
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    start = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    length = np.diff(np.concatenate([start, [len(ks)]]))
+    two = start[length == 2]
+    adj = np.stack([edges_face[order[two]], edges_face[order[two + 1]]], 1)
+    adj = adj[adj[:, 0] != adj[:, 1]]
+    graph = coo_matrix((np.ones(len(adj), dtype=bool), (adj[:, 0], adj[:, 1])), dtype=bool, shape=(F, F))
+    _, labels = csgraph.connected_components(graph, directed=False)
+    lorder = labels.argsort()                                      # grouping.group: default kind, as trimesh calls it
+    ls = labels[lorder]
+    gstart = np.flatnonzero(np.concatenate([[True], ls[1:] != ls[:-1]]))
+    glen = np.diff(np.concatenate([gstart, [len(ls)]]))
+    groups = [lorder[a:a + n] for a, n in zip(gstart, glen)]
+    comp_num = [len(np.unique(f[g].reshape(-1))) for g in groups]
+    g = groups[comp_num.index(max(comp_num))]
+    used = np.unique(f[g].reshape(-1))
+    remap = np.zeros(len(v), np.int64)
+    remap[used] = np.arange(len(used))
+    return v[used], remap[f[g]].astype(np.int32), bool(np.all(np.diff(g) > 0))

@@ -157,3 +157,20 @@ def test_dense_forward_reports_a_lost_hand_over_with_its_own_image(body):
         set_option("share_spin_log2", 0)
     got = recon(opt=opt, netG=eng, features=feat, proj_matrix=None)          # the report cleared the record: no refusal one image late
     assert torch.equal(bits(got), bits(want))
+
+
+# ---------------------------------------------------------------------------------------------
+# the one-command real-package harness, with the repo's CPU checkers standing in for the packages
+# ---------------------------------------------------------------------------------------------
+def test_real_package_harness_self_test():
+    """tools/parity_real_packages.py --stand-ins: every section of the harness (distance / sign, vertex normals, marching cubes,
+    clean_mesh, visibility, voxeliser) runs the product leaf through the C ABI and compares it with the oracle's restatement in
+    the package's place - all PASS, so a DIFF printed where the real packages exist is the package's, not the harness's"""
+    import os
+    import subprocess
+    import sys
+    from common import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "parity_real_packages.py"), "--stand-ins", "--res", "49", "--strict"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " 0 DIFF, 0 ABSENT" in p.stdout and p.stdout.count("[PASS") >= 8, p.stdout[-3000:]
