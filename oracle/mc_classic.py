@@ -302,6 +302,7 @@ def _parse():
 
 
 TRI_TABLE = _parse()          # [256] arrays [T,3] of cube-edge ids
+_FLAT_TABLE = _EDGE_LO = _EDGE_AXIS = None      # filled below, once _flat_table is defined
 
 
 def cut_edges(case: int):
@@ -407,47 +408,91 @@ def loops(tris: np.ndarray):
     return sorted(out, key=lambda s: sorted(s))
 
 
-def marching_cubes(vol: np.ndarray, level: float = 0.5, set_below: bool = True):
-    """The classic algorithm on ``vol`` [n0, n1, n2] with the cube's (x, y, z) = array axes (0, 1, 2), as PyMCubes reads a
-    numpy array.  -> (verts [Nv,3] float64 in array-index coordinates (axis0, axis1, axis2), faces [Nf,3] int64); one vertex per
-    cut lattice edge (shared between the cubes around it), linear interpolation.  ``set_below``: a corner is "set" when its value
-    is below the level (Bourke; False: above)."""
-    v = np.asarray(vol, np.float64)
+def _cell_triangles(v: np.ndarray, level: float, set_below: bool, origin, dims, equal_is_set: bool = True):
+    """the triangles of the cells of the sub-volume ``v`` (float64, its element [0,0,0] is lattice point ``origin`` of a volume
+    of ``dims`` points): [T,3] GLOBAL keys of their vertices - a cut lattice edge is named by (its lower end point, its axis)"""
     n0, n1, n2 = v.shape
-    s = (v < level) if set_below else (v > level)
+    # a value EXACTLY at the level: PyMCubes sets the bit (marchingcubes.h, as recalled: `if (v[m] <= isovalue) cubeindex |= 1 << m`),
+    # Bourke's text does not (`<`).  It matters for a handful of the 1.4e8 values of a 513^3 volume (degenerate triangles there)
+    if set_below:
+        s = (v <= level) if equal_is_set else (v < level)
+    else:
+        s = (v >= level) if equal_is_set else (v > level)
     idx = np.zeros((n0 - 1, n1 - 1, n2 - 1), np.int64)
     for m, (dx, dy, dz) in enumerate(CORNERS):
         idx |= s[dx:n0 - 1 + dx, dy:n1 - 1 + dy, dz:n2 - 1 + dz].astype(np.int64) << m
     cells = np.argwhere((idx > 0) & (idx < 255))
+    if len(cells) == 0:
+        return np.zeros((0, 3), np.int64)
     cases = idx[cells[:, 0], cells[:, 1], cells[:, 2]]
+    tri_e = _FLAT_TABLE[cases]                                # [cells, 5, 3] cube-edge ids
+    valid = tri_e[..., 0] >= 0
+    cell_of = np.repeat(np.arange(len(cells)), 5).reshape(-1, 5)[valid]
+    e = tri_e[valid]                                          # [T, 3]
+    p = cells[cell_of][:, None, :] + _EDGE_LO[e] + np.asarray(origin, np.int64)      # [T, 3, 3] lower end point, global
+    ax = _EDGE_AXIS[e]                                        # [T, 3]
+    return ((p[..., 0] * dims[1] + p[..., 1]) * dims[2] + p[..., 2]) * 3 + ax
+
+
+def _flat_table():
     ntri = np.array([len(t) for t in TRI_TABLE])
     flat = np.full((256, 5, 3), -1, np.int64)
     for c in range(256):
         flat[c, : ntri[c]] = TRI_TABLE[c]
-    tri_e = flat[cases]                                       # [cells, 5, 3] cube-edge ids
-    valid = tri_e[..., 0] >= 0
-    cell_of = np.repeat(np.arange(len(cells)), 5).reshape(-1, 5)[valid]
-    e = tri_e[valid]                                          # [T, 3]
-    # a cut lattice edge is named by its lower end point and its axis
     c0 = CORNERS[EDGE_CORNERS[:, 0]]
     c1 = CORNERS[EDGE_CORNERS[:, 1]]
-    axis = np.argmax(np.abs(c1 - c0), axis=1)
-    lo = np.minimum(c0, c1)
-    p = cells[cell_of][:, None, :] + lo[e]                    # [T, 3, 3] lower end point
-    ax = axis[e]                                              # [T, 3]
-    key = ((p[..., 0] * n1 + p[..., 1]) * n2 + p[..., 2]) * 3 + ax
+    return flat, np.minimum(c0, c1), np.argmax(np.abs(c1 - c0), axis=1)
+
+
+def _mesh_from_keys(v: np.ndarray, key: np.ndarray, level: float):
+    n0, n1, n2 = v.shape
     uk, inv = np.unique(key.reshape(-1), return_inverse=True)
     faces = inv.reshape(-1, 3)
     pk, ak = uk // 3, uk % 3
     q = np.stack([pk // (n1 * n2), (pk // n2) % n1, pk % n2], 1)
     q1 = q.copy()
     q1[np.arange(len(q)), ak] += 1
-    va = v[q[:, 0], q[:, 1], q[:, 2]]
-    vb = v[q1[:, 0], q1[:, 1], q1[:, 2]]
+    va = v[q[:, 0], q[:, 1], q[:, 2]].astype(np.float64)
+    vb = v[q1[:, 0], q1[:, 1], q1[:, 2]].astype(np.float64)
     t = (level - va) / (vb - va)
     verts = q.astype(np.float64)
     verts[np.arange(len(q)), ak] += t
     return verts, faces
+
+
+_FLAT_TABLE, _EDGE_LO, _EDGE_AXIS = _flat_table()
+
+
+def marching_cubes(vol: np.ndarray, level: float = 0.5, set_below: bool = True, equal_is_set: bool = True):
+    """The classic algorithm on ``vol`` [n0, n1, n2] with the cube's (x, y, z) = array axes (0, 1, 2), as PyMCubes reads a
+    numpy array.  -> (verts [Nv,3] float64 in array-index coordinates (axis0, axis1, axis2), faces [Nf,3] int64); one vertex per
+    cut lattice edge (shared between the cubes around it), linear interpolation.  ``set_below``: a corner is "set" when its value
+    is below the level (Bourke; False: above); ``equal_is_set``: ... or exactly at it (PyMCubes' `<=`)."""
+    v = np.asarray(vol, np.float64)
+    key = _cell_triangles(v, level, set_below, (0, 0, 0), v.shape, equal_is_set)
+    return _mesh_from_keys(v, key, level)
+
+
+def marching_cubes_blocks(vol: np.ndarray, level: float = 0.5, set_below: bool = True, block: int = 64, equal_is_set: bool = True):
+    """``marching_cubes`` on a volume too large to hold its case array at once (513^3: 1 GiB of int64): the cells in blocks of
+    ``block``^3, blocks whose values all lie on one side of the level skipped (they hold no triangle) - the same triangles in
+    cell order within a block, blocks in array order; vertices numbered by their global edge key as in ``marching_cubes``."""
+    vol = np.asarray(vol)
+    n0, n1, n2 = vol.shape
+    keys = []
+    for a0 in range(0, n0 - 1, block):
+        for a1 in range(0, n1 - 1, block):
+            for a2 in range(0, n2 - 1, block):
+                sub = vol[a0:a0 + block + 1, a1:a1 + block + 1, a2:a2 + block + 1]
+                if set_below:
+                    bit = (sub <= level) if equal_is_set else (sub < level)
+                else:
+                    bit = (sub >= level) if equal_is_set else (sub > level)
+                if bit.all() or not bit.any():
+                    continue
+                keys.append(_cell_triangles(sub.astype(np.float64), level, set_below, (a0, a1, a2), vol.shape, equal_is_set))
+    key = np.concatenate(keys) if keys else np.zeros((0, 3), np.int64)
+    return _mesh_from_keys(vol, key, level)
 
 
 def case_tris_from_mesher(mesher, set_is_inside: bool):

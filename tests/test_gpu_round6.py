@@ -174,3 +174,43 @@ def test_real_package_harness_self_test():
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " 0 DIFF, 0 ABSENT" in p.stdout and p.stdout.count("[PASS") >= 8, p.stdout[-3000:]
+
+
+# ---------------------------------------------------------------------------------------------
+# device marching cubes at the SHIPPED size against the INDEPENDENT classic implementation
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("which", ["schedule", "dense"])
+def test_device_marching_cubes_513_vs_classic_marching_cubes(body, which):
+    """mcube_res = 512 (configs/icon-filter.yaml:23): lib/common/seg3d_lossless.py:587-596 hands occupancys[1:,1:,1:] to PyMCubes.
+    Until round 5 the device mesh at 513^3 was compared with the repo's OWN host implementation + table-free invariants only; here
+    the published classic algorithm (oracle/mc_classic.py: Lorensen-Cline / Bourke table, read as PyMCubes reads the array, run
+    block-wise over the blocks that hold a crossing) triangulates the same 513^3 volumes - the reference schedule's and the dense
+    one - and the device mesh must be the same vertex set and the same triangle set, winding included, after the reference's
+    own [:, [2,1,0]] / [:, [0,2,1]] conventions."""
+    import os
+    import sys
+    from types import SimpleNamespace
+    from common import ROOT
+    from icon_amd.recon import DenseReconEngine
+    from oracle import mc_classic
+    from test_gpu_round5 import recon513
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from parity_real_packages import compare_meshes
+    eng = make_engine(body)
+    feat = T(body.features)
+    if which == "schedule":
+        occ = recon513(eng)(opt=SimpleNamespace(num_views=1), netG=eng, features=[feat], proj_matrix=None)
+    else:
+        occ = eng.eval_slab(feat, 513, 0, 513)
+    vo, fo = DenseReconEngine(resolutions=[513], align_corners=True).export_mesh(occ)       # the product, reference conventions
+    final = occ[1:, 1:, 1:].contiguous().cpu().numpy()
+    cv, cf = mc_classic.marching_cubes_blocks(final, 0.5, set_below=True, block=64)
+    cv, cf = cv[:, [2, 1, 0]], cf[:, [0, 2, 1]]                                               # seg3d_lossless.py:594-596
+    assert len(fo) > 400000
+    # (coordinates run to 512: a float32 ulp there is 6e-5 - the device interpolates in float32, the classic code in float64)
+    c = compare_meshes(vo.numpy(), fo.numpy(), cv, cf, tol=1e-4, lattice=True)
+    print(c)
+    assert c["verts"][0] == c["verts"][1] and c["faces"][0] == c["faces"][1], c
+    assert c["same_vertex_set"] and c["offset"] is None, c
+    assert c["only_ours"] == 0 and c["only_theirs"] == 0 and c["flipped"] == 0, c
+    assert c["max_vertex_diff"] <= 4e-4, c

@@ -43,7 +43,24 @@ def _rows_sorted(a):
     return a[np.lexsort(a.T[::-1])] if len(a) else a
 
 
-def compare_meshes(va, fa, vb, fb, tol=1e-4):
+def _edge_keys(v, tol):
+    """marching-cubes vertices lie on lattice edges: two coordinates are integers, the third is not.  -> the edge's identity
+    ((lower end point, axis) packed into one int64), -1 where the third coordinate is within 2 tol of an integer as well
+    (a crossing AT a lattice point: up to six edges' vertices cluster there - those are matched by position among themselves)"""
+    r = np.round(v)
+    fr = v - r
+    ar = np.arange(len(v))
+    ax = np.argmax(np.abs(fr), axis=1)
+    amb = np.abs(fr[ar, ax]) < 2 * tol
+    lo = r.copy()
+    lo[ar, ax] = np.floor(v[ar, ax])
+    lo = lo.astype(np.int64) + 4
+    key = ((lo[:, 0] * 8192 + lo[:, 1]) * 8192 + lo[:, 2]) * 3 + ax
+    key[amb] = -1
+    return key
+
+
+def compare_meshes(va, fa, vb, fb, tol=1e-4, lattice=False):
     """(ours, theirs) -> dict: vertex counts, whether the vertex SETS agree (within tol; after a constant offset if one
     aligns them), whether the vertex ORDER agrees, triangle sets as coordinate triples (order- and rotation-free), how many
     triangles of each are missing in the other, how many common triangles are wound the other way round, face order."""
@@ -63,25 +80,77 @@ def compare_meshes(va, fa, vb, fb, tol=1e-4):
             off = cand
             out["offset"] = tuple(float(x) for x in np.round(cand, 4))
     vb = vb - off
-    qa, qb = np.round(va / tol).astype(np.int64), np.round(vb / tol).astype(np.int64)
-    out["same_vertex_set"] = bool(len(qa) == len(qb) and np.abs(_rows_sorted(qa) - _rows_sorted(qb)).max() <= 2)
-    out["same_vertex_order"] = bool(len(va) == len(vb) and np.abs(va - vb).max() <= 2 * tol)
-    out["max_vertex_diff"] = float(np.abs(va - vb).max()) if len(va) == len(vb) and out["same_vertex_order"] else None
+    # vertices are matched by position (nearest neighbour within tol), triangles compared through the matched ids: no
+    # rounding of coordinates into bins, whose edges a 1e-7 difference could straddle
+    if va.shape == vb.shape and np.array_equal(va, vb):            # the same array (clean_mesh keeps a subset of its input): by index
+        dist, near = np.zeros(len(va)), np.arange(len(va))
+    elif lattice:
+        # marching-cubes meshes in voxel units: match by the lattice edge a vertex lies on (nearby DISTINCT vertices - several
+        # edges crossing close to one lattice point - are closer to each other than float32 resolves at coordinate 500)
+        from scipy.spatial import cKDTree
+        ka_, kb_ = _edge_keys(va, tol), _edge_keys(vb, tol)
+        order = np.argsort(ka_, kind="stable")
+        pos = np.searchsorted(ka_[order], kb_)
+        pos = np.minimum(pos, len(va) - 1)
+        hit = (kb_ >= 0) & (ka_[order][pos] == kb_)
+        near = np.where(hit, order[pos], -1)
+        dist = np.where(hit, np.abs(va[np.maximum(near, 0)] - vb).max(1), np.inf)
+        rest_b = np.flatnonzero(~hit)
+        rest_a = np.setdiff1d(np.arange(len(va)), near[hit])
+        if len(rest_b) and len(rest_a):                            # the clusters at lattice points: closest pairs first, one to one
+            dd, nn = cKDTree(va[rest_a]).query(vb[rest_b], k=min(8, len(rest_a)))
+            dd, nn = dd.reshape(len(rest_b), -1), nn.reshape(len(rest_b), -1)
+            cand = sorted((dd[i, j], i, nn[i, j]) for i in range(len(rest_b)) for j in range(dd.shape[1]) if np.isfinite(dd[i, j]))
+            used_a, used_b = set(), set()
+            for d_, i, j in cand:
+                if i not in used_b and j not in used_a and d_ <= 4 * tol:
+                    used_b.add(i); used_a.add(j)
+                    near[rest_b[i]], dist[rest_b[i]] = rest_a[j], d_
+        near = np.where(near < 0, 0, near)
+    else:
+        from scipy.spatial import cKDTree
+        dist, near = cKDTree(va).query(vb, k=1)
+    matched = dist <= 4 * tol if lattice else dist <= 2 * tol
+    ids_b = np.where(matched, near, -1 - np.arange(len(vb)))       # their vertex -> our id (unmatched: a unique negative)
+    bijective = bool(matched.all() and len(np.unique(near)) == len(vb) == len(va))
+    out["same_vertex_set"] = bijective
+    out["same_vertex_order"] = bool(bijective and np.array_equal(near, np.arange(len(va))))
+    out["max_vertex_diff"] = float(dist.max()) if bijective else None
 
-    def tri_keys(v, f):
-        q = np.round(v / (4 * tol)).astype(np.int64)              # coarse enough that both sides round alike
-        t = q[f]                                                    # [F,3,3]
-        ids = (t[..., 0] * 1_000_003 + t[..., 1]) * 1_000_003 + t[..., 2]
-        rot = np.argmin(ids, axis=1)                                # rotate the smallest corner to the front: keeps the winding
-        r = np.stack([np.take_along_axis(ids, ((rot + k) % 3)[:, None], 1)[:, 0] for k in range(3)], 1)
-        return r
-    ka, kb = tri_keys(va, fa), tri_keys(vb, fb)
+    def tri_keys(ids):                                             # rotate the smallest id to the front: keeps the winding
+        rot = np.argmin(ids, axis=1)
+        return np.stack([np.take_along_axis(ids, ((rot + k) % 3)[:, None], 1)[:, 0] for k in range(3)], 1)
+    ka, kb = tri_keys(fa), tri_keys(ids_b[fb])
     sa = {tuple(r) for r in ka.tolist()}
     sb = {tuple(r) for r in kb.tolist()}
+    fl_a = {(r[0], r[2], r[1]) for r in sa}
     fl_b = {(r[0], r[2], r[1]) for r in sb}
-    out["only_ours"] = len(sa - sb - fl_b)
-    out["only_theirs"] = len(sb - sa - {(r[0], r[2], r[1]) for r in sa})
-    out["flipped"] = len((sa & fl_b) - sb)
+    ro, rt = sorted(sa - sb - fl_b), sorted(sb - sa - fl_a)
+    out["clustered"] = 0
+    if ro and rt and len(ro) * len(rt) <= 4_000_000:
+        # leftovers whose three corners coincide within 4 tol, winding kept: the same triangle, its vertices matched to the
+        # wrong members of a cluster of crossings around one lattice point (values within ~tol of the level)
+        pos_b = {}
+        for i, near_i in enumerate(ids_b):
+            pos_b.setdefault(int(near_i), vb[i])
+        def corners(t, theirs):
+            return np.stack([(pos_b[int(i)] if theirs else va[int(i)]) for i in t])
+        left = [corners(t, True) for t in rt]
+        taken = set()
+        for t in ro:
+            co = corners(t, False)
+            for j, ct in enumerate(left):
+                if j in taken:
+                    continue
+                if any(np.abs(co - np.roll(ct, k, axis=0)).max() <= 4 * tol for k in range(3)):
+                    taken.add(j); out["clustered"] += 1
+                    break
+    out["only_ours"] = len(ro) - out["clustered"]
+    out["only_theirs"] = len(rt) - out["clustered"]
+    fl = [t for t in (sa & fl_b) - sb]
+    # (a triangle with two corners at the same place - crossings exactly AT a lattice point - has no winding to compare)
+    fl = [t for t in fl if np.linalg.norm(np.cross(va[t[1]] - va[t[0]], va[t[2]] - va[t[0]])) > (4 * tol) ** 2]
+    out["flipped"] = len(fl)
     out["same_face_set"] = out["only_ours"] == 0 and out["only_theirs"] == 0 and out["flipped"] == 0
     out["same_face_order"] = bool(len(ka) == len(kb) and np.array_equal(ka, kb))
     return out
@@ -95,6 +164,7 @@ def mesh_verdict(section, c, note=""):
         if not c["same_face_order"]:
             klass.append("face ORDER differs")
         report(section, "PASS", f"same {c['verts'][0]} vertices and {c['faces'][0]} triangles as sets"
+               + (f" ({c['clustered']} of them through vertices of a cluster at a lattice point)" if c.get("clustered") else "")
                + (f" (max |dv| {c['max_vertex_diff']:.2e})" if c["max_vertex_diff"] is not None else "")
                + ("; " + ", ".join(klass) if klass else "; same order") + note)
     else:
@@ -147,7 +217,9 @@ def sec_distance_sign(S, point_to_mesh_distance, check_sign, index_vertices_by_f
     untied_face = int((face_diff & ~tied).sum())
     d_untied = float(diff[~tied].max()) if (~tied).any() else 0.0
     d_tied = float(diff[tied].max()) if tied.any() else 0.0
-    ok = untied_face == 0 and d_untied <= 1e-9 and d_tied <= 1e-9
+    # (our d^2 is rebuilt from the float32 sdf = sqrt(d^2) / sqrt(3): two roundings, a few 1e-7 relative)
+    rel = diff / (1.0 + d2)
+    ok = untied_face == 0 and float(rel.max()) <= 1e-6
     report(name + " point_to_mesh_distance", "PASS" if ok and int(face_diff.sum()) == 0 else ("PASS" if ok else "DIFF"),
            f"{len(pts)} points, tied fraction {float(tied.float().mean()):.4f}; max |d^2 diff| untied {d_untied:.3e} tied {d_tied:.3e}; nearest face differs "
            f"on {int(face_diff.sum())} points, {int((face_diff & tied).sum())} of them TIES (runner-up within 1 ulp), {untied_face} not"
@@ -173,7 +245,7 @@ def sec_marching_cubes(S, mesher, name, res):
     eng = DenseReconEngine(resolutions=[res], align_corners=True)
     vo, fo = eng.export_mesh(occ)
     vt, ft = mesher(occ[1:, 1:, 1:].contiguous())
-    c = compare_meshes(vo.numpy(), fo.numpy(), np.asarray(vt), np.asarray(ft))
+    c = compare_meshes(vo.numpy(), fo.numpy(), np.asarray(vt), np.asarray(ft), lattice=True)
     mesh_verdict(f"{name} ({res}^3 volume)", c)
     return (vo, fo), (vt, ft)
 
