@@ -559,16 +559,28 @@ def main():
         if sched:
             ad = AdaptiveReconEngine(faster=True, query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                                      resolutions=sched, align_corners=True).to(dev)
-            for _ in range(2):
+            import gc
+            for _ in range(5):
                 vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
+            # every call on its own (the stream drained in between), 200 of them, the garbage collector frozen as INTEGRATION.md
+            # recommends for a serving loop: the distribution, not one median
+            gc.collect(); gc.freeze(); gc_was = gc.isenabled(); gc.disable()
             ts = []
-            for _ in range(7):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t1) * 1e3)
+            try:
+                for _ in range(200):
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+            finally:
+                if gc_was:
+                    gc.enable()
+                gc.unfreeze()
             extras["reference_schedule_ms_per_volume"] = float(np.median(ts))
+            extras["reference_schedule_ms"] = {"p50": float(np.percentile(ts, 50)), "p99": float(np.percentile(ts, 99)), "max": float(np.max(ts)),
+                                               "calls": len(ts), "gc": "frozen + disabled",
+                                               "launches": "23 kernel launches + 1 fill + 1 copy per [33,65,129,257] schedule (profiles/r06_adaptive_timeline.csv)"}
             extras["reference_schedule_native"] = bool(ad.last_stats.get("native", False))
             extras["reference_schedule_points"] = int(sum(ad.last_stats.get("queries", [])))
             # (3) mesh Chamfer / P2S, lib/dataset/Evaluator.py:200-230, in [-1,1]-cube units x100 (apps/ICON.py:758-759)

@@ -37,7 +37,7 @@ struct icon_adaptive {
     uint8_t *D[kAdMaxLevels] = {nullptr};      // voxels evaluated up to and including level l, [x][y][z] (level 0: all - not stored)
     int32_t *map = nullptr;                    // compacted candidates: [z][y][x] linear index, in the reference's order
     float *pts = nullptr;                      // their world positions [n][3]
-    int32_t *blk_count = nullptr, *blk_off = nullptr;   // compaction scratch (per 256 voxels)
+    int32_t *blk_count = nullptr;              // compaction scratch: candidates per 256 voxels, behind them per 64 such blocks (k_ad_mask)
     int32_t *blk_list = nullptr;               // the 4x4x4 blocks holding a candidate (any order; count in counters[8])
     int *h_counters = nullptr;                 // pinned mirror of `counters` (one direct copy at the end of a schedule, no staging)
     int *counters = nullptr;                   // device: [0..levels) points queried per level, [8] n_blocks, [9] any-positive flag of level 0
@@ -52,7 +52,7 @@ void adaptive_destroy(icon_adaptive *a)
     for (int l = 0; l + 1 < a->n_levels; ++l) (void)hipFree(a->occ[l]);
     for (int l = 1; l < kAdMaxLevels; ++l) (void)hipFree(a->D[l]);
     (void)hipFree(a->P); (void)hipFree(a->M1); (void)hipFree(a->map); (void)hipFree(a->pts);
-    (void)hipFree(a->blk_count); (void)hipFree(a->blk_off); (void)hipFree(a->blk_list); (void)hipHostFree(a->h_counters); (void)hipFree(a->counters);
+    (void)hipFree(a->blk_count); (void)hipFree(a->blk_list); (void)hipHostFree(a->h_counters); (void)hipFree(a->counters);
     delete a;
 }
 
@@ -62,9 +62,44 @@ namespace {
 // One WAVEFRONT = one (z, y) row of the output: the row's weights and source rows are wave-uniform, the lanes take consecutive
 // x (coalesced 256-byte stores; the 257^3 level is 68 MB of output).  History: a thread per voxel spent its time on index
 // arithmetic (75 us for the 257^3 level); four consecutive x per thread shared the row's setup but stored 4 B at a 16 B stride.
-__global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r, int *__restrict__ n_blocks)
+// Since round 6 the launch also carries the per-voxel bookkeeping of the SOURCE level that used to be two more launches at the
+// launch floor (k_ad_pbits after level 0, k_ad_next after every queried level): its first ceil(rp^3 / 256) workgroups write
+// P = (src > balance) in [x][y][z] order for the mask kernel that follows, D = the voxels evaluated up to and including the
+// source level, and level 0's any-positive flag; and it zeroes the two-level counters the mask kernel adds its candidates to.
+struct AdBook {
+    uint8_t *P;                    // [x][y][z] bits of the source level (null: not needed - the level that starts here is the last)
+    uint8_t *D;                    // evaluated-so-far of the source level (null: the source is level 0 - every voxel - or no queried level follows)
+    const uint8_t *C, *Dprev;      // the source level's candidate mask and the level before's D (null: level 0's: every voxel)
+    int rpp;                       // resolution of the level before the source
+    float balance;
+    int *any_pos;                  // level 0 only: some voxel exceeds 0.5 (the reference returns None otherwise, :173-177)
+    int32_t *zero;                 // blk_count ++ sup_count of the level that starts here
+    int n_zero;
+};
+__device__ __forceinline__ int64_t xyz(int r, int x, int y, int z);
+__global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r, int *__restrict__ n_blocks, AdBook bk)
 {
     if (blockIdx.x == 0 && threadIdx.x == 0) *n_blocks = 0;     // the block list of the level that starts here (k_ad_mask fills it)
+    {
+        const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (i < bk.n_zero) bk.zero[i] = 0;
+        if (bk.P || bk.any_pos) {
+            const bool live = i < (int64_t)rp * rp * rp;
+            bool pos = false;
+            if (live) {
+                const int z = (int)(i % rp), y = (int)((i / rp) % rp), x = (int)(i / ((int64_t)rp * rp));
+                const float v = src[((int64_t)z * rp + y) * rp + x];
+                if (bk.P) bk.P[i] = v > bk.balance ? 1 : 0;
+                pos = v > 0.5f;
+                if (bk.D) {
+                    bool d = bk.C[i] != 0;
+                    if (!d && !((x | y | z) & 1)) d = bk.Dprev ? bk.Dprev[xyz(bk.rpp, x >> 1, y >> 1, z >> 1)] != 0 : true;
+                    bk.D[i] = d ? 1 : 0;
+                }
+            }
+            if (bk.any_pos && __any(pos) && (threadIdx.x & 63) == 0) atomicOr(bk.any_pos, 1);
+        }
+    }
     const int row = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
     if (row >= r * r) return;
     const int lane = threadIdx.x & 63;
@@ -125,10 +160,19 @@ __device__ __forceinline__ unsigned long long dup_bits(unsigned long long x)    
 }
 // Also lists the P x P x P blocks of the search that hold a candidate (shift = log2 P; tiles are whole blocks): one atomic per
 // tile reserves the tile's run of the list (any order: the blocks are independent).
+// ... and counts the candidates per 256 voxels of the LINEAR [x][y][z] order (the compaction's blocks) and per 64 such blocks:
+// a core row of the tile is 32 consecutive voxels of that order - at most two blocks - so a thread adds its row's popcounts to one
+// or two counters of each level (zeroed by k_ad_up); k_ad_scatter sums the counters before its block itself.  (Until round 5:
+// k_ad_count + k_ad_scan, two more launches at the launch floor per level.)
+constexpr int kAdSupShift = 7;                                  // 128 blocks = 32,768 voxels per second-level counter: the 16 rows a tile
+                                                                // holds for one x span 16 r + 32 voxels of the order - at most TWO of them
+                                                                // for every r the entry admits, so a tile pre-adds them in LDS (cs) and issues at
+                                                                // most 32 global atomics on the few, hot second-level counters
 __global__ __launch_bounds__(256) void k_ad_mask(const uint8_t *__restrict__ P, int rp, const uint8_t *__restrict__ Dprev, uint8_t *__restrict__ C, int r, int rad,
-                                                int shift, int nbk, int32_t *__restrict__ blk_list, int *__restrict__ n_blocks)
+                                                int shift, int nbk, int32_t *__restrict__ blk_list, int *__restrict__ n_blocks,
+                                                int32_t *__restrict__ blk_count, int32_t *__restrict__ sup_count)
 {
-    __shared__ int wcnt[4], lbase;
+    __shared__ int wcnt[4], lbase, cs[2 * kMaskTX];
     __shared__ unsigned pm[kMaskPX * kMaskPY];                  // parent rows: bit c = P[x][y][pz0 + c]
     __shared__ unsigned long long ma[kMaskRX * kMaskRY], mb[kMaskRX * kMaskRY];
     const int ntx = (r + kMaskTX - 1) / kMaskTX, nty = (r + kMaskTY - 1) / kMaskTY;
@@ -136,6 +180,7 @@ __global__ __launch_bounds__(256) void k_ad_mask(const uint8_t *__restrict__ P, 
     const int ox = tx * kMaskTX - kMaskH, oy = ty * kMaskTY - kMaskH, oz = tz * kMaskTZ - kMaskH;      // region origin (even)
     const int px0 = ox >> 1, py0 = oy >> 1, pz0 = oz >> 1;       // (arithmetic shifts: -4 -> -2)
     const int t = threadIdx.x;
+    if (t < 2 * kMaskTX) cs[t] = 0;
     if (t < kMaskPX * kMaskPY) {
         const int a = t / kMaskPY, b = t % kMaskPY;
         const int x = px0 + a, y = py0 + b;
@@ -194,8 +239,27 @@ __global__ __launch_bounds__(256) void k_ad_mask(const uint8_t *__restrict__ P, 
             m &= ~dm;
         }
         ma[i * kMaskRY + j] = m;
+        // the row's candidates, counted into the compaction's blocks
+        const int z0 = oz + kMaskH;
+        unsigned core = (unsigned)(m >> kMaskH);
+        if (z0 + 32 > r) core &= (z0 < r) ? ((1u << (r - z0)) - 1u) : 0u;
+        if (core) {
+            const int64_t l0 = xyz(r, x, y, z0);
+            const int first = 256 - (int)(l0 & 255);             // voxels of the row that fall into the first block
+            const int c1 = first >= 32 ? __popc(core) : __popc(core & ((1u << first) - 1u));
+            const int c2 = __popc(core) - c1;
+            const int b0 = (int)(l0 >> 8);
+            const int s_first = (int)(xyz(r, x, oy + kMaskH, z0) >> (8 + kAdSupShift));      // of this x's first core row
+            int *sx = cs + 2 * (i - kMaskH);
+            if (c1) { atomicAdd(blk_count + b0, c1); atomicAdd(sx + ((b0 >> kAdSupShift) - s_first), c1); }
+            if (c2) { atomicAdd(blk_count + b0 + 1, c2); atomicAdd(sx + (((b0 + 1) >> kAdSupShift) - s_first), c2); }
+        }
     }
     __syncthreads();
+    if (t < 2 * kMaskTX && cs[t]) {
+        const int x = ox + kMaskH + (t >> 1);
+        atomicAdd(sup_count + (int)(xyz(r, x, oy + kMaskH, oz + kMaskH) >> (8 + kAdSupShift)) + (t & 1), cs[t]);
+    }
     // store: 32 consecutive z per 32 lanes
     for (int it = 0; it < 32; ++it) {
         const int row = it * 8 + (t >> 5), k = t & 31;
@@ -234,56 +298,32 @@ __global__ __launch_bounds__(256) void k_ad_mask(const uint8_t *__restrict__ P, 
     }
 }
 
-// compaction in linear ([x][y][z]) order = the reference's nonzero() order: counts per 256 voxels, scan, scatter
-__global__ __launch_bounds__(256) void k_ad_count(const uint8_t *__restrict__ C, int64_t n, int32_t *__restrict__ blk_count)
+// compaction in linear ([x][y][z]) order = the reference's nonzero() order.  A workgroup = one block of 256 voxels; its offset =
+// the second-level counters before its group of 64 blocks + the block counters before it inside the group, summed by the
+// workgroup itself (a few hundred ints from L2 - the pattern of k_outlier_small); workgroup 0 also publishes the level's total.
+__global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ C, int r, const int32_t *__restrict__ blk_count, const int32_t *__restrict__ sup_count,
+                                                   int n_sup, int32_t *__restrict__ map, float *__restrict__ pts, int *__restrict__ total)
 {
-    __shared__ int ws[4];
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const unsigned long long b = __ballot(i < n && C[i]);
-    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = __popcll(b);
-    __syncthreads();
-    if (threadIdx.x == 0) blk_count[blockIdx.x] = ws[0] + ws[1] + ws[2] + ws[3];
-}
-
-__global__ __launch_bounds__(1024) void k_ad_scan(const int32_t *__restrict__ cnt, int nb, int32_t *__restrict__ off, int *total)
-{
-    __shared__ int wtot[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int carry = 0;
-    for (int base = 0; base < nb; base += 8192) {               // eight consecutive counts per thread (129^3: 8,385 counts, two rounds)
-        const int i = base + (int)threadIdx.x * 8;
-        int v[8], sum = 0;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { v[k] = i + k < nb ? cnt[i + k] : 0; sum += v[k]; }
-        int incl = sum;
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-        __syncthreads();
-        if (lane == 63) wtot[w] = incl;
-        __syncthreads();
-        int before = 0, all = 0;
-#pragma unroll
-        for (int q = 0; q < 16; ++q) { const int t = wtot[q]; before += q < w ? t : 0; all += t; }
-        int run = carry + before + incl - sum;
-#pragma unroll
-        for (int k = 0; k < 8; ++k) { if (i + k < nb) off[i + k] = run; run += v[k]; }
-        carry += all;
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-__global__ __launch_bounds__(256) void k_ad_scatter(const uint8_t *__restrict__ C, int r, const int32_t *__restrict__ blk_off,
-                                                   int32_t *__restrict__ map, float *__restrict__ pts)
-{
-    __shared__ int ws[4];
+    __shared__ int ws[4], red[2][4];
     const int64_t n = (int64_t)r * r * r;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int my_sup = (int)(blockIdx.x >> kAdSupShift);
+    const bool want_all = blockIdx.x == 0;
+    int before = 0, all = 0;
+    for (int k = threadIdx.x; k < (want_all ? n_sup : my_sup); k += 256) { const int t = sup_count[k]; all += t; if (k < my_sup) before += t; }
+    {
+        const int k = (my_sup << kAdSupShift) + (int)threadIdx.x;
+        if (k < (int)blockIdx.x) before += blk_count[k];
+    }
+    for (int d = 32; d >= 1; d >>= 1) { before += __shfl_xor(before, d); all += __shfl_xor(all, d); }
     const bool c = i < n && C[i];
     const unsigned long long b = __ballot(c);
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (lane == 0) ws[w] = __popcll(b);
+    if (lane == 0) { ws[w] = __popcll(b); red[0][w] = before; red[1][w] = all; }
     __syncthreads();
+    if (want_all && threadIdx.x == 0) *total = red[1][0] + red[1][1] + red[1][2] + red[1][3];
     if (!c) return;
-    int k = blk_off[blockIdx.x] + __popcll(b & ((1ull << lane) - 1ull));
+    int k = red[0][0] + red[0][1] + red[0][2] + red[0][3] + __popcll(b & ((1ull << lane) - 1ull));
     for (int q = 0; q < w; ++q) k += ws[q];
     const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
     map[k] = (int32_t)(((int64_t)z * r + y) * r + x);
@@ -321,19 +361,6 @@ __global__ __launch_bounds__(NW == 1 ? 256 : NW * 64) void k_ad_nearest(MeshDev 
     }
 }
 
-// end of a level that another queried level follows: D = voxels evaluated up to and including this level, P = this level's bits
-__global__ __launch_bounds__(256) void k_ad_next(const uint8_t *__restrict__ C, const uint8_t *__restrict__ Dprev, int rp, uint8_t *__restrict__ D, int r,
-                                                const float *__restrict__ occ, float balance, uint8_t *__restrict__ P)
-{
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= (int64_t)r * r * r) return;
-    const int z = (int)(i % r), y = (int)((i / r) % r), x = (int)(i / ((int64_t)r * r));
-    bool d = C[i] != 0;
-    if (!d && !((x | y | z) & 1)) d = Dprev ? Dprev[xyz(rp, x >> 1, y >> 1, z >> 1)] != 0 : true;
-    D[i] = d ? 1 : 0;
-    P[i] = occ[((int64_t)z * r + y) * r + x] > balance ? 1 : 0;
-}
-
 template <class T>
 int grow(T **p, size_t n)
 {
@@ -355,9 +382,41 @@ using namespace icon;
 // exceeds 0.5 (else the reference returns None) - pass NULL to stay asynchronous and read them later with
 // icon_adaptive_counts.
 // ---------------------------------------------------------------------------------------------------------------------------
+static int adaptive_eval_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp, int prior_type, float sdf_clip,
+                              int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
+                              int search, int precision, icon_work_t *work, void *stream, bool defer_rescue);
+
+// The range safety net of the split-precision MLP (k_rescue_fused behind every fused launch: a 5 us launch that reads one word) is
+// DEFERRED when the call synchronises for its counts anyway: the schedule's fused kernels raise one sticky word, the host reads
+// it with the counters, and only a raised word - operands beyond the f16 range, which no shipped checkpoint produces - runs the
+// schedule a second time the per-launch way.  Asynchronous calls (h_counts == NULL) keep the per-launch rescue.
 extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp, int prior_type, float sdf_clip,
                                   int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
                                   int search, int precision, icon_work_t *work, void *stream)
+{
+    ICON_ARG(work != nullptr, "icon_adaptive_eval: null argument");
+    const bool defer = h_counts != nullptr && !rescue_always();
+    int rc = adaptive_eval_impl(mesh, feat, mlp, prior_type, sdf_clip, cmap_mode, resolutions, n_levels, balance, d_out, h_counts, search, precision,
+                                work, stream, defer);
+    if (rc == ICON_OK && defer && work->ad && work->ad->h_counters[10] != 0) {
+        ++work->range_reruns;
+        rc = adaptive_eval_impl(mesh, feat, mlp, prior_type, sdf_clip, cmap_mode, resolutions, n_levels, balance, d_out, h_counts, search, precision,
+                                work, stream, false);
+    }
+    return rc;
+}
+
+// how many schedules on this workspace were run a second time because a fused kernel met operands beyond the f16 range
+extern "C" int icon_adaptive_reruns(icon_work_t *work, int *n)
+{
+    ICON_ARG(work != nullptr && n != nullptr, "icon_adaptive_reruns: null argument");
+    *n = work->range_reruns;
+    return ICON_OK;
+}
+
+static int adaptive_eval_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, const icon_mlp_t *mlp, int prior_type, float sdf_clip,
+                              int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
+                              int search, int precision, icon_work_t *work, void *stream, bool defer_rescue)
 {
     ICON_ARG(feat && mlp && work && resolutions && d_out, "icon_adaptive_eval: null argument");
     ICON_ARG(n_levels >= 1 && n_levels <= kAdMaxLevels, "icon_adaptive_eval: 1..8 levels");
@@ -370,6 +429,8 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         ICON_ARG(l == 0 || resolutions[l] == 2 * resolutions[l - 1] - 1, "icon_adaptive_eval: every level must be 2 r - 1 of the one before");
     }
     ICON_ARG((int64_t)resolutions[n_levels - 1] * resolutions[n_levels - 1] * resolutions[n_levels - 1] < (1ll << 31), "icon_adaptive_eval: lattice too large");
+    // (r^3 < 2^31 => r <= 1290: the 16 core rows of one x span 15 r + 32 voxels of the linear order)
+    static_assert(15 * 1290 + 32 <= (256 << kAdSupShift), "k_ad_mask: a tile's rows of one x must span at most two second-level counters");
     hipStream_t st = (hipStream_t)stream;
     int rc;
 
@@ -398,8 +459,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         if (!rc) rc = grow(&a->M1, (size_t)a->cap);
         if (!rc) rc = grow(&a->map, (size_t)a->cap);
         if (!rc) rc = grow(&a->pts, (size_t)a->cap * 3);
-        if (!rc) rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256);
-        if (!rc) rc = grow(&a->blk_off, (size_t)(a->cap + 255) / 256);
+        if (!rc) rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256 + (size_t)((a->cap + 255) / 256 >> kAdSupShift) + 2);
         if (!rc) rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk);
         if (!rc) rc = grow(&a->counters, (size_t)16);
         if (!rc && hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
@@ -411,16 +471,17 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
     ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
     // whatever way this function is left, the workspace must not keep pointing at a level's compaction buffers: a later point
     // query on it would read them as ITS map
-    struct QMapGuard { icon_work *w; ~QMapGuard() { w->q_map = nullptr; w->q_n_dev = nullptr; } } q_guard{work};
+    struct QMapGuard { icon_work *w; ~QMapGuard() { w->q_map = nullptr; w->q_n_dev = nullptr; w->defer_range_flag = nullptr; } } q_guard{work};
+    work->defer_range_flag = defer_rescue ? a->counters + 10 : nullptr;
 
     // ---- level 0: the coarsest lattice, dense, ONE call ---------------------------------------------------------------
     const int r0 = resolutions[0];
     float *occ0 = a->occ[0];
     work->q_map = nullptr; work->q_n_dev = nullptr;
     if ((rc = icon_grid_eval_slab(mesh, feat, mlp, prior_type, sdf_clip, cmap_mode, r0, 0, r0, occ0, search, precision, work, stream))) return rc;
-    {
+    if (n_levels == 1) {                                        // no upsample launch to carry the any-positive test
         const int64_t n0 = (int64_t)r0 * r0 * r0;
-        hipLaunchKernelGGL(k_ad_pbits, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, occ0, r0, balance, a->P, a->counters + 9);
+        hipLaunchKernelGGL(k_ad_pbits, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, occ0, r0, balance, (uint8_t *)nullptr, a->counters + 9);
     }
 
     const float ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
@@ -428,8 +489,25 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         const int r = resolutions[l], rp = resolutions[l - 1];
         const int64_t n = (int64_t)r * r * r;
         const unsigned nbv = (unsigned)((n + 255) / 256);
-        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)(((int64_t)r * r + 3) / 4)), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r, a->counters + 8);
-        if (l == n_levels - 1) break;                           // "last step no examine": interpolate only
+        // the upsample launch also books the source level: its bits P (needed when this level is examined), D of the source level
+        // (needed when the source level was a queried one: l - 1 >= 1), level 0's any-positive flag, and the zeroed counters
+        const bool examined = l < n_levels - 1;
+        const int64_t nsrc = (int64_t)rp * rp * rp;
+        const int nb_l = (int)nbv, nsup_l = (nb_l >> kAdSupShift) + 1;
+        AdBook bk{};
+        bk.P = examined ? a->P : nullptr;
+        bk.D = (examined && l >= 2) ? a->D[l - 1] : nullptr;
+        bk.C = a->M1;                                           // still the source level's mask (k_ad_mask of THIS level rewrites it later)
+        bk.Dprev = l >= 3 ? a->D[l - 2] : nullptr;
+        bk.rpp = l >= 2 ? resolutions[l - 2] : 0;
+        bk.balance = balance;
+        bk.any_pos = l == 1 ? a->counters + 9 : nullptr;
+        bk.zero = examined ? a->blk_count : nullptr;
+        bk.n_zero = examined ? nb_l + nsup_l : 0;
+        const int64_t book = (bk.P || bk.any_pos) ? (nsrc + 255) / 256 : 0;
+        const int64_t grid_up = std::max<int64_t>(std::max<int64_t>(((int64_t)r * r + 3) / 4, book), (bk.n_zero + 255) / 256);
+        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)grid_up), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r, a->counters + 8, bk);
+        if (!examined) break;                                   // "last step no examine": interpolate only
         // P holds (occ_{l-1} > balance): level 0's from above, later levels' from the end of the previous iteration
         const int rad = l == 1 ? 4 : (l == 2 ? 3 : 1);           // SmoothConv3D 9 / 7 / 3 (seg3d_lossless.py:105-112, 219-226)
         const unsigned nt = (unsigned)((r + kMaskTX - 1) / kMaskTX) * (unsigned)((r + kMaskTY - 1) / kMaskTY) * (unsigned)((r + kMaskTZ - 1) / kMaskTZ);
@@ -439,10 +517,8 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         const int shift = P == 4 ? 2 : 1;
         const int nbk = (r + P - 1) / P;
         hipLaunchKernelGGL(k_ad_mask, dim3(nt), dim3(256), 0, st, a->P, rp, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), C, r, rad,
-                           shift, nbk, icon_prior ? a->blk_list : (int32_t *)nullptr, a->counters + 8);
-        hipLaunchKernelGGL(k_ad_count, dim3(nbv), dim3(256), 0, st, C, n, a->blk_count);
-        hipLaunchKernelGGL(k_ad_scan, dim3(1), dim3(1024), 0, st, a->blk_count, (int)nbv, a->blk_off, a->counters + l);
-        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_off, a->map, a->pts);
+                           shift, nbk, icon_prior ? a->blk_list : (int32_t *)nullptr, a->counters + 8, a->blk_count, a->blk_count + nb_l);
+        hipLaunchKernelGGL(k_ad_scatter, dim3(nbv), dim3(256), 0, st, C, r, a->blk_count, a->blk_count + nb_l, nsup_l, a->map, a->pts, a->counters + l);
         ICON_HIP(hipGetLastError());
         debug_sync("adaptive: upsample + boundary + dilate + compact", st);
         // ---- the level's query: ONE call over the compacted points (count on the device) ---------------------------------
@@ -495,11 +571,7 @@ extern "C" int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *fe
         work->q_map = nullptr; work->q_n_dev = nullptr;
         if (rc) return rc;
         debug_sync("adaptive: sign + list + fused", st);
-        // ---- bookkeeping for the next level -------------------------------------------------------------------------------
-        if (l + 1 < n_levels - 1) {                              // a further queried level follows
-            hipLaunchKernelGGL(k_ad_next, dim3(nbv), dim3(256), 0, st, C, (const uint8_t *)(l >= 2 ? a->D[l - 1] : nullptr), rp, a->D[l], r,
-                               a->occ[l], balance, a->P);
-        }
+        // (the bookkeeping for the next level - D, P - rides on the next level's upsample launch: k_ad_up)
         ICON_HIP(hipGetLastError());
     }
     ICON_HIP(hipGetLastError());

@@ -379,6 +379,11 @@ struct icon_work {
     const int32_t *q_map = nullptr;
     const int *q_n_dev = nullptr;
     int reserve_cus = 0;                  // the persistent MLP kernel leaves this many CUs free (icon_work_set_reserve_cus)
+    // icon_adaptive_eval with host counts (it synchronises at its end anyway): the fused kernels of the schedule raise THIS sticky
+    // word instead of d_flag and no k_rescue_fused is launched behind them (three launches at the launch floor per schedule);
+    // a raised word makes the call run the schedule again with the per-launch rescue.  Null everywhere else.
+    int *defer_range_flag = nullptr;
+    int range_reruns = 0;                 // schedules that had to be run again for that reason (icon_adaptive_reruns)
     struct icon_adaptive *ad = nullptr;   // level buffers of icon_adaptive_eval
     icon::McDevState *mc = nullptr;       // device marching-cubes scratch (icon_mc_count / icon_mc_emit)
     icon::CleanState *clean = nullptr;    // icon_clean_mesh scratch

@@ -688,11 +688,14 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     w.p0 = 0.505f * w.inv0; w.q0 = 0.495f * w.inv0; w.p1 = 0.505f * w.inv1; w.q1 = 0.495f * w.inv1; w.p2 = 0.505f * w.inv2; w.q2 = 0.495f * w.inv2;
     // the range flag of THIS workspace (the handle's own word serves icon_mlp_forward, which has no workspace)
     w.flag = work->d_flag ? work->d_flag : reinterpret_cast<int *>(mlp->d_blob + mlp->off_flag);
+    const bool defer = work->defer_range_flag != nullptr;        // a schedule that checks ONE sticky word at its end (adaptive.hip)
+    if (defer) w.flag = work->defer_range_flag;
 
     int n_cu = 0;
     int rc = device_cu_count(&n_cu);
     if (rc) return rc;
-    if (work->d_flag) { if (!work->flag_clean) ICON_HIP(hipMemsetAsync(work->d_flag, 0, sizeof(int), st)); }    // (k_sign of this call cleared it)
+    if (defer) {}                                                // (the schedule zeroed its word once)
+    else if (work->d_flag) { if (!work->flag_clean) ICON_HIP(hipMemsetAsync(work->d_flag, 0, sizeof(int), st)); }    // (k_sign of this call cleared it)
     else if ((rc = mlp_flag_reset(mlp, st))) return rc;
     work->flag_clean = false;
     const MlpPlain plain = mlp_plain_of(mlp);
@@ -717,8 +720,10 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
                                                                     hipFuncAttributeMaxDynamicSharedMemorySize, kFusedLds); }))) return rc; \
         hipLaunchKernelGGL((k_fused_f16x3<P, L_, ##__VA_ARGS__>), dim3(grid), dim3(kF16Block), kFusedLds, st, G, d_occ, w); \
         debug_sync("k_fused_f16x3", st);                                                                                   \
-        hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
-        debug_sync("k_rescue_fused", st);                                                                                  \
+        if (!defer) {                                                                                                      \
+            hipLaunchKernelGGL((k_rescue_fused<P, L_>), dim3((unsigned)n_resc), dim3(64), 0, st, G, d_occ, plain, w.flag, rescue_always()); \
+            debug_sync("k_rescue_fused", st);                                                                              \
+        }                                                                                                                  \
     } while (0)
     if (small) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 9, true); else ICON_FUSED(ICON_PRIOR_ICON, false, 10, true); }
     else if (prior == ICON_PRIOR_ICON) { if (lattice) ICON_FUSED(ICON_PRIOR_ICON, true, 0); else ICON_FUSED(ICON_PRIOR_ICON, false, 1); }

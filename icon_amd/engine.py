@@ -325,6 +325,12 @@ class Workspace(_Handle):
         contiguous groups of ``group`` tiles (0 = all static); the result does not depend on it"""
         check(_lib.lib().icon_work_set_steal(self.h, C.c_int(int(permille)), C.c_int(int(group))), "icon_work_set_steal")
 
+    def adaptive_reruns(self) -> int:
+        """schedules (icon_adaptive_eval) on this workspace that were run a second time with the per-launch range rescue"""
+        n = C.c_int(0)
+        check(_lib.lib().icon_adaptive_reruns(self.h, C.byref(n)), "icon_adaptive_reruns")
+        return int(n.value)
+
     def stage_ms(self):
         """(features_ms, patch_ms, mlp_ms) of the most recent call, from HIP events on its stream"""
         out = (C.c_float * 3)()

@@ -296,6 +296,11 @@ int icon_adaptive_eval(const icon_mesh_t *mesh, const icon_feat_t *feat, const i
                        int cmap_mode, const int *resolutions, int n_levels, float balance, float *d_out, int64_t *h_counts,
                        int search, int precision, icon_work_t *work, void *stream);
 int icon_adaptive_counts(icon_work_t *work, int n_levels, int64_t *h_counts, void *stream);
+/* With h_counts the call synchronises at its end; the range safety net of the split-precision MLP (operands beyond the f16
+ * range are redone in f32, per launch) is then checked ONCE for the whole schedule and a schedule that met such operands is
+ * run a second time the per-launch way - same results, three launches fewer in every other case.  *n = how often that
+ * happened on this workspace (diagnostics; no shipped checkpoint produces such operands). */
+int icon_adaptive_reruns(icon_work_t *work, int *n);
 
 /* ---------------------------------------------------------------------------------------------
  * The MLP input rows of a call, materialised: what HGPIFuNet.query concatenates into point_feat before the regressor

@@ -214,3 +214,42 @@ def test_device_marching_cubes_513_vs_classic_marching_cubes(body, which):
     assert c["same_vertex_set"] and c["offset"] is None, c
     assert c["only_ours"] == 0 and c["only_theirs"] == 0 and c["flipped"] == 0, c
     assert c["max_vertex_diff"] <= 4e-4, c
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference schedule as one native call: launch diet (26 launches), deferred range rescue
+# ---------------------------------------------------------------------------------------------
+def test_schedule_defers_the_range_rescue_and_reruns_when_it_fires(body):
+    """icon_adaptive_eval with counts synchronises at its end: the fused kernels of its levels raise ONE sticky word and no
+    k_rescue_fused is launched behind them; a raised word (operands beyond the f16 range - here a body squashed flat, whose
+    sliver triangles extrapolate |norm| to 1e5, tests/test_gpu_parity.py) runs the schedule again the per-launch way.  The
+    volume equals the host-driven schedule's (per-call rescue) and is finite; an ordinary subject never reruns."""
+    import warnings
+    from types import SimpleNamespace
+    from icon_amd.engine import IconQueryEngine, query_func
+    from icon_amd.recon import AdaptiveReconEngine
+    feat = T(body.features)
+    eng = make_engine(body)
+    vol, counts, pos = eng.adaptive_eval(feat, [17, 33, 65])
+    assert eng._work().adaptive_reruns() == 0 and pos and torch.isfinite(vol).all()
+    v = (body.smpl_verts * np.asarray((1.0, 1.0, 1e-4), np.float32)).astype(np.float32)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        flat = IconQueryEngine(prior_type="icon", sdf_clip=body.sdf_clip)
+        flat.set_mesh(T(v), T(body.smpl_faces), T(body.smpl_cmap), T(body.smpl_vis))
+        flat.set_regressor({k: torch.from_numpy(w) for k, w in body.state_dict.items()})
+        got, counts, pos = flat.adaptive_eval(feat, [9, 17, 33])
+        reruns = flat._work().adaptive_reruns()
+        kw = dict(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]], resolutions=[9, 17, 33], align_corners=True, faster=True)
+        host = AdaptiveReconEngine(**kw).to(dev())
+        host.native = False
+        want = host(opt=SimpleNamespace(num_views=1), netG=flat, features=[feat], proj_matrix=None)
+    assert torch.isfinite(got).all()
+    assert reruns == 1, reruns                                  # the case really exercises the range path
+    assert host.last_stats["queries"][0] == 9 ** 3 == int(counts[0])
+    if want is not None:
+        assert (got - want).abs().max().item() <= 1e-6 * max(1.0, float(want.abs().max()))
+    # asynchronous form (no counts): the per-launch rescue stays - same volume
+    got2, _, _ = flat.adaptive_eval(feat, [9, 17, 33], counts=False)
+    torch.cuda.synchronize()
+    assert torch.equal(bits(got2), bits(got)) and flat._work().adaptive_reruns() == 1
