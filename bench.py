@@ -347,6 +347,11 @@ def main():
     ap.add_argument("--no-overlap-gather", action="store_true",
                     help="N > 1, sharded: one blocking sign exchange and ONE volume all_gather after the whole slab instead of the "
                          "split / overlapped protocol (DenseReconEngine overlap_gather=False) - the A/B leg of tools/scale_round.sh")
+    ap.add_argument("--slab-layout", default="ab", choices=["ab", "contiguous"],
+                    help="sharded only: 'ab' = two Z-slabs per rank, each volume gather lands in one contiguous block of the result (no "
+                         "assembly copies); 'contiguous' = the round-5 layout (one cost-weighted slab per rank, gathered in two halves)")
+    ap.add_argument("--gather-to", type=int, default=-1,
+                    help="sharded, 'ab' layout: only this rank receives the volume (gather instead of all_gather); -1 = every rank")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--full-extras", action="store_true",
                     help="also run the whole-lattice CPU checker legs (parity sample, mesh vs oracle) above 257^3 (513^3: about a minute)")
@@ -413,7 +418,8 @@ def main():
     recon = DenseReconEngine(query_func=query_func, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
                              resolutions={257: [33, 65, 129, 257], 513: [33, 65, 129, 257, 513]}.get(res, [res]), align_corners=True,
                              balance_value=0.5, faster=True, engine=eng, shard=not args.replicas, overlap_gather=not args.no_overlap_gather,
-                             reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus).to(dev)
+                             reserve_cus=None if args.reserve_cus < 0 else args.reserve_cus, slab_layout=args.slab_layout,
+                             gather_to=None if (args.gather_to < 0 or world == 1 or args.replicas) else args.gather_to).to(dev)
     opt = SimpleNamespace(num_views=1)
 
     mesh_exchange = bool(args.mesh_exchange and world > 1 and not args.replicas)
@@ -476,12 +482,19 @@ def main():
         eng._work(1).profile(False)
     if mesh_exchange:                                   # the step returned (verts, faces): what marching cubes on the volume gives
         assert occ is not None and occ[0].shape[1] == 3 and occ[1].shape[1] == 3 and occ[1].shape[0] > 0
+    elif getattr(recon, "gather_to", None) is not None and recon.gather_to != rank:
+        assert occ is None                              # gather_to: only the destination rank holds the volume
     else:
         assert occ is not None and occ.shape == (res, res, res)
 
     n_points = res ** 3
-    z0, z1 = recon.last_stats["slabs"][rank] if (world > 1 and not args.replicas) else (0, res)      # the cut the engine actually used
-    my_points = (z1 - z0) * res * res
+    # the cut the engine actually used: one Z-slab per rank, or - 'ab' layout - two (DenseReconEngine.ab_pieces)
+    if world > 1 and not args.replicas:
+        my_slabs = list(recon.last_stats["pieces"][rank]) if recon.last_stats.get("pieces") else [tuple(recon.last_stats["slabs"][rank])]
+    else:
+        my_slabs = [(0, res)]
+    z0, z1 = my_slabs[0][0], my_slabs[-1][1]
+    my_points = sum(b - a for a, b in my_slabs) * res * res
     images = world if args.replicas else 1
     value = images * n_points * args.steps / elapsed
     mlp_s = stage[2] * 1e-3
@@ -489,7 +502,7 @@ def main():
     # shell of the lattice is written as 0 without being evaluated - 393 k of the 16.97 M points of a 257^3 volume
     shell_skipped = args.precision == "f16x3" and args.search == "bvh" and os.environ.get("ICON_AMD_SHELL_SKIP", "1") != "0" \
         and os.environ.get("ICON_AMD_UNFUSED", "0") == "0"
-    exec_points = max(min(z1, res - 1) - max(z0, 1), 0) * (res - 2) ** 2 if shell_skipped else my_points
+    exec_points = sum(max(min(b, res - 1) - max(a, 1), 0) for a, b in my_slabs) * (res - 2) ** 2 if shell_skipped else my_points
     achieved = (MLP_FLOP_PER_POINT * exec_points / mlp_s) / 1e12 if mlp_s > 0 else 0.0
     # HBM bytes of the dominant kernel from the PMC passes (FETCH_SIZE / WRITE_SIZE need their own rocprofv3 runs,
     # tools/gpu_round.sh): quoted only while profiles/traffic.json was taken on exactly these kernel sources
@@ -773,6 +786,11 @@ def main():
             out["config"]["gather"] = "mesh" if mesh_exchange else "volume"
             out["config"]["overlap_gather"] = not args.no_overlap_gather
             out["config"]["split_features"] = bool(recon.last_stats.get("split_features", False))
+            out["config"]["slab_layout"] = recon.last_stats.get("layout", "contiguous")
+            out["config"]["gather_to"] = recon.last_stats.get("gather_to")
+            out["config"]["assembly_copies"] = recon.last_stats.get("assembly_copies")
+            if recon.last_stats.get("pieces"):
+                out["config"]["pieces"] = [[list(a), list(b)] for a, b in recon.last_stats["pieces"]]
             if mesh_exchange:
                 out["config"]["exchanged_bytes_per_step"] = recon.last_stats.get("exchanged_bytes")
         if not args.no_cpu_baseline and world == 1 and args.prior == "icon":

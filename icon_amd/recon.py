@@ -100,6 +100,15 @@ class DenseReconEngine(nn.Module):
                   that RCCL's kernels can run beside it (the overlap is otherwise a hope: they cannot co-reside on a CU);
                   costs reserve_cus / CUs of the MLP time (bench.py: config.reserve_cus_cost: 16 of 256 CUs = 0.7 % of a step).
                   None (default) = 16 when the volume gather overlaps the MLP kernel over a device backend (nccl = RCCL), else 0
+    slab_layout   "ab" (default): with the overlapped gather every rank owns TWO Z-slabs - A_r in the lower part of the volume and
+                  B_r in the upper part (lattice order: A_0 .. A_{w-1}, B_0 .. B_{w-1}) - so that each of the two volume
+                  gathers lands in ONE contiguous block of the result: no assembly copies (round 5 cut one contiguous slab per
+                  rank in halves: the gathered halves interleave and had to be copied into place - up to two 68 MB device
+                  copies per 257^3 volume).  "contiguous": the round-5 layout (one slab per rank, cost-weighted cut); it is
+                  also what runs without the overlapped gather, for the mesh exchange and for backends without a second workspace
+    gather_to     None (default): every rank receives the volume (all_gather).  A rank number: only that rank does (gather) -
+                  forward() returns the volume (or None when empty) THERE and None on every other rank; the marching-cubes
+                  consumer is one process, and 7/8 of an all_gather's receive traffic serves nobody
     backend       object providing eval_slab / slab_features / slab_finish (tests inject a CPU
                   checker here; the default is the HIP engine)
     """
@@ -107,7 +116,8 @@ class DenseReconEngine(nn.Module):
     def __init__(self, query_func=None, b_min=((-1.0, 1.0, -1.0),), b_max=((1.0, -1.0, 1.0),), resolutions=(257,),
                  channels=1, balance_value=0.5, align_corners=False, visualize=False, debug=False,
                  use_cuda_impl=False, faster=False, use_shadow=False, engine=None, process_group=None,
-                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, reserve_cus=None, **kwargs):
+                 shard=True, backend=None, balance_slabs=True, overlap_gather=True, reserve_cus=None, slab_layout="ab", gather_to=None,
+                 **kwargs):
         super().__init__()
         self.query_func = query_func
         self.register_buffer("b_min", torch.tensor(b_min).float().unsqueeze(1))   # [1,1,3]
@@ -135,6 +145,10 @@ class DenseReconEngine(nn.Module):
         self.shard = shard
         self.balance_slabs = balance_slabs
         self.overlap_gather = overlap_gather
+        if slab_layout not in ("ab", "contiguous"):
+            raise IconAmdError("slab_layout must be 'ab' or 'contiguous'")
+        self.slab_layout = slab_layout
+        self.gather_to = None if gather_to is None else int(gather_to)
         self.reserve_cus = None if reserve_cus is None else int(reserve_cus)   # CUs the persistent MLP kernel leaves to the collective's kernels when sharded (None: auto)
         self.last_stats = {}
 
@@ -197,7 +211,11 @@ class DenseReconEngine(nn.Module):
             occ = be.eval_slab(im_feat, res, 0, res)
         else:
             occ = self._forward_sharded(be, im_feat, res, dist, world, rank)
-        occ = self._none_if_empty(occ)               # (reads a count back: the stream is idle after it)
+        if occ is None:                              # gather_to: this rank is not the destination - its kernels and sends are enqueued;
+            if im_feat.is_cuda:                      # drain the stream as the None test does on the destination
+                torch.cuda.current_stream(im_feat.device).synchronize()
+        else:
+            occ = self._none_if_empty(occ)           # (reads a count back: the stream is idle after it)
         # ... so every launch of this call has reported: bad SMPL input (device mesh build) and a shared-walk search that gave
         # up raise HERE, with this image's volume, not one image late.  Sharded: every collective of the step has completed on
         # every rank by now - a rank that raises leaves the others consistent (they meet the error at the next rendezvous)
@@ -376,6 +394,11 @@ class DenseReconEngine(nn.Module):
         need_exchange = (getattr(be, "cmap_mode", "local") == "reference" and getattr(be, "prior_type", "icon") == "icon"
                          and "cmap" in getattr(be, "smpl_feats", ("cmap",)))   # the tiled cmap rule is what couples the ranks
         pieces = hasattr(be, "slab_finish_gathered")
+        if (self.slab_layout == "ab" and pieces and self.overlap_gather and not local_only and getattr(be, "split_features", False)
+                and -(-res // world) > 1 and 2 * world <= 64):
+            return self._forward_sharded_ab(be, im_feat, res, dist, world, rank, need_exchange)
+        if self.gather_to is not None and not local_only:
+            raise IconAmdError("gather_to needs the 'ab' slab layout (overlap_gather=True, the HIP engine as backend)")
         # the volume is gathered in two halves of every rank's (padded) slab: the first half travels over xGMI while
         # the second half is still in the MLP kernel
         per_a = (per + 1) // 2 if (self.overlap_gather and pieces and per > 1 and not local_only) else per
@@ -499,6 +522,112 @@ class DenseReconEngine(nn.Module):
         if all(b - a == per for a, b in parts):
             return allv.view(world * per, res, res)[:res]
         return torch.cat([allv[r, : b - a] for r, (a, b) in enumerate(parts)], 0)   # unequal slabs: drop each rank's padding planes
+
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def ab_pieces(res: int, world: int):
+        """The 'ab' partition: per = ceil(res / world) planes per rank, pa = ceil(per / 2) of them in the A part [0, world pa) of the
+        volume and pb = per - pa in the B part behind it; rank r owns A_r = [r pa, (r + 1) pa) and B_r = [world pa + r pb,
+        world pa + (r + 1) pb), clipped to the lattice (the last pieces may be short or empty).  -> (pa, pb, [(A_r, B_r)])"""
+        per = -(-res // world)
+        pa = (per + 1) // 2
+        pb = per - pa
+        clip = lambda z: min(z, res)
+        return pa, pb, [((clip(r * pa), clip((r + 1) * pa)), (clip(world * pa + r * pb), clip(world * pa + (r + 1) * pb))) for r in range(world)]
+
+    def _forward_sharded_ab(self, be, im_feat, res, dist, world, rank, need_exchange):
+        """Two slabs per rank, each a complete pipeline on its own workspace: geometry pass, its own 2-bit sign message, asynchronous
+        exchange; MLP; asynchronous volume gather STRAIGHT into its block of the result.  Lattice order of the 2 x world pieces =
+        A_0 .. A_{w-1}, B_0 .. B_{w-1} = the order the two sign gathers leave their messages in ONE buffer [2, world, stride]: the
+        very outlier list of the unsharded call (piece h of rank r is message h world + r).  The volume is ONE fresh buffer
+        [world per, res, res]; gather A fills [0, world pa), gather B the rest; the result is its first `res` planes - a view."""
+        g = self.process_group
+        dev = im_feat.device
+        pa, pb, pieces = self.ab_pieces(res, world)
+        mine = pieces[rank]
+        gloo_dev = dev.type == "cuda" and dist.get_backend(g) == "gloo"       # debugging aid: device tensors staged through the host
+        dst = self.gather_to
+        if dst is not None and not (0 <= dst < world):
+            raise IconAmdError(f"gather_to={dst}: no such rank in a group of {world}")
+        key = (res, world, rank, str(dev), "ab")
+        if getattr(self, "_ab_key", None) != key:
+            stride = 8 + ((pa * res * res + 3) // 4 + 7) // 8 * 8
+            self._ab_slab = [torch.zeros((pa, res, res), dtype=torch.float32, device=dev), torch.zeros((max(pb, 1), res, res), dtype=torch.float32, device=dev)]
+            self._ab_msg = torch.zeros((2, stride), dtype=torch.int8, device=dev)
+            self._ab_stride = stride
+            self._ab_key = key
+        slab, msg, stride = self._ab_slab, self._ab_msg, self._ab_stride
+        receives = dst is None or dst == rank
+        vol = torch.empty(((pa + pb) * world, res, res), dtype=torch.float32, device=dev) if receives else None
+        blocks = (slice(0, world * pa), slice(world * pa, world * (pa + pb)))
+        order = []
+
+        def gather_signs(h, sig):
+            if gloo_dev:
+                out = torch.empty(world * stride, dtype=torch.int8)
+                dist.all_gather_into_tensor(out, msg[h].cpu(), group=g)
+                sig[h].view(-1).copy_(out)
+                return None
+            return dist.all_gather_into_tensor(sig[h].view(-1), msg[h], group=g, async_op=True)
+
+        def gather_volume(h):
+            n = pa if h == 0 else pb
+            if n == 0:
+                return None
+            src = slab[h][:n]
+            if dst is None:
+                if gloo_dev:
+                    out = torch.empty((world * n, res, res), dtype=torch.float32)
+                    dist.all_gather_into_tensor(out, src.cpu(), group=g)
+                    vol[blocks[h]].copy_(out)
+                    return None
+                return dist.all_gather_into_tensor(vol[blocks[h]], src, group=g, async_op=True)
+            root = dist.get_global_rank(g, dst) if g is not None else dst
+            if gloo_dev:
+                lst = [torch.empty((n, res, res), dtype=torch.float32) for _ in range(world)] if receives else None
+                dist.gather(src.cpu(), lst, dst=root, group=g)
+                if receives:
+                    vol[blocks[h]].copy_(torch.cat(lst))
+                return None
+            # the destination receives every rank's piece directly in its place (one contiguous view per rank)
+            lst = [vol[blocks[h]][r * n:(r + 1) * n] for r in range(world)] if receives else None
+            return dist.gather(src, lst, dst=root, group=g, async_op=True)
+
+        sig = torch.empty((2, world, stride), dtype=torch.int8, device=dev) if need_exchange else None
+        waits = []
+        if need_exchange:
+            for h, (z0, z1) in enumerate(mine):
+                msg[h][:8].zero_()
+                if z1 > z0:
+                    be.slab_features(im_feat, res, z0, z1, msg=msg[h], work=h)
+                order.append(f"features_{'ab'[h]}")
+                hd = gather_signs(h, sig)
+                order.append(f"gather_signs_{'ab'[h]}" + ("" if hd is None else "_async"))
+                waits.append(hd)
+            for hd in waits:
+                if hd is not None:
+                    hd.wait()
+            order.append("wait_signs")
+        handles = []
+        for h, (z0, z1) in enumerate(mine):
+            if not need_exchange:
+                if z1 > z0:
+                    be.slab_features(im_feat, res, z0, z1, work=h)
+                order.append(f"features_{'ab'[h]}")
+            if z1 > z0:
+                be.slab_finish_gathered(res, z0, z1, sig.view(-1) if need_exchange else None, stride, 2 * world, h * world + rank,
+                                        out=slab[h][: z1 - z0], device=dev, work=h)
+            order.append(f"finish_{'ab'[h]}")
+            hd = gather_volume(h)
+            order.append(f"gather_volume_{'ab'[h]}" + ("" if hd is None else "_async"))
+            handles.append(hd)
+        for hd in handles:
+            if hd is not None:
+                hd.wait()
+        self.last_stats = dict(exchanged_bytes=2 * stride * world if need_exchange else 0, collectives=(2 if need_exchange else 0) + 2,
+                               slabs=[(a[0], b[1]) for a, b in pieces], pieces=pieces, split_features=True, order=order, layout="ab",
+                               gather_to=dst, assembly_copies=0)
+        return vol[:res] if receives else None
 
     def _forward_generic(self, **kwargs):
         """Any b_min/b_max/align_corners/proj_matrix: materialise the lattice coordinates exactly as

@@ -120,7 +120,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=False, split=False):
+def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=False, split=False, layout="contiguous", gather_to=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -145,8 +145,33 @@ def _worker(rank, world, port, cmap_mode, q, legacy=False, overlap=True, skew=Fa
         else:
             be_used = be
         recon = DenseReconEngine(query_func=None, b_min=[[-1.0, 1.0, -1.0]], b_max=[[1.0, -1.0, 1.0]],
-                                 resolutions=[9, RES], align_corners=True, backend=be_used, overlap_gather=overlap)
+                                 resolutions=[9, RES], align_corners=True, backend=be_used, overlap_gather=overlap, slab_layout=layout,
+                                 gather_to=gather_to)
         occ = recon(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)
+        if layout == "ab":
+            # two slabs per rank; each volume gather lands in one contiguous block of ONE buffer: the result is a view of it
+            pa, pb, pieces = DenseReconEngine.ab_pieces(RES, world)
+            st = recon.last_stats
+            ok = st.get("layout") == "ab" and st["assembly_copies"] == 0 and st["pieces"] == pieces and st["gather_to"] == gather_to
+            if gather_to is None or gather_to == rank:
+                ok = ok and occ is not None and occ.shape == (RES, RES, RES) and np.array_equal(occ.numpy(), be.full)
+                ok = ok and occ.is_contiguous() and occ.storage_offset() == 0 and occ.untyped_storage().nbytes() == (pa + pb) * world * RES * RES * 4
+            else:
+                ok = ok and occ is None
+            want = ["features_a", "gather_signs_a", "features_b", "gather_signs_b", "wait_signs", "finish_a", "gather_volume_a", "finish_b", "gather_volume_b"] \
+                if cmap_mode == "reference" else ["features_a", "finish_a", "gather_volume_a", "features_b", "finish_b", "gather_volume_b"]
+            ok = ok and [o.replace("_async", "") for o in st["order"]] == want
+            ok = ok and all(o.endswith("_async") for o in st["order"] if o.startswith("gather_"))
+            mine = [p for p in pieces[rank] if p[1] > p[0]]
+            feats = [c[1:3] for c in be.calls if c[0] == "features"]
+            fins = [c[1:5] for c in be.calls if c[0] == "finish"]
+            ok = ok and feats == mine and fins == [p + p for p in mine]
+            # a second image on the same engine: fresh result buffer (the first volume is not overwritten), same protocol
+            occ2 = recon(opt=None, netG=None, features=[torch.from_numpy(a.features)], proj_matrix=None)
+            if occ is not None:
+                ok = ok and occ2 is not None and occ2.data_ptr() != occ.data_ptr() and np.array_equal(occ.numpy(), be.full) and np.array_equal(occ2.numpy(), be.full)
+            q.put((rank, bool(ok), [c[0] for c in be.calls] + ["ab"]))
+            return
         ok = occ is not None and occ.shape == (RES, RES, RES) and np.array_equal(occ.numpy(), be.full)
         if skew:
             from icon_amd.recon import slab_partition, plane_weights
@@ -210,6 +235,46 @@ def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, split, world):
     assert all(r[1] for r in res), res
     if split and cmap_mode == "reference" and overlap:
         assert all(r[2][-1] == "split" for r in res), res          # the split protocol really ran on every rank
+
+
+@pytest.mark.parametrize("world,cmap_mode,gather_to", [(2, "reference", None), (2, "local", None), (2, "reference", 1), (2, "local", 0),
+                                                       (3, "reference", None), (3, "reference", 1), (4, "local", 0),
+                                                       (8, "reference", None), (8, "reference", 5)])
+def test_ab_layout_gloo(world, cmap_mode, gather_to):
+    """the 'ab' slab layout (round 6, the default with the overlapped gather): two Z-slabs per rank - A_r, B_r - each a complete
+    pipeline on its own workspace; lattice order of the pieces = A_0..A_{w-1}, B_0..B_{w-1} = message order of the two sign
+    gathers in ONE buffer (the backend asserts the global outlier list, every piece's rank offset and the workspace pairing);
+    each volume gather lands in one contiguous block of one fresh buffer whose first `res` planes ARE the result (no assembly
+    copy: storage size, offset and contiguity asserted); gather_to: only the destination rank receives (dist.gather straight
+    into its place) and forward() is None elsewhere.  World sizes with short and EMPTY last pieces (17 planes over 8 ranks)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cmap_mode, q, False, True, False, True, "ab", gather_to)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in res) == list(range(world))
+    assert all(r[1] for r in res), res
+    assert all(r[2][-1] == "ab" for r in res), res
+
+
+def test_ab_pieces_partition():
+    """every plane belongs to exactly one piece; no rank carries more than ceil(res / world) planes (what the contiguous cut gives
+    its largest slab); the pieces in (A_0..A_{w-1}, B_0..B_{w-1}) order are the lattice order"""
+    for res in (9, 17, 33, 65, 129, 257, 513):
+        for world in (2, 3, 4, 5, 8, 16):
+            if -(-res // world) < 2:
+                continue
+            pa, pb, pieces = DenseReconEngine.ab_pieces(res, world)
+            flat = [p[0] for p in pieces] + [p[1] for p in pieces]
+            planes = [z for a, b in flat for z in range(a, b)]
+            assert planes == list(range(res)), (res, world)
+            assert max(sum(b - a for a, b in p) for p in pieces) <= -(-res // world)
+            assert pa + pb == -(-res // world) and 0 <= pa - pb <= 1
 
 
 @pytest.mark.parametrize("world", [4, 8])

@@ -418,7 +418,8 @@ def test_real_ranks_on_one_gpu_run_the_hip_slab_kernels(world):
     """SURVEY.md section 8e under REAL ranks: `world` processes (torch.distributed.run, gloo - they share this box's one GPU) each
     run the HIP kernels of their Z-slab through the sharded protocol of DenseReconEngine (packed 2-bit sign messages, one
     all_gather, the slab finished in two pieces, gathered volume), both cmap modes, 65^3 and 129^3, with and without the
-    overlap / cost-balanced cut / reserved CUs; rank 0 asserts the assembled volume == the single-process volume, bit for
+    overlap / cost-balanced cut / reserved CUs, in the 'ab' layout (two slabs per rank, gathers straight into the result; also with
+    gather_to = the last rank) and the contiguous one; rank 0 asserts the assembled volume == the single-process volume, bit for
     bit (tests/dist_gpu_worker.py).  The gloo tests of tests/test_dist_gloo.py prove the host protocol with a checker
     backend; this one puts the real kernels behind it."""
     import os
@@ -434,7 +435,7 @@ def test_real_ranks_on_one_gpu_run_the_hip_slab_kernels(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "tests", "dist_gpu_worker.py")]
     p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert p.returncode == 0 and f"DIST_GPU_OK world={world} checked=8" in p.stdout, p.stdout[-4000:]
+    assert p.returncode == 0 and f"DIST_GPU_OK world={world} checked=16" in p.stdout, p.stdout[-4000:]
 
 
 @pytest.mark.parametrize("world", [2, 3])
