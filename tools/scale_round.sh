@@ -3,7 +3,10 @@
 # number in DESIGN.md section 6 is a projection until this has run).  Runs the headline step at N in {1,2,4,8} for
 #   gather   : volume all-gather (north_star, what the driver's SCALE run measures)  |  --mesh-exchange
 #   reserve  : CUs the persistent MLP grid leaves to RCCL: 0 | 16
-#   overlap  : split phase 1 + two-half gathers (default)  |  --no-overlap-gather (one blocking exchange, one gather)
+#   overlap  : two slabs per rank, own sign exchange each, gathers straight into the result ('ab' layout, default)  |
+#              --slab-layout contiguous (round 5: one slab in two halves, assembly copies)  |  --no-overlap-gather (one blocking
+#              exchange, one gather)
+#   receiver : every rank (all_gather)  |  --gather-to 0 (only the mesh consumer receives)
 # and cfg 5 (one 513^3 image per GPU, no collective), and prints ONE table; the JSON lines are kept under $OUT.
 #   usage: bash tools/scale_round.sh [outdir]          env: NS="1 2 4 8"  STEPS=20  WARMUP=3
 #   on a box with fewer GPUs than N: ICON_AMD_DIST_BACKEND=gloo runs the control flow on the devices that are there (numbers mean nothing)
@@ -22,6 +25,8 @@ for n in $NS; do
   if [ "$n" = "1" ]; then run n1 1; continue; fi
   for rc in 0 16; do
     run n${n}_vol_rc${rc}_ov $n --reserve-cus $rc
+    run n${n}_vol_rc${rc}_ov_contig $n --reserve-cus $rc --slab-layout contiguous
+    run n${n}_vol_rc${rc}_ov_to0 $n --reserve-cus $rc --gather-to 0
     run n${n}_vol_rc${rc}_blk $n --reserve-cus $rc --no-overlap-gather
     run n${n}_mesh_rc${rc} $n --reserve-cus $rc --mesh-exchange
   done
@@ -41,7 +46,8 @@ for f in sorted(glob.glob(os.path.join(out, "*.json"))):
     dist = c.get("dist") or {}
     rs = c.get("rank_stage_ms") or []
     slow = max((r["step_ms"] for r in rs), default=d["ms_per_step"])
-    rows.append((os.path.basename(f)[:-5], d["n_gpus"], d["scaling"], c.get("gather", "-"), c.get("reserve_cus", "-"), c.get("overlap_gather", "-"),
+    rows.append((os.path.basename(f)[:-5], d["n_gpus"], d["scaling"], str(c.get("gather", "-")) + ("" if c.get("gather_to") is None else f" -> rank {c['gather_to']}")
+                 + ("" if c.get("slab_layout") in (None, "contiguous") else " [ab]"), c.get("reserve_cus", "-"), c.get("overlap_gather", "-"),
                  c.get("split_features", "-"), f"{d['value'] / 1e6:.1f}", f"{d['ms_per_step']:.3f}", f"{slow:.3f}",
                  f"{max((r['mlp_ms'] for r in rs), default=c['stage_ms']['mlp']):.3f}", f"{max((r['features_ms'] for r in rs), default=c['stage_ms']['features']):.3f}",
                  dist.get("backend", "-"), dist.get("world_size_seen", "-"), dist.get("distinct_devices", "-")))
