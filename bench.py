@@ -752,7 +752,7 @@ def main():
                 "tail_ms": float(stage[2] - np.median(span)),
                 "tail_inside_kernel_ms": float((wg[:, 1] + span).max() - np.median(span)),
                 "workgroups": int(len(wg)), "tiles_per_workgroup": {"min": int(wg[:, 4].min()), "max": int(wg[:, 4].max())},
-                "partition": "static runs + a pool (15 % of the tiles) drawn in groups of 2 by the workgroups that finish first "
+                "partition": "static runs + a pool (15 % of the tiles by default) drawn in groups of 2 by the workgroups that finish first "
                              "(icon_work_set_steal); the XCDs hold different clocks under the power limit - per_xcd_clock_mhz - and take "
                              "tiles in that proportion - per_xcd_tiles",
                 "wg_note": "last timed step.  tail_ms = avg_launch_ms (HIP events around the kernel and its two 5-us companions) - the median "

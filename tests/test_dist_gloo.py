@@ -238,8 +238,7 @@ def test_zslab_sharding_gloo(cmap_mode, legacy, overlap, skew, split, world):
 
 
 @pytest.mark.parametrize("world,cmap_mode,gather_to", [(2, "reference", None), (2, "local", None), (2, "reference", 1), (2, "local", 0),
-                                                       (3, "reference", None), (3, "reference", 1), (4, "local", 0),
-                                                       (8, "reference", None), (8, "reference", 5)])
+                                                       (3, "reference", None), (3, "reference", 1), (4, "local", 0), (8, "reference", 5)])
 def test_ab_layout_gloo(world, cmap_mode, gather_to):
     """the 'ab' slab layout (round 6, the default with the overlapped gather): two Z-slabs per rank - A_r, B_r - each a complete
     pipeline on its own workspace; lattice order of the pieces = A_0..A_{w-1}, B_0..B_{w-1} = message order of the two sign

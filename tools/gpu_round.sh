@@ -40,4 +40,9 @@ python tools/time_coarse.py 2>/dev/null | grep "^slab" > gpurun_out/${T}_coarse_
 python tools/trav_stats.py 2>/dev/null | grep "^33\|^65\|^129\|^257" | cut -c1-250 > gpurun_out/${T}_traversal_stats.txt
 (echo "box $(cat /proc/sys/kernel/random/boot_id)"; N=${STRESS_N:-4000} python tools/stress_adaptive.py 2>&1 | tail -2) > gpurun_out/${T}_stress.txt; cat gpurun_out/${T}_stress.txt
 python tools/time_mesh_extract.py 2>/dev/null | tail -8 > gpurun_out/${T}_mesh_extract.txt
+# round 6: the fused kernel's tile partition, the search beside the MLP kernel, the schedule's latency distribution, the real-package harness's self-test
+python tools/steal_probe.py > gpurun_out/${T}_steal_probe.txt 2>/dev/null
+python tools/overlap_probe.py > gpurun_out/${T}_overlap_probe.txt 2>/dev/null
+python tools/schedule_latency.py > gpurun_out/${T}_schedule_latency.txt 2>/dev/null; cat gpurun_out/${T}_schedule_latency.txt | cut -c1-200
+python tools/parity_real_packages.py --stand-ins > gpurun_out/${T}_parity_harness_selftest.txt 2>&1; tail -1 gpurun_out/${T}_parity_harness_selftest.txt
 find gpurun_out -name "*.db" -delete
