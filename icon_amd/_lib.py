@@ -30,7 +30,7 @@ SYMBOLS = [
     "icon_mlp_create", "icon_mlp_destroy", "icon_mlp_forward", "icon_mlp_set_last_op",
     "icon_work_create", "icon_work_destroy", "icon_work_profile", "icon_work_stage_ms", "icon_work_profile_detail", "icon_work_profile_workgroups", "icon_work_set_steal", "icon_work_set_reserve_cus",
     "icon_query_points", "icon_query_points_dcalib", "icon_query_rows", "icon_grid_rows",
-    "icon_adaptive_eval", "icon_adaptive_counts", "icon_adaptive_reruns", "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish", "icon_grid_slab_features_msg",
+    "icon_volume_any_above", "icon_adaptive_eval", "icon_adaptive_counts", "icon_adaptive_reruns", "icon_grid_eval_slab", "icon_grid_slab_features", "icon_grid_slab_finish", "icon_grid_slab_features_msg",
     "icon_grid_slab_finish_gathered", "icon_debug_set_shell_skip", "icon_debug_set_option", "icon_work_status", "icon_sdf_query_ties", "icon_work_set_tie_rule",
     "icon_export_mesh", "icon_mc_count", "icon_mc_emit", "icon_mc_count_range", "icon_mc_emit_keyed", "icon_debug_traversal_stats", "icon_debug_set_unfused",
     "icon_visibility", "icon_mesh_components", "icon_clean_mesh", "icon_semantic_voxelize",

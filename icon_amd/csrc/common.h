@@ -382,6 +382,7 @@ struct icon_work {
     // icon_adaptive_eval with host counts (it synchronises at its end anyway): the fused kernels of the schedule raise THIS sticky
     // word instead of d_flag and no k_rescue_fused is launched behind them (three launches at the launch floor per schedule);
     // a raised word makes the call run the schedule again with the per-launch rescue.  Null everywhere else.
+    int *h_any = nullptr;                 // host-mapped word of icon_volume_any_above
     int *defer_range_flag = nullptr;
     int range_reruns = 0;                 // schedules that had to be run again for that reason (icon_adaptive_reruns)
     struct icon_adaptive *ad = nullptr;   // level buffers of icon_adaptive_eval

@@ -210,17 +210,36 @@ __global__ __launch_bounds__(1024) void k_sign_wide(MeshDev m, Calib cal, const 
     if (threadIdx.x == 0) block_counts[blockIdx.x] = __popcll(gm[0]) + __popcll(gm[1]) + __popcll(gm[2]) + __popcll(gm[3]);
 }
 
-// the shell of the planes [za, zb) of a slab whose MLP tiles skipped it: exact zeros (in_cube * pred, HGPIFuNet.py:363)
-__global__ __launch_bounds__(64) void k_shell_zero(float *__restrict__ out, int res, int z0, int za, int zb)
+// the shell of the planes [za, zb) of a slab whose MLP tiles skipped it: exact zeros (in_cube * pred, HGPIFuNet.py:363).
+// The first `row_wgs` workgroups take one ROW per thread and zero its two end points; the workgroups behind them take one FACE
+// row per wavefront (rows y = 0 / res - 1 of every plane, every row of the planes z = 0 / res - 1) and zero it whole with
+// coalesced stores.  (Until round 6: one 64-thread workgroup per row - 66,049 workgroups at 257^3, 16 us of launch rate.)
+__global__ __launch_bounds__(256) void k_shell_zero(float *__restrict__ out, int res, int z0, int za, int zb, int row_wgs)
 {
-    const int64_t row = blockIdx.x;                       // rows of the planes [za, zb)
-    const int iy = (int)(row % res), iz = za + (int)(row / res);
-    float *o = out + ((int64_t)(iz - z0) * res + iy) * res;
-    if (iz == 0 || iz == res - 1 || iy == 0 || iy == res - 1) {
-        for (int x = threadIdx.x; x < res; x += 64) o[x] = 0.0f;
-    } else if (threadIdx.x < 2) {
-        o[threadIdx.x ? res - 1 : 0] = 0.0f;
+    const int planes = zb - za;
+    if ((int)blockIdx.x < row_wgs) {
+        const int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        if (row >= (int64_t)planes * res) return;
+        const int iy = (int)(row % res), iz = za + (int)(row / res);
+        float *o = out + ((int64_t)(iz - z0) * res + iy) * res;
+        o[0] = 0.0f; o[res - 1] = 0.0f;
+        return;
     }
+    // face rows: first the two y-rows of every plane, then the whole planes z = 0 and z = res - 1 where the piece holds them
+    const int f = ((int)blockIdx.x - row_wgs) * 4 + (int)(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int iy, iz;
+    if (f < 2 * planes) { iz = za + (f >> 1); iy = (f & 1) ? res - 1 : 0; }
+    else {
+        const int g = f - 2 * planes;                              // row g of the face planes present: z = 0 first
+        const bool has0 = za == 0, has1 = zb == res;
+        const int pl = g / res;
+        if (pl >= (has0 ? 1 : 0) + (has1 ? 1 : 0)) return;
+        iz = (pl == 0 && has0) ? 0 : res - 1;
+        iy = g % res;
+    }
+    float *o = out + ((int64_t)(iz - z0) * res + iy) * res;
+    for (int x = lane; x < res; x += 64) o[x] = 0.0f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -661,7 +680,9 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
         const int zs = std::max(za, L.off), ze = std::min(zb, L.res - L.off);
         if (L.off) {
             const int64_t rows = (int64_t)(zb - za) * L.res;
-            if (rows > 0) hipLaunchKernelGGL(k_shell_zero, dim3((unsigned)rows), dim3(64), 0, st, d_occ, L.res, L.z0, za, zb);
+            const int row_wgs = (int)((rows + 255) / 256);
+            const int64_t face_rows = 2 * (int64_t)(zb - za) + (int64_t)((za == 0 ? 1 : 0) + (zb == L.res ? 1 : 0)) * L.res;
+            if (rows > 0) hipLaunchKernelGGL(k_shell_zero, dim3((unsigned)(row_wgs + (face_rows + 3) / 4)), dim3(256), 0, st, d_occ, L.res, L.z0, za, zb, row_wgs);
         }
         G.res = L.res; G.z0 = L.z0; G.off = L.off; G.nx = L.res - 2 * L.off; G.zs = zs;
         N = (ze > zs) ? (int64_t)(ze - zs) * G.nx * G.nx : 0;

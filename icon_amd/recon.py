@@ -649,6 +649,14 @@ class DenseReconEngine(nn.Module):
         (seg3d_lossless.py:173-177); those points are the stride-s sub-lattice of ours."""
         rs = self._res()
         st = [max((rs[-1][k] - 1) // max(rs[0][k] - 1, 1), 1) for k in range(3)]   # x, y, z
+        if occ.is_cuda and occ.is_contiguous() and occ.dtype == torch.float32 and occ.shape[0] == occ.shape[1] == occ.shape[2]:
+            # one native kernel + the stream wait the reference's own test implies (icon_volume_any_above)
+            from .engine import _stream
+            hit = C.c_int(0)
+            with torch.cuda.device(occ.device):
+                check(_lib.lib().icon_volume_any_above(_lib.ptr(occ), C.c_int(occ.shape[0]), C.c_int(st[0]), C.c_int(st[1]), C.c_int(st[2]),
+                                                       C.c_float(0.5), _mc_workspace(occ.device).h, _stream(), C.byref(hit)), "icon_volume_any_above")
+            return occ if hit.value else None
         if (occ[::st[2], ::st[1], ::st[0]] > 0.5).sum() == 0:
             return None
         return occ

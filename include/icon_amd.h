@@ -369,6 +369,12 @@ int icon_work_set_tie_rule(icon_work_t *work, int rule, int ulps);
  * LONGEST walk (what a latency-bound launch - fewer packets than wave slots - waits for). */
 int icon_debug_traversal_stats(const icon_mesh_t *mesh, int res, int z0, int z1, uint64_t out[4]);
 
+/* Seg3dLossless._forward_faster's None rule (lib/common/seg3d_lossless.py:173-177: the call returns None when nothing exceeds
+ * 0.5 on the COARSEST lattice) for a dense device volume d_occ [res,res,res]: the coarsest lattice is the sub-lattice of strides
+ * (sx, sy, sz).  *h_any = 1 when one of its points exceeds `level`, else 0.  One kernel writing a host-mapped word, then the call
+ * waits for the stream - the same synchronisation point the reference's `(occupancys > 0.5).sum() == 0` is. */
+int icon_volume_any_above(const float *d_occ, int res, int sx, int sy, int sz, float level, icon_work_t *work, void *stream, int *h_any);
+
 /* ---------------------------------------------------------------------------------------------
  * Seg3dLossless.export_mesh (lib/common/seg3d_lossless.py:583-604): marching cubes at 0.5 on
  * occ[1:,1:,1:]; vertices returned as (x,y,z) in voxel units of the cropped grid

@@ -253,3 +253,32 @@ def test_schedule_defers_the_range_rescue_and_reruns_when_it_fires(body):
     got2, _, _ = flat.adaptive_eval(feat, [9, 17, 33], counts=False)
     torch.cuda.synchronize()
     assert torch.equal(bits(got2), bits(got)) and flat._work().adaptive_reruns() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# the None rule of reconEngine.forward as one native kernel
+# ---------------------------------------------------------------------------------------------
+def test_none_rule_kernel_equals_the_torch_expression():
+    """Seg3dLossless._forward_faster returns None when nothing exceeds 0.5 on its COARSEST lattice (seg3d_lossless.py:173-177) -
+    for a dense volume the sub-lattice of stride (res_last - 1) / (res_first - 1).  icon_volume_any_above against
+    `(occ[::s, ::s, ::s] > 0.5).sum() == 0`: volumes whose only voxel above the level sits ON the sub-lattice (first, last, inner
+    point) and one step OFF it (the rule must not see it), an all-below volume, exactly 0.5 (not above)."""
+    from icon_amd.recon import DenseReconEngine
+    for res_list in ([33, 65, 129], [17, 129], [65]):
+        rec = DenseReconEngine(resolutions=res_list, align_corners=True).to(dev())
+        r, s = res_list[-1], (res_list[-1] - 1) // max(res_list[0] - 1, 1)
+        base = torch.full((r, r, r), 0.25, device=dev())
+        cases = [((0, 0, 0), True), ((r - 1, r - 1, r - 1), True), ((s, 2 * s % r, 0), True), ((r - 1, 0, s), True)]
+        if s > 1:
+            cases += [((1, 0, 0), False), ((s, s, s + 1), False), ((s - 1, s, s), False)]
+        for (z, y, x), seen in cases:
+            vol = base.clone()
+            vol[z, y, x] = 0.75
+            want = not bool((vol[::s, ::s, ::s] > 0.5).sum() == 0)
+            assert want == seen, (res_list, z, y, x)
+            got = rec._none_if_empty(vol)
+            assert (got is not None) == seen, (res_list, z, y, x)
+            assert got is None or got.data_ptr() == vol.data_ptr()
+        assert rec._none_if_empty(base) is None
+        edge = base.clone(); edge[0, 0, 0] = 0.5
+        assert rec._none_if_empty(edge) is None

@@ -398,8 +398,25 @@ def test_bench_self_launch_two_ranks_on_one_gpu():
     assert p.returncode == 0, p.stderr[-3000:]
     out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     assert out["n_gpus"] == 2 and len(out["config"]["rank_stage_ms"]) == 2 and out["config"]["parallelism"] == "zslab2"
+    # default: the 'ab' layout - two Z-slabs per rank, in lattice order A_0, A_1, B_0, B_1; no assembly copies
+    assert out["config"]["slab_layout"] == "ab" and out["config"]["assembly_copies"] == 0 and out["config"]["gather_to"] is None
+    pc = out["config"]["pieces"]
+    order = [pc[0][0], pc[1][0], pc[0][1], pc[1][1]]
+    assert order[0][0] == 0 and order[-1][1] == 65 and all(a[1] == b[0] for a, b in zip(order[:-1], order[1:])), pc
+    # the round-5 layout on request: one contiguous slab per rank
+    p = subprocess.run(base + ["--slab-layout", "contiguous"], env=dict(env, ICON_AMD_DIST_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["slab_layout"] == "contiguous"
     planes = [r["planes"] for r in out["config"]["rank_stage_ms"]]
     assert planes[0][0] == 0 and planes[0][1] == planes[1][0] and planes[1][1] == 65
+    # ... and only rank 0 receiving the volume
+    p = subprocess.run(base + ["--gather-to", "0"], env=dict(env, ICON_AMD_DIST_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    out = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["gather_to"] == 0 and out["config"]["slab_layout"] == "ab"
     # BASELINE.json configs[4]: one image per GPU, whole volumes, no data-path collective
     p = subprocess.run(base + ["--replicas"], env=dict(env, ICON_AMD_DIST_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                        text=True, timeout=900)

@@ -24,6 +24,8 @@ timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_adaptive -- e
 timeout 200 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/${T}_meshbuild -- python $R/tools/time_mesh_build.py 20 > $R/gpurun_out/${T}_meshbuild.log 2>&1
 cd $R
 python tools/rocprof_summary.py stats $(find gpurun_out/${T}_stats -name "*.db" | head -1) > gpurun_out/${T}_kernel_stats.csv; head -9 gpurun_out/${T}_kernel_stats.csv
+# every launch of the dominant kernel (2 warm-up + 10 timed steps) beside the bench line of the SAME run (its roofline.wg_span_ms is the last step's)
+(python tools/rocprof_summary.py launches $(find gpurun_out/${T}_stats -name "*.db" | head -1) k_fused_f16x3; grep '^{"metric"' gpurun_out/${T}_stats.log | python -c "import sys, json; r = json.loads(sys.stdin.read())['roofline']; print('# bench line of this run: avg_launch_ms', r['avg_launch_ms'], 'wg_span_ms', r.get('wg_span_ms'), 'tail_ms', r.get('tail_ms'), 'tail_inside_kernel_ms', r.get('tail_inside_kernel_ms'), 'per_xcd_clock_mhz', [round(x) for x in r.get('per_xcd_clock_mhz', [])], 'per_xcd_tiles', r.get('per_xcd_tiles'))") > gpurun_out/${T}_fused_launches.txt; tail -2 gpurun_out/${T}_fused_launches.txt | cut -c1-300
 python tools/rocprof_summary.py traffic $(find gpurun_out/${T}_fetch -name "*.db" | head -1) $(find gpurun_out/${T}_write -name "*.db" | head -1) > gpurun_out/${T}_traffic.json
 python tools/pmc_extract.py $(find gpurun_out/${T}_pmc -name "*.db" | head -1) | grep -A9 "k_fused\|k_nearest" > gpurun_out/${T}_pmc.txt
 if [ -n "$WITH_LDS" ]; then

@@ -1,6 +1,7 @@
 """Summaries of rocprofv3 result databases for profiles/ (the .db files themselves stay in gpurun_out/).
   kernel stats : python tools/rocprof_summary.py stats <results.db> > profiles/rNN_kernel_stats_X.csv
   timeline     : python tools/rocprof_summary.py timeline <results.db> <last N dispatches>
+  launches     : python tools/rocprof_summary.py launches <results.db> <kernel name part>     (every launch's duration)
   HBM traffic  : python tools/rocprof_summary.py traffic <fetch.db> <write.db> > profiles/traffic.json
 FETCH_SIZE / WRITE_SIZE are in KiB per dispatch.  MI355X_MICROARCH.md (HBM section): on gfx950 FETCH_SIZE reports
 half of the bytes of a wide (16 B/lane) coalesced streaming read; other access widths and WRITE_SIZE are
@@ -75,6 +76,20 @@ def timeline(path, last):
         prev_end = e_
 
 
+def launches(path, needle):
+    """every dispatch of the kernels whose name contains `needle`, in launch order: duration (us).  The stats view averages over
+    ALL launches of a run, the untimed warm-up steps included (cold clocks, first touch): this is the list behind the average"""
+    cur = sqlite3.connect(path).cursor()
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    sel = [(short(n), (e_ - s_) / 1e3) for n, s_, e_ in rows if needle in n]
+    print("kernel,launch,dur_us")
+    for k, (n, d) in enumerate(sel):
+        print(f"\"{n}\",{k},{d:.2f}")
+    if sel:
+        ds = sorted(d for _, d in sel)
+        print(f"# {len(sel)} launches: min {ds[0]:.2f} median {ds[len(ds) // 2]:.2f} max {ds[-1]:.2f} mean {sum(ds) / len(ds):.2f} us")
+
+
 def counters(path, counter):
     cur = sqlite3.connect(path).cursor()
     q = cur.execute("select kernel_name, avg(value), count(*) from counters_collection where counter_name = ? group by kernel_name",
@@ -120,5 +135,7 @@ if __name__ == "__main__":
         stats(sys.argv[2])
     elif sys.argv[1] == "timeline":
         timeline(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "launches":
+        launches(sys.argv[2], sys.argv[3])
     else:
         traffic(sys.argv[2], sys.argv[3])
