@@ -892,15 +892,20 @@ a = synth.make_assets("body")
 T = lambda x: torch.from_numpy(x).to(dev)
 out = {}
 for cmap_mode in ("reference", "local"):
-    for overlap in (True, False):
+    for overlap, layout, gather_to in ((True, "ab", None), (True, "ab", 0), (True, "contiguous", None), (False, "ab", None)):
         eng = IconQueryEngine(prior_type="icon", sdf_clip=a.sdf_clip, cmap_mode=cmap_mode)
         eng.set_mesh(T(a.smpl_verts), T(a.smpl_faces), T(a.smpl_cmap), T(a.smpl_vis))
         eng.set_regressor({k: torch.from_numpy(v) for k, v in a.state_dict.items()})
-        rec = DenseReconEngine(query_func=query_func, resolutions=[17, 65], align_corners=True, engine=eng, overlap_gather=overlap).to(dev)
+        rec = DenseReconEngine(query_func=query_func, resolutions=[17, 65], align_corners=True, engine=eng, overlap_gather=overlap,
+                               slab_layout=layout, gather_to=gather_to).to(dev)
         want = eng.eval_slab(T(a.features), 65, 0, 65)
-        got = rec._forward_sharded(eng, T(a.features), 65, dist, 1, 0)          # the N > 1 code path, one rank: RCCL broadcast / all_gather / async handles
-        assert torch.equal(got, want), (cmap_mode, overlap)
+        got = rec._forward_sharded(eng, T(a.features), 65, dist, 1, 0)          # the N > 1 code path, one rank: RCCL broadcast / all_gather / gather / async handles
+        assert torch.equal(got, want), (cmap_mode, overlap, layout, gather_to)
         assert rec.last_stats["slabs"] == [(0, 65)]
+        ab = overlap and layout == "ab"
+        assert rec.last_stats.get("layout", "contiguous") == ("ab" if ab else "contiguous")
+        if ab:      # two slabs of the one rank, two sign gathers into one buffer, two volume gathers (all_gather or gather) into one result
+            assert rec.last_stats["pieces"] == [((0, 33), (33, 65))] and rec.last_stats["assembly_copies"] == 0 and got.storage_offset() == 0
 dist.barrier(); dist.destroy_process_group()
 print("NCCL-WORLD1-OK")
 '''
@@ -908,7 +913,7 @@ print("NCCL-WORLD1-OK")
 
 def test_sharded_path_on_rccl_world_size_one():
     """every collective call of the Z-slab path (cut broadcast, int8 message all_gather, the two asynchronous volume gathers
-    and their handles) issued on the real backend - "nccl" = RCCL - with one rank: API and dtype compatibility that the gloo
+    and their handles; round 6: the 'ab' layout's gathers into views of one result buffer, `dist.gather` for gather_to) issued on the real backend - "nccl" = RCCL - with one rank: API and dtype compatibility that the gloo
     tests cannot vouch for; the volume must equal the unsharded one bit for bit"""
     import os
     import socket
