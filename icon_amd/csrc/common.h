@@ -397,7 +397,7 @@ struct icon_work {
     double clock_kernel_ms = 0.0;
     // the fused kernel's tile partition (icon_work_set_steal): the last steal_permille / 1000 of the tiles are not assigned
     // to a workgroup up front but drawn in contiguous groups of steal_grp by whoever finishes its static run first
-    unsigned int *d_steal = nullptr;         // [2] ticket counter, finished-workgroup counter (self-cleaning, fused_f16x3.hip)
+    unsigned int *d_steal = nullptr;         // [9] one ticket counter per XCD's list, finished-workgroup counter (self-cleaning, fused_f16x3.hip)
     int steal_permille = 150, steal_grp = 2;
     bool ev_valid = false;
 };

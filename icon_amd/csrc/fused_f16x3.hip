@@ -84,18 +84,50 @@ struct FusedGeom {
     // hardware ids (XCC_ID, HW_ID) and the tiles it evaluated (static run + stolen) - icon_work_profile_workgroups: the span of
     // every workgroup, the clock of every XCD, the tail of the launch (kernel time - median span)
     unsigned long long *clock;
-    // static-plus-stealing partition: the tiles [0, steal_from) are cut into one contiguous run per workgroup as before; the
-    // tiles behind them are handed out in contiguous groups of steal_grp from steal[0] (a ticket counter; steal[1] counts the
-    // workgroups that have finished - the last one zeroes both, so the pair is clean for the next launch on the stream without
-    // a memset).  steal == nullptr: the whole launch is static (SMALL variants, device-side N).
+    // static runs + XCD-local pools: the tiles are cut into one contiguous SPAN per workgroup (as the static partition of rounds
+    // 1-5 cut them); a workgroup runs the first steal_static tiles of its span itself, the rest of every span is cut into
+    // steal_ngrp groups of steal_grp tiles that whoever finishes first draws - from the spans of ITS OWN XCD first (block b runs on
+    // XCD b mod 8: list x = the groups of the workgroups x, x + 8, ... in order; steal[x] is its ticket counter), from the next
+    // XCD's list once its own is exhausted.  A die that holds a lower clock under the power limit leaves groups to the others;
+    // tiles change XCD - and with them the triangles and texels in that XCD's L2 - only for the few percent that really move.
+    // steal[8] counts the workgroups that have finished; the last one zeroes all nine words (clean for the next launch, no
+    // memset).  steal == nullptr: the whole launch is static (SMALL variants, device-side N).
     unsigned int *steal;
-    int64_t steal_from;
-    int steal_grp;
+    int steal_static, steal_grp, steal_ngrp;
 };
-// the workgroup's draw state: six LDS words in the slack behind the side arrays
+// the workgroup's draw state and the partition's parameters: nine LDS words in the slack behind the side arrays (as scalars they
+// pushed the MFMA body's spills past the 64 a vector register holds: 20 bytes of scratch per lane)
 constexpr int kPoolOff = kSideOff + kSideFloats * 4;
-enum { kPoolNext = 0, kPoolOrigin, kPoolGroup, kPoolTiles, kPoolDone, kPoolWords };
+enum { kPoolNext = 0, kPoolMask, kPoolDone, kPoolPer, kPoolRem, kPoolStatic, kPoolGroup, kPoolNGrp, kPoolGrid, kPoolWords };
 static_assert(kPoolOff + 4 * kPoolWords <= kSideOff + 4352, "the draw state lives in the slack behind the side arrays");
+constexpr int kPoolLenShift = 24;                        // kPoolNext = first tile | tiles << 24 (tiles < 2^23: N < 2^31), -1: none
+constexpr int kMaxStealGroup = 127;
+
+// One draw (one lane): the next group of this workgroup - own XCD's list first.  Writes kPoolNext (and the exhausted-lists mask).
+__device__ __forceinline__ void pool_draw(unsigned int *steal, volatile int *pool)
+{
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    const int per = pool[kPoolPer], rem = pool[kPoolRem], stat = pool[kPoolStatic], grp = pool[kPoolGroup], ngrp = pool[kPoolNGrp],
+              grid = pool[kPoolGrid];
+    int mask = pool[kPoolMask], word = -1;
+    for (int s = 0; s < 8 && word < 0; ++s) {
+        const int x = (int)((xcc + (unsigned)s) & 7u);
+        if ((mask >> x) & 1) continue;
+        const int nwg = (grid - x + 7) >> 3;                 // workgroups x, x + 8, ... below the grid size (<= 0: none)
+        for (;;) {
+            const int t = (int)atomicAdd(steal + x, 1u);
+            if (t >= nwg * ngrp) { mask |= 1 << x; break; }  // this list is exhausted: never asked again by this workgroup
+            const int k = t / ngrp, g = t - k * ngrp, b = x + 8 * k;
+            const int sb = b * per + min(b, rem), eb = sb + per + (b < rem ? 1 : 0);
+            const int a = sb + stat + g * grp;
+            if (a < eb) { word = a | (min(grp, eb - a) << kPoolLenShift); break; }
+            // (the last group of a span one tile shorter than the longest is empty: draw again)
+        }
+    }
+    pool[kPoolMask] = mask;
+    pool[kPoolNext] = word;
+}
 
 __device__ __forceinline__ void wg_stamp(unsigned long long *rec)
 {
@@ -405,38 +437,31 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
     // reads per 257^3 launch when the tiles stopped being 1 KiB-aligned runs of the linear order)
     const int tp = (SMALL && G.N <= (int64_t)(kTilePts / 2) * gridDim.x) ? kTilePts / 2 : kTilePts;       // points per tile (wave-uniform)
     const int ntiles = (int)((G.N + tp - 1) / tp);                  // N < 2^31 (checked by the launcher)
-    // the static part: [0, nstat) in one contiguous run per workgroup; behind it the pool the early finishers draw from.
-    // What the draws need (pool origin, group size, tile count) and the workgroup's draw state live in six LDS words, not in
-    // scalar registers: the MFMA body below spills its scalars into vector lanes, and 64 spilled scalars are one more vector
-    // register than the kernel has (measured: 66 spills = 20 bytes of scratch per lane)
+    // the workgroup's span of the tiles, and of it the static run it evaluates itself (all of it when the launch is static)
     const bool stealing = !SMALL && G.steal != nullptr;
-    const int nstat = stealing ? (int)G.steal_from : ntiles;
-    const int per = nstat / (int)gridDim.x, rem = nstat % (int)gridDim.x;
+    const int per = ntiles / (int)gridDim.x, rem = ntiles % (int)gridDim.x;
     int tile = (int)blockIdx.x * per + min((int)blockIdx.x, rem);
-    int tile_end = __builtin_amdgcn_readfirstlane(tile + per + ((int)blockIdx.x < rem ? 1 : 0));
+    int tile_end = tile + (stealing ? min(G.steal_static, per) : per + ((int)blockIdx.x < rem ? 1 : 0));
     tile = __builtin_amdgcn_readfirstlane(tile);
+    tile_end = __builtin_amdgcn_readfirstlane(tile_end);
     volatile int *pool = reinterpret_cast<volatile int *>(smem + kPoolOff);
     if (!SMALL) {
         if (threadIdx.x == 0) {
-            pool[kPoolOrigin] = nstat; pool[kPoolGroup] = G.steal_grp; pool[kPoolTiles] = ntiles; pool[kPoolDone] = 0;
-            int nb = 0;                                      // (any value >= 0: the pool is open)
-            if (stealing && tile >= tile_end) {              // no static run at all (fewer static tiles than workgroups): draw now
-                nb = nstat + (int)atomicAdd(G.steal, 1u) * G.steal_grp;
-                if (nb >= ntiles) nb = -1;
-            }
-            pool[kPoolNext] = nb;
+            pool[kPoolPer] = per; pool[kPoolRem] = rem; pool[kPoolStatic] = G.steal_static; pool[kPoolGroup] = G.steal_grp;
+            pool[kPoolNGrp] = G.steal_ngrp; pool[kPoolGrid] = (int)gridDim.x; pool[kPoolDone] = 0; pool[kPoolMask] = 0; pool[kPoolNext] = -1;
+            if (stealing && tile >= tile_end) pool_draw(G.steal, pool);      // no static run at all: draw now
         }
         __syncthreads();
         if (stealing && tile >= tile_end) {
-            const int nb = __builtin_amdgcn_readfirstlane(pool[kPoolNext]);
+            const int word = __builtin_amdgcn_readfirstlane(pool[kPoolNext]);
             __syncthreads();                                 // (every wave has read the word before a draw of the loop rewrites it)
-            if (nb >= 0) { tile = nb; tile_end = min(nb + G.steal_grp, ntiles); }
+            if (word >= 0) { tile = word & ((1 << kPoolLenShift) - 1); tile_end = tile + (word >> kPoolLenShift); }
         }
     }
     if (tile < tile_end) issue_chunk(w.image, smem, 0, wave0, lane0);
 
-    // `nb`: the first tile of the group drawn while the LAST tile of the current run is in flight (-1: none, or no draw) - one
-    // returned atomic of wave 4, which has no work item in the feature phase; the barrier that publishes the tile publishes it
+    // `nb`: the group drawn while the LAST tile of the current run is in flight (first tile | tiles << 24; -1: none, or no draw) -
+    // a few returned atomics of wave 4, which has no work item in the feature phase; the barrier that publishes the tile publishes it
     for (int nb = -1; tile < tile_end;) {
         // Everything derived from the thread index is re-derived per tile from an opaque copy: hoisted out of
         // the loop, those ~20 lane-dependent addresses would have to stay live across the 250-register MFMA
@@ -448,10 +473,7 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         // ---- feature phase: waves 0-3, one work item per thread -> Xs[t][16] -----------------------------
         const int t = tid;
         const bool draw = !SMALL && stealing && tile + 1 == tile_end;       // wave-uniform: this is the run's last tile
-        if (!SMALL && draw && t == 256 && pool[kPoolNext] >= 0) {
-            const int g = pool[kPoolOrigin] + (int)atomicAdd(G.steal, 1u) * pool[kPoolGroup];
-            pool[kPoolNext] = g < pool[kPoolTiles] ? g : -1;    // -1: the pool is empty, this workgroup draws no more
-        }
+        if (!SMALL && draw && t == 256) pool_draw(G.steal, pool);           // (-1: every list is exhausted)
         const bool worker = t < tp;                             // wave-uniform
         int64_t q = (int64_t)tile * tp + (worker ? t : 0);
         if (q >= G.N) q = G.N - 1;                               // padding lanes of the last tile recompute its last item
@@ -537,15 +559,16 @@ __global__ __launch_bounds__(kF16Block, 2) void k_fused_f16x3(FusedGeom G, float
         }
         // the next tile: the one behind this, or the first of the group drawn during this one
         if (!SMALL && nb >= 0) {
-            tile = nb;
-            tile_end = min(nb + __builtin_amdgcn_readfirstlane(pool[kPoolGroup]), __builtin_amdgcn_readfirstlane(pool[kPoolTiles]));
+            tile = nb & ((1 << kPoolLenShift) - 1);
+            tile_end = tile + (nb >> kPoolLenShift);
         } else ++tile;
     }
     if (!SMALL && stealing && threadIdx.x == 0) {
         // the last workgroup to finish leaves the pair clean for the next launch (every draw of this launch precedes its
         // workgroup's arrival here in program order; agent-scope atomics on both words)
         __threadfence();
-        if (atomicAdd(G.steal + 1, 1u) == gridDim.x - 1) { atomicExch(G.steal, 0u); atomicExch(G.steal + 1, 0u); }
+        if (atomicAdd(G.steal + 8, 1u) == gridDim.x - 1)
+            for (int k = 0; k < 9; ++k) atomicExch(G.steal + k, 0u);
     }
     if (G.clock && threadIdx.x == 0 && blockIdx.x < kMaxProfGrid) {
         if (blockIdx.x == 0) wg_stamp(G.clock + 2);
@@ -693,7 +716,7 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     G.near = work_near(work, mesh); G.code8 = work->d_code8;
     if (!lattice) { G.n_dev = work->q_n_dev; G.out_map = work->q_map; }
     G.clock = work->prof ? work->d_clock : nullptr;
-    G.steal = nullptr; G.steal_from = 0; G.steal_grp = 1;
+    G.steal = nullptr; G.steal_static = 0; G.steal_grp = 1; G.steal_ngrp = 0;
     G.block_offsets = work->d_block_offsets; G.grp_mask = (const unsigned long long *)work->d_grp_mask;
     G.sg.mode = fs.mode; G.sg.list = fs.list; G.sg.k_dev = fs.k_dev; G.sg.k_host = fs.k_host; G.sg.rank_offset = fs.rank_offset;
     G.sg.gathered = fs.gathered; G.sg.stride = fs.stride; G.sg.world = fs.world; G.sg.rank = fs.rank; G.sg.seg = nullptr;
@@ -728,11 +751,17 @@ int launch_fused_f16x3(const icon_mesh *mesh, const icon_feat *feat, const icon_
     // one persistent workgroup per CU (LDS-bound: 132 KiB, all registers).  Multi-GPU: a collective's kernels cannot co-reside
     // with it on a CU - icon_work_set_reserve_cus leaves some CUs to them
     const unsigned grid = (unsigned)std::min<int64_t>(ntiles, std::max(n_cu - work->reserve_cus, 1));
-    if (!small && work->d_steal && work->steal_permille > 0 && ntiles > (int64_t)grid) {
-        // static-plus-stealing: a workgroup's span depends on its planes (the clip band costs more per tile than the far
-        // field) and on its XCD's clock under the power limit; the launch ends with the slowest one.  The pool evens it out.
-        G.steal = work->d_steal; G.steal_grp = work->steal_grp;
-        G.steal_from = ntiles - ntiles * work->steal_permille / 1000;
+    {
+        // static runs + XCD-local pools: a workgroup's time depends on its XCD's clock under the power limit (and a little on its
+        // planes: the clip band costs more per tile than the far field); the launch ends with the slowest one.  The last
+        // steal_permille / 1000 of every workgroup's span is handed out in groups to whoever finishes first.
+        const int per = (int)(ntiles / grid);
+        const int pool_len = (int)((int64_t)per * work->steal_permille / 1000);
+        if (!small && work->d_steal && pool_len > 0 && ntiles > (int64_t)grid) {
+            G.steal = work->d_steal; G.steal_grp = std::min(work->steal_grp, kMaxStealGroup);
+            G.steal_static = per - pool_len;
+            G.steal_ngrp = (pool_len + 1 + G.steal_grp - 1) / G.steal_grp;     // covers the spans that are one tile longer
+        }
     }
     if (G.clock) work->clock_grid = (int)std::min<unsigned>(grid, (unsigned)kMaxProfGrid);
 #define ICON_FUSED(P, L_, ID, ...)                                                                                         \

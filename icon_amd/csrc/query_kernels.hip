@@ -772,11 +772,11 @@ extern "C" int icon_work_profile_workgroups(icon_work_t *w, double *rec, int cap
     return ICON_OK;
 }
 
-// permille of the fused kernel's tiles that are drawn dynamically (0 = the static partition of rounds 1-5), in contiguous
-// groups of `group` tiles.  Any setting gives the same volume bit for bit (a tile's result does not depend on who evaluates it).
+// permille of every workgroup's span of tiles that is drawn dynamically (0 = the static partition of rounds 1-5), in contiguous
+// groups of `group` tiles (<= 127), own XCD's spans first.  Any setting gives the same volume bit for bit (a tile's result does not depend on who evaluates it).
 extern "C" int icon_work_set_steal(icon_work_t *w, int permille, int group)
 {
-    ICON_ARG(w != nullptr && permille >= 0 && permille <= 1000 && group >= 1 && group <= 4096, "icon_work_set_steal: bad argument");
+    ICON_ARG(w != nullptr && permille >= 0 && permille <= 1000 && group >= 1 && group <= 127, "icon_work_set_steal: bad argument");
     w->steal_permille = permille; w->steal_grp = group;
     return ICON_OK;
 }
@@ -964,8 +964,8 @@ int ensure_work(icon_work *w, int64_t n_points, bool need_x)
     if (!w->d_total) ICON_HIP(hipMalloc((void **)&w->d_total, sizeof(int64_t)));
     if (!w->d_flag) ICON_HIP(hipMalloc((void **)&w->d_flag, sizeof(int)));
     if (!w->d_steal) {
-        ICON_HIP(hipMalloc((void **)&w->d_steal, 2 * sizeof(unsigned int)));
-        ICON_HIP(hipMemset(w->d_steal, 0, 2 * sizeof(unsigned int)));     // (synchronous with respect to the host: ordered before any launch)
+        ICON_HIP(hipMalloc((void **)&w->d_steal, 9 * sizeof(unsigned int)));
+        ICON_HIP(hipMemset(w->d_steal, 0, 9 * sizeof(unsigned int)));     // (synchronous with respect to the host: ordered before any launch)
     }
     if (!w->d_seg) ICON_HIP(hipMalloc((void **)&w->d_seg, (kMaxWorld + 1) * sizeof(int64_t)));
     return ICON_OK;

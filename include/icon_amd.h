@@ -194,8 +194,9 @@ int icon_work_profile_detail(icon_work_t *work, double out[4]);
  * lattice points it evaluated (static run + drawn from the pool).  *n = workgroups of the launch; at most cap records are
  * written.  bench.py derives roofline.wg_span_ms / per_xcd_clock_mhz / tail_ms from it. */
 int icon_work_profile_workgroups(icon_work_t *work, double *rec, int cap, int *n);
-/* The fused MLP kernel's tile partition: the first (1000 - permille) / 1000 of a launch's tiles are cut into one contiguous
- * run per workgroup, the rest is a pool that workgroups draw from in contiguous groups of `group` tiles as they finish.
+/* The fused MLP kernel's tile partition: the tiles are cut into one contiguous span per workgroup; a workgroup evaluates the first
+ * (1000 - permille) / 1000 of its span itself, the rest of every span is drawn in contiguous groups of `group` tiles (1 .. 127) by
+ * the workgroups that finish first - from the spans of their own XCD first (one L2 per XCD), then from the others'.
  * permille = 0: all static.  Default 150, 2.  The result does not depend on the setting (bit for bit). */
 int icon_work_set_steal(icon_work_t *work, int permille, int group);
 

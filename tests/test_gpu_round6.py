@@ -28,8 +28,8 @@ def bits(t):
 def test_steal_partition_is_free(body, cmap_mode):
     """a tile's result does not depend on which workgroup evaluates it or when: every (pool share, group size) reproduces the
     all-static volume of rounds 1-5 bit for bit - incl. everything pooled (no static run: the first group is drawn before
-    the loop), one-tile groups (a draw per tile), groups larger than the pool (one workgroup takes it whole), and a slab that
-    is not the whole lattice.  NaN-prefilled outputs: a tile nobody evaluated would show."""
+    the loop), one-tile groups (a draw per tile), groups larger than a span's pool part (one draw takes it whole), a pool share
+    that rounds to no tile at all (static), and a slab that is not the whole lattice.  NaN-prefilled outputs: a tile nobody evaluated would show."""
     feat = T(body.features)
     eng = make_engine(body, cmap_mode=cmap_mode)
     res = 129                                     # 127^3 interior points = 8,002 tiles of 256 > 256 workgroups
@@ -38,7 +38,7 @@ def test_steal_partition_is_free(body, cmap_mode):
     want = eng.eval_slab(feat, res, 0, res).clone()
     want_part = eng.eval_slab(feat, res, 40, 97).clone()
     assert float(want.max()) > 0.5 and torch.isfinite(want).all()
-    for permille, group in [(100, 2), (100, 1), (37, 3), (500, 8), (1000, 1), (1000, 7), (1000, 4096), (999, 2), (1, 1)]:
+    for permille, group in [(100, 2), (100, 1), (37, 3), (500, 8), (1000, 1), (1000, 7), (1000, 127), (999, 2), (1, 1), (400, 127)]:
         w.set_steal(permille, group)
         for rep in range(2):                      # twice: the second launch finds the ticket pair as the first left it (clean)
             out = torch.full((res, res, res), float("nan"), device=dev())
@@ -123,8 +123,8 @@ def test_workgroup_profile_records(body):
             if permille == 0:
                 assert rec[:, 4].max() - rec[:, 4].min() <= 1
             else:
-                static = (ntiles - ntiles * permille // 1000) // rec.shape[0]
-                assert rec[:, 4].min() >= static
+                per = ntiles // rec.shape[0]                     # every workgroup evaluates the static part of its own span itself
+                assert rec[:, 4].min() >= per - per * permille // 1000
     finally:
         w.profile(False)
         w.set_steal(150, 2)
