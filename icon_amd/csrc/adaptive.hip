@@ -39,8 +39,12 @@ struct icon_adaptive {
     float *pts = nullptr;                      // their world positions [n][3]
     int32_t *blk_count = nullptr;              // compaction scratch: candidates per 256 voxels, behind them per 64 such blocks (k_ad_mask)
     int32_t *blk_list = nullptr;               // the 4x4x4 blocks holding a candidate (any order; count in counters[8])
-    int *h_counters = nullptr;                 // pinned mirror of `counters` (one direct copy at the end of a schedule, no staging)
-    int *counters = nullptr;                   // device: [0..levels) points queried per level, [8] n_blocks, [9] any-positive flag of level 0
+    int *h_counters = nullptr;                 // host-mapped mirror of `counters`: the last upsample launch of a schedule writes it (no copy launch)
+    int *h_counters_dev = nullptr;             //   ... its device address
+    int *counters = nullptr;                   // device: [0..levels) points queried per level, [8] n_blocks, [9] any-positive flag of level 0, [10] range flag
+    int *counters_base = nullptr;              // TWO sets of 16: a call uses the set the call before did not, and its last upsample launch zeroes
+    int cur_set = 0;                           //   the other one for the call after it (no memset launch ahead of the first kernel)
+    bool other_clean = true;                   // the set the next call will use is zero (false after a call that ended early)
     int64_t cap = 0;                           // voxels of the largest queried level
 };
 
@@ -52,7 +56,7 @@ void adaptive_destroy(icon_adaptive *a)
     for (int l = 0; l + 1 < a->n_levels; ++l) (void)hipFree(a->occ[l]);
     for (int l = 1; l < kAdMaxLevels; ++l) (void)hipFree(a->D[l]);
     (void)hipFree(a->P); (void)hipFree(a->M1); (void)hipFree(a->map); (void)hipFree(a->pts);
-    (void)hipFree(a->blk_count); (void)hipFree(a->blk_list); (void)hipHostFree(a->h_counters); (void)hipFree(a->counters);
+    (void)hipFree(a->blk_count); (void)hipFree(a->blk_list); (void)hipHostFree(a->h_counters); (void)hipFree(a->counters_base);
     delete a;
 }
 
@@ -75,11 +79,19 @@ struct AdBook {
     int *any_pos;                  // level 0 only: some voxel exceeds 0.5 (the reference returns None otherwise, :173-177)
     int32_t *zero;                 // blk_count ++ sup_count of the level that starts here
     int n_zero;
+    // the LAST upsample launch of a schedule of >= 3 levels (every counter is final by then): mirror the 16 counters into the
+    // host-mapped record the call reads after its synchronisation, and zero the set the NEXT call will count in
+    const int *mirror_src;
+    int *mirror_dst, *zero_set;
 };
 __device__ __forceinline__ int64_t xyz(int r, int x, int y, int z);
 __global__ __launch_bounds__(256) void k_ad_up(const float *__restrict__ src, int rp, float *__restrict__ dst, int r, int *__restrict__ n_blocks, AdBook bk)
 {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *n_blocks = 0;     // the block list of the level that starts here (k_ad_mask fills it)
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_blocks) *n_blocks = 0;     // the block list of the level that starts here (k_ad_mask fills it)
+    if (blockIdx.x == 0 && threadIdx.x < 16) {
+        if (bk.mirror_dst) bk.mirror_dst[threadIdx.x] = bk.mirror_src[threadIdx.x];
+        if (bk.zero_set) bk.zero_set[threadIdx.x] = 0;
+    }
     {
         const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
         if (i < bk.n_zero) bk.zero[i] = 0;
@@ -461,14 +473,25 @@ static int adaptive_eval_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, 
         if (!rc) rc = grow(&a->pts, (size_t)a->cap * 3);
         if (!rc) rc = grow(&a->blk_count, (size_t)(a->cap + 255) / 256 + (size_t)((a->cap + 255) / 256 >> kAdSupShift) + 2);
         if (!rc) rc = grow(&a->blk_list, (size_t)nbk * nbk * nbk);
-        if (!rc) rc = grow(&a->counters, (size_t)16);
-        if (!rc && hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocDefault) != hipSuccess)
+        if (!rc) rc = grow(&a->counters_base, (size_t)32);
+        if (!rc && hipMemset(a->counters_base, 0, 32 * sizeof(int)) != hipSuccess) rc = fail(ICON_ERR_HIP, "icon_adaptive_eval: hipMemset of the counters failed");
+        if (!rc && hipHostMalloc((void **)&a->h_counters, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocPortable) != hipSuccess)
             rc = fail(ICON_ERR_HIP, "icon_adaptive_eval: hipHostMalloc of the counter mirror failed");
+        if (!rc && hipHostGetDevicePointer((void **)&a->h_counters_dev, a->h_counters, 0) != hipSuccess)
+            rc = fail(ICON_ERR_HIP, "icon_adaptive_eval: no device address for the counter mirror");
+        a->counters = a->counters_base; a->cur_set = 0; a->other_clean = true;
         if (rc) { adaptive_destroy(a); return rc; }
         work->ad = a;
     }
     a->occ[n_levels - 1] = d_out;
-    ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
+    // this call counts in the set the call before did not use; that set was zeroed by the last upsample launch of the call before
+    // (or has never been used) - unless that call ended early
+    a->cur_set ^= 1;
+    a->counters = a->counters_base + 16 * a->cur_set;
+    if (!a->other_clean) ICON_HIP(hipMemsetAsync(a->counters, 0, 16 * sizeof(int), st));
+    a->other_clean = false;
+    int *const other_set = a->counters_base + 16 * (a->cur_set ^ 1);
+    bool mirrored = false;
     // whatever way this function is left, the workspace must not keep pointing at a level's compaction buffers: a later point
     // query on it would read them as ITS map
     struct QMapGuard { icon_work *w; ~QMapGuard() { w->q_map = nullptr; w->q_n_dev = nullptr; w->defer_range_flag = nullptr; } } q_guard{work};
@@ -504,9 +527,15 @@ static int adaptive_eval_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, 
         bk.any_pos = l == 1 ? a->counters + 9 : nullptr;
         bk.zero = examined ? a->blk_count : nullptr;
         bk.n_zero = examined ? nb_l + nsup_l : 0;
+        if (l == n_levels - 1) {
+            bk.zero_set = other_set;                            // (the set of the call before: nobody reads it any more)
+            a->other_clean = true;
+            if (n_levels >= 3 && h_counts) { bk.mirror_src = a->counters; bk.mirror_dst = a->h_counters_dev; mirrored = true; }
+        }
         const int64_t book = (bk.P || bk.any_pos) ? (nsrc + 255) / 256 : 0;
         const int64_t grid_up = std::max<int64_t>(std::max<int64_t>(((int64_t)r * r + 3) / 4, book), (bk.n_zero + 255) / 256);
-        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)grid_up), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r, a->counters + 8, bk);
+        hipLaunchKernelGGL(k_ad_up, dim3((unsigned)grid_up), dim3(256), 0, st, a->occ[l - 1], rp, a->occ[l], r,
+                           examined ? a->counters + 8 : (int *)nullptr, bk);     // (the last level starts no block list - and the mirror must not see a reset)
         if (!examined) break;                                   // "last step no examine": interpolate only
         // P holds (occ_{l-1} > balance): level 0's from above, later levels' from the end of the previous iteration
         const int rad = l == 1 ? 4 : (l == 2 ? 3 : 1);           // SmoothConv3D 9 / 7 / 3 (seg3d_lossless.py:105-112, 219-226)
@@ -575,9 +604,13 @@ static int adaptive_eval_impl(const icon_mesh_t *mesh, const icon_feat_t *feat, 
         ICON_HIP(hipGetLastError());
     }
     ICON_HIP(hipGetLastError());
+    if (!a->other_clean) {                                      // one level only: no upsample launch to carry the zeroing
+        ICON_HIP(hipMemsetAsync(other_set, 0, 16 * sizeof(int), st));
+        a->other_clean = true;
+    }
     if (h_counts) {
-        int *host = a->h_counters;                              // pinned: one direct copy (a pageable target is staged: two copies and a wait, ~70 us)
-        ICON_HIP(hipMemcpyAsync(host, a->counters, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
+        int *host = a->h_counters;                              // host-mapped: written by the last upsample launch; else one direct copy
+        if (!mirrored) ICON_HIP(hipMemcpyAsync(host, a->counters, 16 * sizeof(int), hipMemcpyDeviceToHost, st));
         ICON_HIP(hipStreamSynchronize(st));
         for (int l = 0; l < n_levels; ++l) h_counts[l] = host[l];
         h_counts[0] = (int64_t)r0 * r0 * r0;                    // level 0 evaluates every voxel
