@@ -593,7 +593,7 @@ def main():
             extras["reference_schedule_ms_per_volume"] = float(np.median(ts))
             extras["reference_schedule_ms"] = {"p50": float(np.percentile(ts, 50)), "p99": float(np.percentile(ts, 99)), "max": float(np.max(ts)),
                                                "calls": len(ts), "gc": "frozen + disabled",
-                                               "launches": "23 kernel launches per [33,65,129,257] schedule, no fill, no copy (profiles/r06_adaptive_timeline.csv)"}
+                                               "launches": "21 kernel launches per [33,65,129,257] schedule, no fill, no copy (profiles/r06_adaptive_timeline.csv)"}
             extras["reference_schedule_native"] = bool(ad.last_stats.get("native", False))
             extras["reference_schedule_points"] = int(sum(ad.last_stats.get("queries", [])))
             # (3) mesh Chamfer / P2S, lib/dataset/Evaluator.py:200-230, in [-1,1]-cube units x100 (apps/ICON.py:758-759)

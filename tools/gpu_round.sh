@@ -34,7 +34,7 @@ python tools/mlp_power_probe.py f16x3 5 > gpurun_out/${T}_power_probe.txt; cat g
 fi
 DBA=$(find gpurun_out/${T}_adaptive -name "*.db" | head -1)
 python tools/rocprof_summary.py stats $DBA > gpurun_out/${T}_adaptive_kernel_stats.csv
-python tools/rocprof_summary.py timeline $DBA 36 > gpurun_out/${T}_adaptive_timeline.csv
+python tools/rocprof_summary.py timeline $DBA 23 > gpurun_out/${T}_adaptive_timeline.csv
 grep "^adaptive" gpurun_out/${T}_adaptive.log | cut -c1-100
 python tools/rocprof_summary.py stats $(find gpurun_out/${T}_meshbuild -name "*.db" | head -1) | grep "k_face_prep\|k_vertex_normals\|k_bvh\|k_tri_records\|k_scan_cells\|k_bin_\|kernel,calls" > gpurun_out/${T}_mesh_build_kernel_stats.csv
 grep "^build 1[0-9]" gpurun_out/${T}_meshbuild.log | cut -c1-170 | head -3
