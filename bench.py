@@ -455,7 +455,8 @@ def main():
         occ = step()
         # stage_ms waits on this step's last event (the MLP) - the same point the reference's
         # `(occupancys > 0.5).sum() == 0` check already synchronises on
-        stage += np.array(eng._work().stage_ms())
+        last_stage = np.array(eng._work().stage_ms())
+        stage += last_stage
         if two_works and recon.last_stats.get("split_features"):
             try:
                 stage += np.array(eng._work(1).stage_ms())     # the rank's stage times = both half-slabs
@@ -749,14 +750,14 @@ def main():
                 "wg_span_ms": {"min": float(span.min()), "median": float(np.median(span)), "max": float(span.max())},
                 "per_xcd_clock_mhz": [float(mhz[xcd == x].mean()) if (xcd == x).any() else None for x in range(8)],
                 "per_xcd_tiles": [int(wg[xcd == x, 4].sum()) for x in range(8)],
-                "tail_ms": float(stage[2] - np.median(span)),
+                "tail_ms": float(last_stage[2] - np.median(span)),
                 "tail_inside_kernel_ms": float((wg[:, 1] + span).max() - np.median(span)),
                 "workgroups": int(len(wg)), "tiles_per_workgroup": {"min": int(wg[:, 4].min()), "max": int(wg[:, 4].max())},
                 "partition": "static runs + a pool (15 % of the tiles by default) drawn in groups of 2 by the workgroups that finish first "
                              "(icon_work_set_steal); the XCDs hold different clocks under the power limit - per_xcd_clock_mhz - and take "
                              "tiles in that proportion - per_xcd_tiles",
-                "wg_note": "last timed step.  tail_ms = avg_launch_ms (HIP events around the kernel and its two 5-us companions) - the median "
-                           "workgroup span; tail_inside_kernel_ms = last workgroup's end - first workgroup's start - median span"})
+                "wg_note": "last timed step.  tail_ms = that step's launch duration (HIP events around the kernel and its two 5-us companions) - "
+                           "the median workgroup span; tail_inside_kernel_ms = last workgroup's end - first workgroup's start - median span"})
         elif not isinstance(wg, np.ndarray):
             out["roofline"]["wg_note"] = wg
         if isinstance(zero_ms, float):
