@@ -505,3 +505,63 @@ def test_attach_refuses_a_network_module_with_maskout_set():
             IconQueryEngine.attach(net())
     finally:
         del sys.modules["fake_hgpifunet"]
+
+
+def test_fused_kernel_tile_partition_covers_every_tile_once():
+    """The tile partition of k_fused_f16x3 (csrc/fused_f16x3.hip: launch_fused_f16x3 + pool_draw), restated on the host: one
+    contiguous span per workgroup; the first steal_static tiles of a span are the workgroup's own run, the rest is cut into
+    steal_ngrp groups of steal_grp tiles; list x = the groups of the workgroups x, x + 8, ...; ticket t of list x -> workgroup
+    x + 8 (t div ngrp), group t mod ngrp (empty for a span one tile shorter than the longest: drawn again).  For random tile
+    counts, grid sizes (not multiples of 8, smaller than 8), pool shares and group sizes, with the workgroups drawing in random
+    order from random home XCDs: every tile is evaluated exactly once and every list ends exhausted."""
+    rng = np.random.RandomState(11)
+    for trial in range(400):
+        grid = int(rng.choice([1, 3, 7, 8, 9, 31, 64, 200, 256, 304]))
+        ntiles = int(grid + 1 + rng.randint(0, 40 * grid)) if trial % 5 else grid + 1
+        permille = int(rng.choice([1, 37, 100, 150, 500, 999, 1000]))
+        grp = int(rng.choice([1, 2, 3, 8, 127]))
+        per, rem = ntiles // grid, ntiles % grid
+        pool_len = per * permille // 1000
+        seen = np.zeros(ntiles, np.int32)
+        span = lambda b: (b * per + min(b, rem), b * per + min(b, rem) + per + (1 if b < rem else 0))
+        if pool_len == 0:                                          # the launcher keeps the launch static
+            for b in range(grid):
+                seen[span(b)[0]:span(b)[1]] += 1
+            assert (seen == 1).all()
+            continue
+        stat, ngrp = per - pool_len, (pool_len + 1 + grp - 1) // grp
+        for b in range(grid):
+            seen[span(b)[0]:span(b)[0] + min(stat, per)] += 1
+        counters = [0] * 8
+        masks = [0] * grid
+
+        def draw(b, xcc):
+            for s in range(8):
+                x = (xcc + s) & 7
+                if (masks[b] >> x) & 1:
+                    continue
+                nwg = (grid - x + 7) >> 3
+                while True:
+                    t = counters[x]; counters[x] += 1
+                    if t >= nwg * ngrp:
+                        masks[b] |= 1 << x
+                        break
+                    k, g = divmod(t, ngrp)
+                    wb = x + 8 * k
+                    sb, eb = span(wb)
+                    a = sb + stat + g * grp
+                    if a < eb:
+                        return a, min(grp, eb - a)
+            return None
+        active = list(range(grid))
+        home = {b: int(rng.randint(0, 8)) if trial % 3 == 0 else b % 8 for b in range(grid)}
+        while active:
+            b = active[int(rng.randint(len(active)))]
+            got = draw(b, home[b])
+            if got is None:
+                active.remove(b)
+            else:
+                assert got[1] <= 127 and got[0] < (1 << 24)        # the packed word: first tile | tiles << 24
+                seen[got[0]:got[0] + got[1]] += 1
+        assert (seen == 1).all(), (grid, ntiles, permille, grp, np.flatnonzero(seen != 1)[:8])
+        assert all(counters[x] >= ((grid - x + 7) >> 3) * ngrp for x in range(8))
