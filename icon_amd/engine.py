@@ -43,7 +43,7 @@ def _key(*tensors) -> tuple:
     the tensors it was made from (kept next to every cached handle): as long as those are alive the
     caching allocator cannot hand the same address to the next image's tensors, so an equal
     (data_ptr, _version, shape) really is the same data."""
-    return tuple((t.data_ptr(), t._version, tuple(t.shape), str(t.device)) for t in tensors)
+    return tuple((t.data_ptr(), t._version, t.shape, t.device) for t in tensors)      # (torch.Size / torch.device compare by value)
 
 
 def _dev_f32(t: torch.Tensor, what: str) -> torch.Tensor:
@@ -843,7 +843,7 @@ class IconQueryEngine:
             self._work().h, _stream()), "icon_grid_eval_slab")
         return out
 
-    def native_schedule_reason(self, im_feat, regressor=None) -> Optional[str]:
+    def native_schedule_reason(self, im_feat, regressor=None, _handle_out: Optional[list] = None) -> Optional[str]:
         """why the reference's coarse-to-fine schedule cannot run as ONE native call (icon_adaptive_eval) for the bound
         regressor / settings - the host-driven schedule of recon.AdaptiveReconEngine takes over then - or None"""
         reg = self._bound_regressor(regressor)
@@ -853,17 +853,19 @@ class IconQueryEngine:
             return "search != 'bvh'"
         if self.tie_rule is not None:
             return "diagnostics tie rule set"
-        self._mlp_handle(regressor)
+        mlp = self._mlp_handle(regressor)
         if getattr(self, "_effective_precision", self.precision) != "f16x3":
             return f"precision {getattr(self, '_effective_precision', self.precision)!r}"
+        if _handle_out is not None:              # the caller runs adaptive_eval(_mlp=...) right behind this check: the key over the
+            _handle_out.append(mlp)              # checkpoint's 21 tensors is computed once per call, not twice
         return None
 
     @_guarded
-    def adaptive_eval(self, im_feat, resolutions: Sequence[int], balance: float = 0.5, regressor=None, counts: bool = True):
+    def adaptive_eval(self, im_feat, resolutions: Sequence[int], balance: float = 0.5, regressor=None, counts: bool = True, _mlp=None):
         """Seg3dLossless._forward_faster (lib/common/seg3d_lossless.py:152-265) as one native call (icon_adaptive_eval): ->
         (volume [R,R,R] of the last resolution, points queried per level, bool: some voxel of the coarsest level > 0.5).
         ``counts=False``: nothing is read back (the last two are None; Workspace counters hold them)."""
-        mesh, mlp, feat = self._mesh_handle(), self._mlp_handle(regressor), self._feat_handle(im_feat)
+        mesh, mlp, feat = self._mesh_handle(), (_mlp if _mlp is not None else self._mlp_handle(regressor)), self._feat_handle(im_feat)
         res = [int(r) for r in resolutions]
         n = len(res)
         out = torch.empty((res[-1],) * 3, dtype=torch.float32, device=im_feat.device)

@@ -937,9 +937,10 @@ class AdaptiveReconEngine(DenseReconEngine):
         if (self.native and self.lattice_level0 and lattice_engine is not None and len(res_list) >= 1
                 and all(res_list[k] == 2 * res_list[k - 1] - 1 for k in range(1, len(res_list)))):
             im_feat = feats[-1] if isinstance(feats, (list, tuple)) else feats
-            why = lattice_engine.native_schedule_reason(im_feat)
+            got = []
+            why = lattice_engine.native_schedule_reason(im_feat, _handle_out=got)
             if why is None:
-                vol, counts, any_pos = lattice_engine.adaptive_eval(im_feat, res_list, float(self.balance_value))
+                vol, counts, any_pos = lattice_engine.adaptive_eval(im_feat, res_list, float(self.balance_value), _mlp=got[0] if got else None)
                 self.last_stats = dict(queries=[counts[0]] + [c for c in counts[1:-1] if c > 0], native=True)
                 return vol if any_pos else None
             refused = why
