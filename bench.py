@@ -582,10 +582,8 @@ def main():
             ts = []
             try:
                 for _ in range(200):
-                    torch.cuda.synchronize()
                     t1 = time.perf_counter()
-                    vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)
-                    torch.cuda.synchronize()
+                    vol_ad = ad(opt=opt, netG=eng, features=feats, proj_matrix=None)     # (returns after its own synchronisation: the counts)
                     ts.append((time.perf_counter() - t1) * 1e3)
             finally:
                 if gc_was:
