@@ -31,7 +31,7 @@ RESULTS = []
 
 
 def report(section, status, text):
-    RESULTS.append((section, status))
+    RESULTS.append((section, status, text))
     print(f"[{status:6s}] {section}: {text}", flush=True)
 
 
@@ -313,6 +313,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--stand-ins", action="store_true", help="self-test: the repo's CPU checkers in the packages' place (must all PASS)")
     ap.add_argument("--strict", action="store_true")
+    ap.add_argument("--json", default="", help="also write the lines as JSON (section, status, text) to this file")
     args = ap.parse_args()
     only = {s for s in args.only.split(",") if s}
     want = lambda k: not only or k in only
@@ -439,9 +440,14 @@ def main():
                                                                       tet, occ, sem, wsum, sigma)
                     return sem[0]
                 sec_voxelize(subject(), their_vox, "voxelize_cuda")
-    n_diff = sum(1 for _, s in RESULTS if s == "DIFF")
-    n_pass = sum(1 for _, s in RESULTS if s == "PASS")
-    n_abs = sum(1 for _, s in RESULTS if s == "ABSENT")
+    n_diff = sum(1 for r in RESULTS if r[1] == "DIFF")
+    n_pass = sum(1 for r in RESULTS if r[1] == "PASS")
+    n_abs = sum(1 for r in RESULTS if r[1] == "ABSENT")
+    if args.json:
+        import json
+        with open(args.json, "w") as f:
+            json.dump({"pass": n_pass, "diff": n_diff, "absent": n_abs,
+                       "lines": [{"section": a, "status": b, "text": c} for a, b, c in RESULTS]}, f, indent=1)
     print(f"parity_real_packages: {n_pass} PASS, {n_diff} DIFF, {n_abs} ABSENT")
     return 1 if (args.strict and n_diff) else 0
 
